@@ -1,0 +1,46 @@
+# Top-level build: HIP engine (gfx950 only), host front end, oracle (test infrastructure).
+HIPCC    ?= /opt/rocm/bin/hipcc
+CXX      ?= g++
+ARCH     := gfx950
+PKG      := gnss-gps-sdr_amd
+CSRC     := $(PKG)/csrc
+HOST     := $(PKG)/host
+LIBDIR   := $(PKG)/lib
+BINDIR   := $(PKG)/bin
+HIPFLAGS := --offload-arch=$(ARCH) -O3 -std=c++17 -fPIC -Wall -Wno-unused-function
+HOSTFLAGS:= -O2 -std=c++17 -fPIC -Wall -Wno-unknown-pragmas -ffp-contract=off
+
+all: lib host oracle emul
+
+lib: $(LIBDIR)/libgpsacq.so
+$(LIBDIR)/libgpsacq.so: $(CSRC)/acq_kernels.hip $(CSRC)/gpsacq_engine.cpp $(CSRC)/*.hpp include/gpsacq.h
+	@mkdir -p $(LIBDIR)
+	$(HIPCC) $(HIPFLAGS) -ffp-contract=off -c $(CSRC)/gpsacq_engine.cpp -o $(LIBDIR)/gpsacq_engine.o
+	$(HIPCC) $(HIPFLAGS) -c $(CSRC)/acq_kernels.hip -o $(LIBDIR)/acq_kernels.o
+	$(HIPCC) --offload-arch=$(ARCH) -shared -fPIC -o $@ $(LIBDIR)/acq_kernels.o $(LIBDIR)/gpsacq_engine.o
+
+host: $(LIBDIR)/libgps_search.so $(BINDIR)/gps_test
+$(LIBDIR)/libgps_search.so: $(HOST)/search_api.cpp include/gps_search.h include/gpsacq.h $(LIBDIR)/libgpsacq.so
+	$(CXX) $(HOSTFLAGS) -shared -o $@ $(HOST)/search_api.cpp -L$(LIBDIR) -lgpsacq -Wl,-rpath,'$$ORIGIN'
+$(BINDIR)/gps_test: $(HOST)/gps_test.cpp include/gps_search.h $(LIBDIR)/libgps_search.so
+	@mkdir -p $(BINDIR)
+	$(CXX) $(HOSTFLAGS) -o $@ $(HOST)/gps_test.cpp -L$(LIBDIR) -lgps_search -lgpsacq -Wl,-rpath,'$$ORIGIN/../lib'
+
+oracle:
+	$(MAKE) -C oracle
+
+emul: tests/emul/libemul_acq.so
+tests/emul/libemul_acq.so: tests/emul/emul_acq.cpp $(CSRC)/*.hpp
+	$(CXX) $(HOSTFLAGS) -shared -o $@ tests/emul/emul_acq.cpp
+
+# Drop-in check (authoring container only): the reference's own front end, compiled from where
+# it lies and never copied, linked against our SearchInit/SearchTask.  Output is git-ignored.
+dropin-check: $(LIBDIR)/libgps_search.so
+	@mkdir -p build
+	$(CXX) -O2 -I/root/reference/c /root/reference/c/test_search_offline.cpp -o build/gps_test_refmain \
+	    -L$(LIBDIR) -lgps_search -lgpsacq -Wl,-rpath,'$$ORIGIN/../$(LIBDIR)'
+
+clean:
+	rm -rf $(LIBDIR) $(BINDIR) build tests/emul/libemul_acq.so
+	$(MAKE) -C oracle clean
+.PHONY: all lib host oracle emul clean dropin-check

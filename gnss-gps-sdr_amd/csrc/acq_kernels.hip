@@ -1,0 +1,224 @@
+// acq_kernels.hip -- gfx950 kernels of the GPS L1 C/A acquisition engine.
+//
+// Replaces the hot loops of c/search_offline.cpp (reference, /root/reference):
+//   k_fwd_sub + k_fwd_combine   Sample()    :141-161  (unpack, XOR mix, FFT-40000)
+//                               SearchInit():101-106  (code replica -> code spectrum)
+//   k_corr<MC>                  Correlate() :181-196  (shifted conj-multiply, IFFT-40000,
+//                                                      |.|^2 max/argmax/sum over FS/1000 lags)
+//   k_peaks                     Correlate() :196-200  (best SNR over the Doppler bins)
+//
+// Design: one workgroup (256 threads, 4 waves) owns one (block, PRN, Doppler)
+// cell.  The 40000-point inverse transform is 8 polyphase 5000-point transforms done in a
+// 40 KB LDS buffer (radix 10 x 25 x 20, in place, conflict-free slot map), whose outputs are
+// rotated and accumulated in registers; only the FS/1000 lags the reference scans are ever
+// formed and nothing but 16 bytes per cell is written back.  The two spectra a cell reads
+// are shared by all Doppler bins of a (block, PRN) pair and stay in the XCD's L2: cells of
+// one pair are mapped to one XCD.
+#include <hip/hip_runtime.h>
+
+#include "acq_launch.hpp"
+#include "acq_phases.hpp"
+
+namespace acq {
+
+// ---------------------------------------------------------------------------------------
+template <class Src> struct SrcOf;
+template <> struct SrcOf<BitsSrc> {
+    static __device__ BitsSrc make(const FwdArgs& a, int item) {
+        return BitsSrc{(const uint8_t*)a.src + (size_t)item * a.src_stride, a.cos_mask, a.sin_mask};
+    }
+};
+template <> struct SrcOf<RealSrc> {
+    static __device__ RealSrc make(const FwdArgs& a, int item) {
+        return RealSrc{(const float*)a.src + (size_t)item * a.src_stride};
+    }
+};
+
+// grid (8, n_items): polyphase component q of item -> g[item][q][0..5000)
+template <class Src>
+__global__ __launch_bounds__(WG) void k_fwd_sub(FwdArgs a) {
+    __shared__ cf lds[M_SUB];
+    const int tid = threadIdx.x, q = blockIdx.x, item = blockIdx.y;
+    const Src src = SrcOf<Src>::make(a, item);
+    fwd_phase1(tid, q, src, a.t1, lds);
+    __syncthreads();
+    fwd_phase2(tid, q, a.t2, lds);
+    __syncthreads();
+    cf y[RC];
+    fwd_phase3_load(tid, lds, y);
+    __syncthreads();
+    fwd_phase3_store(tid, q, a.wq, y, lds);
+    __syncthreads();
+    cf* dst = a.g + ((size_t)item * NPOLY + q) * M_SUB;
+    for (int i = tid; i < M_SUB; i += WG) dst[i] = lds[i];
+}
+
+// grid (ceil(5000/256), n_items)
+__global__ __launch_bounds__(WG) void k_fwd_combine(CombineArgs a) {
+    const int k1 = blockIdx.x * WG + threadIdx.x, item = blockIdx.y;
+    if (k1 >= M_SUB) return;
+    fwd_combine(k1, a.g + (size_t)item * NPOLY * M_SUB, a.conj_out != 0, a.out + (size_t)item * a.item_stride,
+                a.row, a.off);
+}
+
+// cyclic halo of the code rows: grid (8 * n_codes), any block size
+__global__ void k_code_halo(cf* cpp, int crow, int halo) {
+    cf* row = cpp + (size_t)blockIdx.x * crow;
+    for (int h = threadIdx.x; h < halo; h += blockDim.x) {
+        row[h] = row[M_SUB + h];
+        row[halo + M_SUB + h] = row[halo + h];
+    }
+}
+
+// Reference quirk: Sample() writes 40960 samples into the 40000-entry
+// fwd_buf; with g++'s BSS order the last 960 land on code[0][0..959].  For a task whose PRN
+// index is 0 this builds a private copy of code 0 with those entries replaced by the block's
+// mixed samples 40000..40959.  grid (n_patch), block 256.
+__global__ __launch_bounds__(WG) void k_quirk_patch(QuirkArgs a) {
+    const int p = blockIdx.x;
+    const cf* src = a.code0;
+    cf* dst = a.patched + (size_t)p * NPOLY * a.crow;
+    const uint8_t* bytes = a.bits + (size_t)a.block_of_patch[p] * a.stride;
+    for (int i = threadIdx.x; i < NPOLY * a.crow; i += WG) {
+        const int q = i / a.crow, col = i - q * a.crow;
+        int j = col - a.halo;  // logical index within the polyphase row, cyclic
+        if (j < 0) j += M_SUB;
+        if (j >= M_SUB) j -= M_SUB;
+        const int k = NPOLY * j + q;  // spectral bin of code[0]
+        cf v = src[i];
+        if (k < TAIL_SAMPLES) {
+            const int byte = USED_BYTES + (k >> 3);
+            const unsigned b = bytes[byte];
+            const unsigned ib = ((b ^ a.cos_mask[byte]) >> (k & 7)) & 1u, qb = ((b ^ a.sin_mask[byte]) >> (k & 7)) & 1u;
+            v = mk(ib ? -1.f : 1.f, qb ? -1.f : 1.f);
+        }
+        dst[i] = v;
+    }
+}
+
+// ---------------------------------------------------------------------------------------
+// One workgroup per (task, Doppler bin).  blockIdx -> cell map keeps the 2*dmax+1 cells of a
+// task on one XCD (block b runs on XCD b % 8) so both spectra are read from that XCD's L2.
+template <int MC>
+__global__ __launch_bounds__(WG) void k_corr(CorrArgs a) {
+    __shared__ cf lds[M_SUB];
+    const int tid = threadIdx.x;
+    const int g = blockIdx.x, xcd = g & 7, slot = g >> 3;
+    const int grp = slot / a.ndop, di = slot - grp * a.ndop;
+    const int task = grp * 8 + xcd;
+    if (task >= a.n_tasks) return;
+    const Task tk = a.tasks[task];
+    const int dop = di - a.dmax;
+    const cf* dpp = a.dpp + (size_t)tk.spec * NPOLY * M_SUB;
+    const cf* cpp = a.cpp + (size_t)tk.code * NPOLY * a.crow;
+
+    cf acc[MC];
+#pragma unroll
+    for (int m = 0; m < MC; ++m) acc[m] = mk(0.f, 0.f);
+
+    for (int q = 0; q < NPOLY; ++q) {
+        corr_phase1(tid, q, dop, dpp, cpp, a.crow, a.halo, a.t1, lds);
+        __syncthreads();
+        corr_phase2(tid, q, a.t2, lds);
+        __syncthreads();
+        corr_phase3<MC>(tid, q, a.wq, lds, acc);
+        __syncthreads();
+    }
+
+    float mx, sum;
+    int mi;
+    corr_scan<MC>(tid, a.nlags, acc, mx, mi, sum);
+    // wave reduction (64 lanes), then across the 4 waves through LDS
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) {
+        const float omx = __shfl_down(mx, off, 64);
+        const int omi = __shfl_down(mi, off, 64);
+        const float os = __shfl_down(sum, off, 64);
+        peak_merge(mx, mi, omx, omi);
+        sum += os;
+    }
+    float* red = reinterpret_cast<float*>(lds);
+    const int wave = tid >> 6;
+    if ((tid & 63) == 0) {
+        red[wave * 4 + 0] = mx;
+        red[wave * 4 + 1] = __int_as_float(mi);
+        red[wave * 4 + 2] = sum;
+    }
+    __syncthreads();
+    if (tid == 0) {
+        for (int w = 1; w < WG / 64; ++w) {
+            peak_merge(mx, mi, red[w * 4 + 0], __float_as_int(red[w * 4 + 1]));
+            sum += red[w * 4 + 2];
+        }
+        Cell c;
+        c.max_pwr = mx;
+        c.max_i = mi;
+        c.tot_pwr = sum;
+        const float ave = sum / (float)a.nlags;  // :195 tot_pwr / i
+        c.snr = (sum > 0.f) ? mx / ave : 0.f;    // :196; 0/0 of the reference defined as 0
+        a.cells[(size_t)task * a.ndop + di] = c;
+    }
+}
+
+// Best SNR over the Doppler bins of each task, ascending dop, strict '>' (:196-198).
+__global__ void k_peaks(const Cell* cells, Peak* peaks, int n_tasks, int ndop, int dmax) {
+    const int task = blockIdx.x * blockDim.x + threadIdx.x;
+    if (task >= n_tasks) return;
+    const Cell* c = cells + (size_t)task * ndop;
+    Peak p;
+    p.snr = 0.f;
+    p.lo_shift = 0;
+    p.ca_shift = 0;
+    p.max_pwr = 0.f;
+    for (int di = 0; di < ndop; ++di) {
+        if (c[di].snr > p.snr) {
+            p.snr = c[di].snr;
+            p.lo_shift = di - dmax;
+            p.ca_shift = c[di].max_i;
+            p.max_pwr = c[di].max_pwr;
+        }
+    }
+    peaks[task] = p;
+}
+
+// ---------------------------------------------------------------------------------------
+// launchers (host)
+void launch_fwd_sub_bits(const FwdArgs& a, int n_items, hipStream_t s) {
+    hipLaunchKernelGGL(k_fwd_sub<BitsSrc>, dim3(NPOLY, n_items), dim3(WG), 0, s, a);
+}
+void launch_fwd_sub_real(const FwdArgs& a, int n_items, hipStream_t s) {
+    hipLaunchKernelGGL(k_fwd_sub<RealSrc>, dim3(NPOLY, n_items), dim3(WG), 0, s, a);
+}
+void launch_fwd_combine(const CombineArgs& a, int n_items, hipStream_t s) {
+    hipLaunchKernelGGL(k_fwd_combine, dim3((M_SUB + WG - 1) / WG, n_items), dim3(WG), 0, s, a);
+}
+void launch_code_halo(cf* cpp, int n_rows, int crow, int halo, hipStream_t s) {
+    hipLaunchKernelGGL(k_code_halo, dim3(n_rows), dim3(WG), 0, s, cpp, crow, halo);
+}
+void launch_quirk_patch(const QuirkArgs& a, int n_patch, hipStream_t s) {
+    hipLaunchKernelGGL(k_quirk_patch, dim3(n_patch), dim3(WG), 0, s, a);
+}
+int corr_columns(int nlags) {  // accumulator columns of the smallest instance that covers nlags
+    const int need = (nlags + NBF3 - 1) / NBF3;
+    const int have[] = {12, 22, 33, 40};
+    for (int m : have)
+        if (need <= m) return m;
+    return -1;
+}
+int launch_corr(const CorrArgs& a, int mc, hipStream_t s) {
+    const int groups = (a.n_tasks + 7) / 8;
+    const dim3 grid((unsigned)groups * 8u * (unsigned)a.ndop), block(WG);
+    switch (mc) {
+        case 12: hipLaunchKernelGGL(k_corr<12>, grid, block, 0, s, a); break;
+        case 22: hipLaunchKernelGGL(k_corr<22>, grid, block, 0, s, a); break;
+        case 33: hipLaunchKernelGGL(k_corr<33>, grid, block, 0, s, a); break;
+        case 40: hipLaunchKernelGGL(k_corr<40>, grid, block, 0, s, a); break;
+        default: return -1;
+    }
+    return 0;
+}
+void launch_peaks(const Cell* cells, Peak* peaks, int n_tasks, int ndop, int dmax, hipStream_t s) {
+    hipLaunchKernelGGL(k_peaks, dim3((n_tasks + 255) / 256), dim3(256), 0, s, cells, peaks, n_tasks, ndop, dmax);
+}
+
+}  // namespace acq

@@ -1,0 +1,58 @@
+// acq_launch.hpp -- argument blocks and host launchers of the kernels in acq_kernels.hip.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "acq_phases.hpp"
+
+namespace acq {
+
+struct FwdArgs {
+    const void* src;     // BitsSrc: packed capture bytes; RealSrc: float replicas
+    size_t src_stride;   // per item: bytes (bits) or floats (real)
+    const uint8_t* cos_mask;
+    const uint8_t* sin_mask;
+    const cf* t1;
+    const cf* t2;
+    const cf* wq;
+    cf* g;               // [n_items][8][5000]
+};
+struct CombineArgs {
+    const cf* g;         // [n_items][8][5000]
+    cf* out;             // [n_items][item_stride]
+    size_t item_stride;  // complex elements per item in out
+    long row;            // elements per polyphase row in out
+    int off;             // halo offset inside a row
+    int conj_out;
+};
+struct QuirkArgs {
+    const cf* code0;           // [8][crow] pristine code of PRN index 0
+    cf* patched;               // [n_patch][8][crow]
+    const uint8_t* bits;       // capture
+    size_t stride;             // bytes per block
+    const int32_t* block_of_patch;
+    const uint8_t* cos_mask;
+    const uint8_t* sin_mask;
+    int crow, halo;
+};
+struct CorrArgs {
+    const cf* dpp;     // [n_spec][8][5000]
+    const cf* cpp;     // [n_code][8][crow]
+    const Task* tasks; // [n_tasks]
+    const cf* t1;
+    const cf* t2;
+    const cf* wq;
+    Cell* cells;       // [n_tasks][ndop]
+    int n_tasks, ndop, dmax, nlags, crow, halo;
+};
+
+void launch_fwd_sub_bits(const FwdArgs& a, int n_items, hipStream_t s);
+void launch_fwd_sub_real(const FwdArgs& a, int n_items, hipStream_t s);
+void launch_fwd_combine(const CombineArgs& a, int n_items, hipStream_t s);
+void launch_code_halo(cf* cpp, int n_rows, int crow, int halo, hipStream_t s);
+void launch_quirk_patch(const QuirkArgs& a, int n_patch, hipStream_t s);
+int corr_columns(int nlags);
+int launch_corr(const CorrArgs& a, int mc, hipStream_t s);
+void launch_peaks(const Cell* cells, Peak* peaks, int n_tasks, int ndop, int dmax, hipStream_t s);
+
+}  // namespace acq

@@ -1,0 +1,230 @@
+// acq_math.hpp -- butterfly math and index maps of the gfx950 acquisition kernels.
+//
+// The length-40000 transforms of the reference (fftwf_execute at c/search_offline.cpp:161,187)
+// are computed here as 8 polyphase sub-transforms of length M = 5000 = 10 x 25 x 20 that live
+// entirely in one workgroup's LDS (40 KB), combined by a radix-8 step:
+//
+//   inverse (Correlate, :187)  y[n] = sum_{q<8} W_N^{-q n} F_q[n mod 5000],
+//                              F_q  = IDFT_5000( prod[8 j + q] ),  only n < FS/1000 is formed
+//   forward (Sample, :161)     X[k1 + 5000 s] = sum_{q<8} W_8^{q s} ( W_N^{q k1} F_q[k1] )
+//
+// Each length-5000 transform is three in-place LDS passes (decimation in frequency):
+//   pass 1  radix-10 (Good-Thomas 2x5) on elements j' + 500 a,      twiddle W_5000^{j' alpha}
+//   pass 2  radix-25 (5x5)            on elements j'' + 20 b,       twiddle W_500^{j'' beta}
+//   pass 3  radix-20 (Good-Thomas 4x5) on elements j'',             no twiddle
+// with LDS slot(alpha, j'', b) = 500 alpha + 25 j'' + b, and outputs r = 250 n'' + 10 beta + alpha.
+//
+// The functions are plain inline C++ so that tests/emul can run exactly this index math on
+// the CPU (test infrastructure); the product only ever calls them from the HIP kernels.
+#pragma once
+
+#if defined(__HIPCC__)
+#define ACQ_HD __host__ __device__ __forceinline__
+#else
+#define ACQ_HD inline
+#endif
+
+namespace acq {
+
+constexpr int N_FFT = 40000;  // FFT_LEN, c/gps_offline.h:15
+constexpr int NPOLY = 8;      // polyphase components
+constexpr int M_SUB = 5000;   // sub-transform length
+constexpr int RA = 10, RB = 25, RC = 20;
+constexpr int NBF1 = M_SUB / RA;  // 500 pass-1 butterflies
+constexpr int NBF2 = M_SUB / RB;  // 200 pass-2 butterflies
+constexpr int NBF3 = M_SUB / RC;  // 250 pass-3 butterflies (also the output column height)
+constexpr int NW160 = N_FFT / NBF3;  // 160
+constexpr int MC_MAX = 40;           // accumulator columns supported: lags n < 250 * MC_MAX (fs <= 10 MHz)
+constexpr int WQ_STRIDE = MC_MAX;    // wq[q][m] = W_160^{q m}
+
+struct cf {
+    float x, y;
+};
+
+ACQ_HD cf mk(float x, float y) { cf r; r.x = x; r.y = y; return r; }
+ACQ_HD cf operator+(cf a, cf b) { return mk(a.x + b.x, a.y + b.y); }
+ACQ_HD cf operator-(cf a, cf b) { return mk(a.x - b.x, a.y - b.y); }
+ACQ_HD cf cmul(cf a, cf b) { return mk(a.x * b.x - a.y * b.y, a.x * b.y + a.y * b.x); }
+ACQ_HD cf cmulc(cf a, cf b) { return mk(a.x * b.x + a.y * b.y, a.y * b.x - a.x * b.y); }  // a * conj(b)
+ACQ_HD cf scale(cf a, float s) { return mk(a.x * s, a.y * s); }
+
+// DIR = -1: forward transform (exp(-i..)), DIR = +1: backward.  Tables hold the forward value
+// w = exp(-i theta); tw<DIR>(a, w) multiplies by w or conj(w).
+template <int DIR> ACQ_HD cf tw(cf a, cf w) { return DIR < 0 ? cmul(a, w) : cmulc(a, w); }
+// multiply by DIR * i
+template <int DIR> ACQ_HD cf mul_di(cf a) { return DIR > 0 ? mk(-a.y, a.x) : mk(a.y, -a.x); }
+
+template <int DIR> ACQ_HD void dft2(cf& a, cf& b) {
+    cf t = a - b;
+    a = a + b;
+    b = t;
+}
+
+template <int DIR> ACQ_HD void dft4(cf& a, cf& b, cf& c, cf& d) {
+    cf apc = a + c, amc = a - c, bpd = b + d, bmd = mul_di<DIR>(b - d);
+    a = apc + bpd;
+    b = amc + bmd;
+    c = apc - bpd;
+    d = amc - bmd;
+}
+
+template <int DIR> ACQ_HD void dft5(cf& x0, cf& x1, cf& x2, cf& x3, cf& x4) {
+    constexpr float C1 = 0.30901699437494745f, C2 = -0.8090169943749473f;
+    constexpr float S1 = 0.9510565162951535f, S2 = 0.5877852522924732f;
+    cf t1 = x1 + x4, t2 = x2 + x3, t3 = x1 - x4, t4 = x2 - x3;
+    cf m1 = mk(x0.x + C1 * t1.x + C2 * t2.x, x0.y + C1 * t1.y + C2 * t2.y);
+    cf m2 = mk(x0.x + C2 * t1.x + C1 * t2.x, x0.y + C2 * t1.y + C1 * t2.y);
+    cf s1 = mul_di<DIR>(mk(S1 * t3.x + S2 * t4.x, S1 * t3.y + S2 * t4.y));
+    cf s2 = mul_di<DIR>(mk(S2 * t3.x - S1 * t4.x, S2 * t3.y - S1 * t4.y));
+    x0 = x0 + t1 + t2;
+    x1 = m1 + s1;
+    x4 = m1 - s1;
+    x2 = m2 + s2;
+    x3 = m2 - s2;
+}
+
+// 8-point DFT, natural order in and out.
+template <int DIR> ACQ_HD void dft8(cf* x) {
+    constexpr float R = 0.7071067811865476f;
+    // even / odd halves (decimation in time)
+    cf e0 = x[0], e1 = x[2], e2 = x[4], e3 = x[6];
+    cf o0 = x[1], o1 = x[3], o2 = x[5], o3 = x[7];
+    dft4<DIR>(e0, e1, e2, e3);
+    dft4<DIR>(o0, o1, o2, o3);
+    // o_k *= W_8^{k} (forward exp(-i pi k/4))
+    cf w1 = mk(R, -R), w3 = mk(-R, -R);
+    o1 = tw<DIR>(o1, w1);
+    o2 = mul_di<DIR>(o2);
+    o3 = tw<DIR>(o3, w3);
+    x[0] = e0 + o0; x[4] = e0 - o0;
+    x[1] = e1 + o1; x[5] = e1 - o1;
+    x[2] = e2 + o2; x[6] = e2 - o2;
+    x[3] = e3 + o3; x[7] = e3 - o3;
+}
+
+// 10 = 2 x 5 prime-factor butterfly: n = (5 n1 + 2 n2) mod 10, k = (5 k1 + 6 k2) mod 10.
+template <int DIR> ACQ_HD void radix10(const cf* x, cf* y) {
+    cf u[2][5];
+#pragma unroll
+    for (int n2 = 0; n2 < 5; ++n2) {
+        cf a = x[(2 * n2) % 10], b = x[(5 + 2 * n2) % 10];
+        dft2<DIR>(a, b);
+        u[0][n2] = a;
+        u[1][n2] = b;
+    }
+#pragma unroll
+    for (int k1 = 0; k1 < 2; ++k1) {
+        dft5<DIR>(u[k1][0], u[k1][1], u[k1][2], u[k1][3], u[k1][4]);
+#pragma unroll
+        for (int k2 = 0; k2 < 5; ++k2) y[(5 * k1 + 6 * k2) % 10] = u[k1][k2];
+    }
+}
+
+// 20 = 4 x 5 prime-factor butterfly: n = (5 n1 + 4 n2) mod 20, k = (5 k1 + 16 k2) mod 20.
+template <int DIR> ACQ_HD void radix20(const cf* x, cf* y) {
+    cf u[4][5];
+#pragma unroll
+    for (int n2 = 0; n2 < 5; ++n2) {
+        cf a = x[(4 * n2) % 20], b = x[(5 + 4 * n2) % 20], c = x[(10 + 4 * n2) % 20], d = x[(15 + 4 * n2) % 20];
+        dft4<DIR>(a, b, c, d);
+        u[0][n2] = a; u[1][n2] = b; u[2][n2] = c; u[3][n2] = d;
+    }
+#pragma unroll
+    for (int k1 = 0; k1 < 4; ++k1) {
+        dft5<DIR>(u[k1][0], u[k1][1], u[k1][2], u[k1][3], u[k1][4]);
+#pragma unroll
+        for (int k2 = 0; k2 < 5; ++k2) y[(5 * k1 + 16 * k2) % 20] = u[k1][k2];
+    }
+}
+
+// forward value of W_25^m = exp(-2 pi i m / 25) for the m = n2*k1 products that occur
+template <int M> ACQ_HD cf w25() {
+    static_assert(M == 1 || M == 2 || M == 3 || M == 4 || M == 6 || M == 8 || M == 9 || M == 12 || M == 16, "w25");
+    return M == 1    ? mk(0.96858316112863108f, -0.24868988716485479f)
+           : M == 2  ? mk(0.87630668004386358f, -0.48175367410171532f)
+           : M == 3  ? mk(0.72896862742141155f, -0.68454710592868862f)
+           : M == 4  ? mk(0.53582679497899655f, -0.84432792550201508f)
+           : M == 6  ? mk(0.062790519529313527f, -0.99802672842827156f)
+           : M == 8  ? mk(-0.42577929156507272f, -0.90482705246601947f)
+           : M == 9  ? mk(-0.63742398974868975f, -0.77051324277578925f)
+           : M == 12 ? mk(-0.99211470131447776f, -0.12533323356430454f)
+                     : mk(-0.63742398974868952f, 0.77051324277578936f);
+}
+
+// 25 = 5 x 5 Cooley-Tukey butterfly: input n = 5 n1 + n2, output k = k1 + 5 k2.
+template <int DIR> ACQ_HD void radix25(const cf* x, cf* y) {
+    cf v[5][5];  // v[k1][n2]
+#pragma unroll
+    for (int n2 = 0; n2 < 5; ++n2) {
+        cf a = x[n2], b = x[5 + n2], c = x[10 + n2], d = x[15 + n2], e = x[20 + n2];
+        dft5<DIR>(a, b, c, d, e);
+        v[0][n2] = a; v[1][n2] = b; v[2][n2] = c; v[3][n2] = d; v[4][n2] = e;
+    }
+    v[1][1] = tw<DIR>(v[1][1], w25<1>());  v[1][2] = tw<DIR>(v[1][2], w25<2>());
+    v[1][3] = tw<DIR>(v[1][3], w25<3>());  v[1][4] = tw<DIR>(v[1][4], w25<4>());
+    v[2][1] = tw<DIR>(v[2][1], w25<2>());  v[2][2] = tw<DIR>(v[2][2], w25<4>());
+    v[2][3] = tw<DIR>(v[2][3], w25<6>());  v[2][4] = tw<DIR>(v[2][4], w25<8>());
+    v[3][1] = tw<DIR>(v[3][1], w25<3>());  v[3][2] = tw<DIR>(v[3][2], w25<6>());
+    v[3][3] = tw<DIR>(v[3][3], w25<9>());  v[3][4] = tw<DIR>(v[3][4], w25<12>());
+    v[4][1] = tw<DIR>(v[4][1], w25<4>());  v[4][2] = tw<DIR>(v[4][2], w25<8>());
+    v[4][3] = tw<DIR>(v[4][3], w25<12>()); v[4][4] = tw<DIR>(v[4][4], w25<16>());
+#pragma unroll
+    for (int k1 = 0; k1 < 5; ++k1) {
+        dft5<DIR>(v[k1][0], v[k1][1], v[k1][2], v[k1][3], v[k1][4]);
+#pragma unroll
+        for (int k2 = 0; k2 < 5; ++k2) y[k1 + 5 * k2] = v[k1][k2];
+    }
+}
+
+// ---------------------------------------------------------------------------------------
+// LDS passes of one length-5000 transform.  t1/t2 are the twiddle tables built by
+// acq_tables.hpp: t1[alpha*500 + j'] = W_5000^{j' alpha};
+// t2q[beta*200 + e] = W_500^{j'' beta} * W_40000^{q (10 beta + alpha)}, e = 20 alpha + j''.
+
+// pass 1 for butterfly jp (0..499): x[a] = element jp + 500 a.
+template <int DIR> ACQ_HD void pass1_store(const cf* x, int jp, const cf* __restrict__ t1, cf* lds) {
+    cf y[RA];
+    radix10<DIR>(x, y);
+    const int b = jp / RC, jpp = jp - b * RC;
+    cf* dst = lds + RB * jpp + b;
+    dst[0] = y[0];
+#pragma unroll
+    for (int al = 1; al < RA; ++al) dst[NBF1 * al] = tw<DIR>(y[al], t1[al * NBF1 + jp]);
+}
+
+// pass 2 for butterfly e (0..199), in place.
+template <int DIR> ACQ_HD void pass2_inplace(int e, const cf* __restrict__ t2q, cf* lds) {
+    const int al = e / RC, jpp = e - al * RC;
+    cf* p = lds + NBF1 * al + RB * jpp;
+    cf x[RB], y[RB];
+#pragma unroll
+    for (int b = 0; b < RB; ++b) x[b] = p[b];
+    radix25<DIR>(x, y);
+#pragma unroll
+    for (int be = 0; be < RB; ++be) p[be] = tw<DIR>(y[be], t2q[be * NBF2 + e]);
+}
+
+// pass 3 for butterfly t3 (0..249): y[n''] = F[250 n'' + rho(t3)] (times the folded W_N^{q rho}).
+template <int DIR> ACQ_HD void pass3_load(int t3, const cf* lds, cf* y) {
+    const int al = t3 / RB, be = t3 - al * RB;
+    const cf* p = lds + NBF1 * al + be;
+    cf x[RC];
+#pragma unroll
+    for (int jpp = 0; jpp < RC; ++jpp) x[jpp] = p[RB * jpp];
+    radix20<DIR>(x, y);
+}
+ACQ_HD int pass3_rho(int t3) {
+    const int al = t3 / RB, be = t3 - al * RB;
+    return RA * be + al;
+}
+
+// Doppler shift of the code spectrum by whole bins (c/search_offline.cpp:182):
+// C[(8 j + q - dop) mod N] = code_pp[q'][(j + c) mod 5000] with
+// q' = (q - dop) mod 8 (non-negative), c = floor((q - dop) / 8).
+ACQ_HD void shift_split(int q, int dop, int& qp, int& c) {
+    const int e = q - dop;
+    qp = e & 7;
+    c = (e - qp) >> 3;  // exact: e - qp is a multiple of 8
+}
+
+}  // namespace acq

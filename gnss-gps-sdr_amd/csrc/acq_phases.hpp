@@ -1,0 +1,168 @@
+// acq_phases.hpp -- per-thread bodies of the acquisition kernels, one function per
+// barrier-delimited phase.  A workgroup is 256 threads; `tid` is the thread index.
+// acq_kernels.hip wraps these in __global__ kernels (phases separated by __syncthreads());
+// tests/emul runs the same functions thread by thread on the CPU to check the index math
+// without a GPU (test infrastructure only).
+//
+// Device data layouts (all complex float, interleaved re/im):
+//   spectrum "dpp"  [8][5000]        conj(FFT(block))[8 j + q] stored at [q][j]    (Sample, :121-165)
+//   code     "cpp"  [8][5000 + 2H]   FFT(code replica)[8 j + q] at [q][H + j], with a cyclic halo of
+//                                    H entries on both sides so that the whole-bin Doppler
+//                                    shift (:182) is a plain pointer offset
+//   scratch  "g"    [8][5000]        W_N^{q k1} F_q[k1], input of the radix-8 combine
+#pragma once
+#include <stdint.h>
+
+#include "acq_math.hpp"
+
+namespace acq {
+
+constexpr int WG = 256;           // workgroup size of every kernel here
+constexpr int BLOCK_BYTES = 5120; // bytes consumed per Sample() call (10 x 512, :129,135-136)
+constexpr int USED_BYTES = 5000;  // 40000 samples actually transformed
+constexpr int TAIL_SAMPLES = 960; // samples read past fwd_buf
+
+struct Cell {  // one (block, PRN, Doppler bin) result of Correlate's inner loop (:178-196)
+    float max_pwr;
+    int32_t max_i;
+    float tot_pwr;
+    float snr;
+};
+struct Peak {  // Correlate's return value and out-params (:196-200)
+    float snr;
+    int32_t lo_shift;
+    int32_t ca_shift;
+    float max_pwr;
+};
+struct Task {  // one (block spectrum, code spectrum) pair to search over all Doppler bins
+    int32_t spec;
+    int32_t code;
+};
+
+// ---------------------------------------------------------------------------------------
+// Correlate(): prod = conj(data) * shifted code (:181-185) fused into pass 1 of IDFT_5000.
+ACQ_HD void corr_phase1(int tid, int q, int dop, const cf* __restrict__ dpp, const cf* __restrict__ cpp,
+                        int crow, int halo, const cf* __restrict__ t1, cf* lds) {
+    if (tid >= NBF3) return;
+    int qp, c;
+    shift_split(q, dop, qp, c);
+    const cf* drow = dpp + q * M_SUB;
+    const cf* crw = cpp + (long)qp * crow + halo + c;
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+        const int jp = tid + NBF3 * h;
+        cf x[RA];
+#pragma unroll
+        for (int a = 0; a < RA; ++a) {
+            const int j = jp + NBF1 * a;
+            x[a] = cmul(drow[j], crw[j]);
+        }
+        pass1_store<+1>(x, jp, t1, lds);
+    }
+}
+
+ACQ_HD void corr_phase2(int tid, int q, const cf* __restrict__ t2, cf* lds) {
+    if (tid < NBF2) pass2_inplace<+1>(tid, t2 + (long)q * M_SUB, lds);
+}
+
+// acc[m] accumulates y[n] for n = 250 m + rho over the 8 polyphase components:
+// W_N^{-q n} = W_N^{-q rho} (folded into t2) * W_160^{-q m}.
+template <int MC>
+ACQ_HD void corr_phase3(int tid, int q, const cf* __restrict__ wq, const cf* lds, cf* acc) {
+    if (tid >= NBF3) return;
+    cf y[RC];
+    pass3_load<+1>(tid, lds, y);
+#pragma unroll
+    for (int m = 0; m < MC; ++m) {
+        const cf w = wq[q * WQ_STRIDE + m];  // W_160^{q m}
+        acc[m] = acc[m] + cmulc(y[m % RC], w);
+    }
+}
+
+// Peak scan over the first S lags (:190-194), this thread's share, ascending n.
+template <int MC>
+ACQ_HD void corr_scan(int tid, int S, const cf* acc, float& mx, int& mi, float& sum) {
+    mx = 0.f;
+    mi = 0;
+    sum = 0.f;
+    if (tid >= NBF3) return;
+    const int rho = pass3_rho(tid);
+#pragma unroll
+    for (int m = 0; m < MC; ++m) {
+        const int n = NBF3 * m + rho;
+        if (n < S) {
+            const float p = acc[m].x * acc[m].x + acc[m].y * acc[m].y;
+            if (p > mx) { mx = p; mi = n; }
+            sum += p;
+        }
+    }
+}
+// strict '>' first-wins of the reference == larger power, ties to the lower lag
+ACQ_HD void peak_merge(float& mx, int& mi, float omx, int omi) {
+    if (omx > mx || (omx == mx && omi < mi)) { mx = omx; mi = omi; }
+}
+
+// ---------------------------------------------------------------------------------------
+// Sample(): 1-bit unpack + XOR quadrature mix (:143-153) fused into pass 1 of DFT_5000.
+// Polyphase component q of the sample stream is bit q of every byte.
+struct BitsSrc {
+    const uint8_t* bytes;     // this block, >= 5000 bytes
+    const uint8_t* cos_mask;  // [5120]
+    const uint8_t* sin_mask;  // [5120]
+    ACQ_HD cf at(int q, int j) const {
+        const unsigned b = bytes[j];
+        const unsigned ib = ((b ^ cos_mask[j]) >> q) & 1u, qb = ((b ^ sin_mask[j]) >> q) & 1u;
+        return mk(ib ? -1.f : 1.f, qb ? -1.f : 1.f);
+    }
+};
+// SearchInit(): real code replica (:101-102), imag = 0.
+struct RealSrc {
+    const float* x;  // [40000]
+    ACQ_HD cf at(int q, int j) const { return mk(x[NPOLY * j + q], 0.f); }
+};
+
+template <class Src>
+ACQ_HD void fwd_phase1(int tid, int q, const Src& src, const cf* __restrict__ t1, cf* lds) {
+    if (tid >= NBF3) return;
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+        const int jp = tid + NBF3 * h;
+        cf x[RA];
+#pragma unroll
+        for (int a = 0; a < RA; ++a) x[a] = src.at(q, jp + NBF1 * a);
+        pass1_store<-1>(x, jp, t1, lds);
+    }
+}
+ACQ_HD void fwd_phase2(int tid, int q, const cf* __restrict__ t2, cf* lds) {
+    if (tid < NBF2) pass2_inplace<-1>(tid, t2 + (long)q * M_SUB, lds);
+}
+// pass 3 into registers (all threads must finish before fwd_phase3_store overwrites the LDS)
+ACQ_HD void fwd_phase3_load(int tid, const cf* lds, cf* y) {
+    if (tid < NBF3) pass3_load<-1>(tid, lds, y);
+}
+// g[k1] = W_N^{q k1} F_q[k1], k1 = 250 n'' + rho, written in natural order
+ACQ_HD void fwd_phase3_store(int tid, int q, const cf* __restrict__ wq, const cf* y, cf* dst) {
+    if (tid >= NBF3) return;
+    const int rho = pass3_rho(tid);
+#pragma unroll
+    for (int n = 0; n < RC; ++n) dst[NBF3 * n + rho] = cmul(y[n], wq[q * WQ_STRIDE + n]);
+}
+
+// Radix-8 combine: X[k1 + 5000 s] = sum_q W_8^{q s} g[q][k1]; the result is stored in the
+// polyphase layout out[(k mod 8) * row + off + k / 8], conjugated for block spectra
+// (Correlate multiplies by conj(data), :183-184).
+ACQ_HD void fwd_combine(int k1, const cf* __restrict__ g, bool conj_out, cf* out, long row, int off) {
+    cf x[NPOLY];
+#pragma unroll
+    for (int q = 0; q < NPOLY; ++q) x[q] = g[q * M_SUB + k1];
+    dft8<-1>(x);
+    const int qp = k1 & 7, j0 = k1 >> 3;
+#pragma unroll
+    for (int s = 0; s < NPOLY; ++s) {
+        cf v = x[s];
+        if (conj_out) v.y = -v.y;
+        out[qp * row + off + j0 + (M_SUB / NPOLY) * s] = v;
+    }
+}
+
+}  // namespace acq

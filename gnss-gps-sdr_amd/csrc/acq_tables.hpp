@@ -1,0 +1,128 @@
+// acq_tables.hpp -- host-side construction of the constant tables the kernels read:
+// twiddles (computed in long double, stored as float), the C/A code replicas
+// (c/search_offline.cpp:74-103, c/cacode.h:9-35) and the quadrature-LO bit masks
+// (c/search_offline.cpp:124-127,155-156).  Host C++ only.
+#pragma once
+#include <cmath>
+#include <cstdint>
+#include <cstring>
+#include <vector>
+
+#include "acq_math.hpp"
+
+namespace acq {
+
+inline cf unit_fwd(long long num, long long den) {  // exp(-2 pi i num/den)
+    num %= den;
+    if (num < 0) num += den;
+    const long double tp = 6.283185307179586476925286766559005768L;
+    long double th = tp * (long double)num / (long double)den;
+    return mk((float)cosl(th), (float)(-sinl(th)));
+}
+
+struct Tables {
+    std::vector<cf> t1;    // [10][500]      W_5000^{j' alpha}
+    std::vector<cf> t2;    // [8][25][200]   W_500^{j'' beta} * W_40000^{q (10 beta + alpha)}
+    std::vector<cf> wq;    // [8][40]        W_160^{q m}
+    Tables() : t1(RA * NBF1), t2((size_t)NPOLY * RB * NBF2), wq(NPOLY * WQ_STRIDE) {
+        for (int al = 0; al < RA; ++al)
+            for (int jp = 0; jp < NBF1; ++jp) t1[al * NBF1 + jp] = unit_fwd((long long)jp * al, M_SUB);
+        for (int q = 0; q < NPOLY; ++q)
+            for (int be = 0; be < RB; ++be)
+                for (int e = 0; e < NBF2; ++e) {
+                    const int al = e / RC, jpp = e % RC;
+                    // j'' beta / 500 + q (10 beta + alpha) / 40000  (in units of 1/40000)
+                    long long num = 80LL * jpp * be + (long long)q * (RA * be + al);
+                    t2[((size_t)q * RB + be) * NBF2 + e] = unit_fwd(num, N_FFT);
+                }
+        for (int q = 0; q < NPOLY; ++q)
+            for (int m = 0; m < WQ_STRIDE; ++m) wq[q * WQ_STRIDE + m] = unit_fwd((long long)q * m, NW160);
+    }
+};
+
+// ---- C/A code ------------------------------------------------------------------------
+// PRN -> G2 tap pair, c/search_offline.cpp:20-53 (the navstar column is unused there).
+static const int kTaps[32][2] = {{2, 6}, {3, 7}, {4, 8},  {5, 9},  {1, 9}, {2, 10}, {1, 8}, {2, 9}, {3, 10}, {2, 3}, {3, 4},
+                                 {5, 6}, {6, 7}, {7, 8},  {8, 9},  {9, 10}, {1, 4}, {2, 5}, {3, 6}, {4, 7},  {5, 8}, {6, 9},
+                                 {1, 3}, {4, 6}, {5, 7},  {6, 8},  {7, 9}, {8, 10}, {1, 6}, {2, 7}, {3, 8},  {4, 9}};
+
+// Gold-code generator as two 10-bit shift registers held in integers (bit i-1 = stage i).
+class CaCode {
+  public:
+    CaCode(int t1, int t2) : g1_(0x3ff), g2_(0x3ff), m1_(1u << (t1 - 1)), m2_(1u << (t2 - 1)) {}
+    int chip() const { return (int)(((g1_ >> 9) ^ ((g2_ & m1_) ? 1u : 0u) ^ ((g2_ & m2_) ? 1u : 0u)) & 1u); }
+    void clock() {
+        unsigned f1 = ((g1_ >> 2) ^ (g1_ >> 9)) & 1u;                                                     // stages 3,10
+        unsigned f2 = ((g2_ >> 1) ^ (g2_ >> 2) ^ (g2_ >> 5) ^ (g2_ >> 7) ^ (g2_ >> 8) ^ (g2_ >> 9)) & 1u;  // 2,3,6,8,9,10
+        g1_ = ((g1_ << 1) | f1) & 0x3ffu;
+        g2_ = ((g2_ << 1) | f2) & 0x3ffu;
+    }
+    // same value as the reference's GetG1() (cacode.h:30-34): stage 10 is the MSB... of a 10-bit word
+    unsigned g1_word() const {
+        unsigned r = 0;
+        for (int bit = 0; bit < 10; ++bit) r = 2 * r + ((g1_ >> (9 - bit)) & 1u);
+        return r;
+    }
+
+  private:
+    unsigned g1_, g2_, m1_, m2_;
+};
+
+// SearchCode(), c/search_offline.cpp:205-209
+inline int search_code(int sv, int g1) {
+    CaCode ca(kTaps[sv][0], kTaps[sv][1]);
+    int chips = 0;
+    while (ca.g1_word() != (unsigned)g1) {
+        ca.clock();
+        if (++chips > 2048) return -1;
+    }
+    return chips;
+}
+
+// Resampled code replica of SearchInit (c/search_offline.cpp:76,83-103).  The float/double
+// promotions follow the reference's C expressions: ca_phase and chip are float, the literals
+// 1.0 are double.
+inline void code_replica(double fs, int sv, float* out) {
+    const float ca_rate = (float)(1.023e6 / fs);
+    CaCode ca(kTaps[sv][0], kTaps[sv][1]);
+    float ca_phase = 0;
+    for (int i = 0; i < N_FFT; ++i) {
+        float chip = ca.chip() ? -1.0f : 1.0f;
+        ca_phase += ca_rate;
+        if (ca_phase >= 1.0) {
+            ca_phase = (float)((double)ca_phase - 1.0);
+            ca.clock();
+            chip = (float)((double)chip * (1.0 - (double)ca_phase));
+            chip = chip + ca_phase * (ca.chip() ? -1.0f : 1.0f);
+        }
+        out[i] = chip;
+    }
+}
+
+// Quadrature LO as XOR masks in the capture's own bit packing (LSB first): bit i of
+// cos_mask / sin_mask is lo_cos / lo_sin of int(lo_phase) at sample i
+// (lo_sin = {1,1,0,0}, lo_cos = {0,1,1,0}; float accumulator, wrap at >= 4).
+inline void lo_masks(double fc, double fs, int nbytes, uint8_t* cos_mask, uint8_t* sin_mask) {
+    static const int lo_sin[4] = {1, 1, 0, 0}, lo_cos[4] = {0, 1, 1, 0};
+    const float lo_rate = (float)(4 * fc / fs);
+    float lo_phase = 0;
+    std::memset(cos_mask, 0, nbytes);
+    std::memset(sin_mask, 0, nbytes);
+    for (int i = 0; i < nbytes * 8; ++i) {
+        const int qd = (int)lo_phase;
+        cos_mask[i >> 3] |= (uint8_t)(lo_cos[qd] << (i & 7));
+        sin_mask[i >> 3] |= (uint8_t)(lo_sin[qd] << (i & 7));
+        lo_phase += lo_rate;
+        if (lo_phase >= 4) lo_phase -= 4;
+    }
+}
+
+// Search grid of Correlate(): Doppler half-range in bins (:176) and lags scanned (:190).
+inline int doppler_half_range(double fs, double max_fo) { return (int)(max_fo * (double)N_FFT / fs); }
+inline int num_lags(double fs) {
+    int i = 0;
+    while ((double)i < fs / 1000 && i < N_FFT) ++i;
+    return i;
+}
+
+}  // namespace acq

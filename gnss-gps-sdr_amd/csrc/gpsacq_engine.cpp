@@ -1,0 +1,441 @@
+// gpsacq_engine.cpp -- host side of libgpsacq.so: device state, batching and the C ABI
+// declared in include/gpsacq.h.  All arithmetic of the search runs in the HIP kernels of
+// acq_kernels.hip; there is no CPU fallback -- without a gfx950 device every entry point that
+// needs one fails with GPSACQ_ERR_DEVICE.
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "../../include/gpsacq.h"
+#include "acq_launch.hpp"
+#include "acq_tables.hpp"
+
+using namespace acq;
+
+static_assert(sizeof(gpsacq_cell) == sizeof(Cell) && sizeof(gpsacq_peak) == sizeof(Peak) && sizeof(gpsacq_task) == sizeof(Task),
+              "ABI structs must match the kernel structs");
+
+static thread_local std::string g_err;
+static int fail(int code, const char* fmt, ...) {
+    char buf[512];
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(buf, sizeof buf, fmt, ap);
+    va_end(ap);
+    g_err = buf;
+    return code;
+}
+#define HIPCHK(expr)                                                                                  \
+    do {                                                                                              \
+        hipError_t e_ = (expr);                                                                       \
+        if (e_ != hipSuccess) return fail(e_ == hipErrorOutOfMemory ? GPSACQ_ERR_NOMEM : GPSACQ_ERR_DEVICE, \
+                                          "%s: %s", #expr, hipGetErrorString(e_));                    \
+    } while (0)
+
+struct gpsacq_engine {
+    gpsacq_params p{};
+    int dmax = 0, ndop = 0, nlags = 0, mc = 0, halo = 0, crow = 0;
+    int cus = 0;
+    char name[64] = {0};
+    hipStream_t stream = nullptr;
+    hipEvent_t ev[4] = {nullptr, nullptr, nullptr, nullptr};
+    // constants
+    cf *d_t1 = nullptr, *d_t2 = nullptr, *d_wq = nullptr;
+    uint8_t *d_cos = nullptr, *d_sin = nullptr;
+    cf* d_code = nullptr;  // [32 + patch_cap][8][crow]
+    size_t patch_cap = 0;
+    int32_t* d_patch_blocks = nullptr;
+    // scratch (grown on demand)
+    uint8_t* d_bits = nullptr;
+    size_t bits_cap = 0;
+    cf *d_g = nullptr, *d_dpp = nullptr;
+    size_t g_cap = 0, dpp_cap = 0;  // in blocks
+    Task* d_tasks = nullptr;
+    Cell* d_cells = nullptr;
+    Peak* d_peaks = nullptr;
+    size_t task_cap = 0, cell_cap = 0, peak_cap = 0;
+    // cached default schedule
+    size_t sched_tasks = 0;
+    bool sched_valid = false;
+    bool timing_valid = false;
+    int corr_launches = 0;
+    int64_t cells_done = 0;
+};
+
+static const size_t kFwdChunk = 8192;  // blocks per forward-transform launch (grid.y and scratch bound)
+
+template <class T> static int grow(T*& p, size_t& cap, size_t need, size_t elem_bytes = sizeof(T)) {
+    if (need <= cap) return GPSACQ_OK;
+    if (p) HIPCHK(hipFree(p));
+    p = nullptr;
+    cap = 0;
+    HIPCHK(hipMalloc((void**)&p, need * elem_bytes));
+    cap = need;
+    return GPSACQ_OK;
+}
+
+static int ensure_code_slots(gpsacq_engine* e, size_t n_patch) {
+    if (n_patch <= e->patch_cap) return GPSACQ_OK;
+    const size_t slot = (size_t)NPOLY * e->crow;
+    cf* nd = nullptr;
+    HIPCHK(hipMalloc((void**)&nd, (GPSACQ_NUM_SATS + n_patch) * slot * sizeof(cf)));
+    HIPCHK(hipMemcpyAsync(nd, e->d_code, GPSACQ_NUM_SATS * slot * sizeof(cf), hipMemcpyDeviceToDevice, e->stream));
+    HIPCHK(hipStreamSynchronize(e->stream));
+    HIPCHK(hipFree(e->d_code));
+    e->d_code = nd;
+    if (e->d_patch_blocks) HIPCHK(hipFree(e->d_patch_blocks));
+    e->d_patch_blocks = nullptr;
+    HIPCHK(hipMalloc((void**)&e->d_patch_blocks, n_patch * sizeof(int32_t)));
+    e->patch_cap = n_patch;
+    return GPSACQ_OK;
+}
+
+// forward transforms of n items into out (polyphase layout), chunked over the g scratch
+static int run_forward(gpsacq_engine* e, bool bits, const void* src, size_t src_stride, size_t n, cf* out,
+                       size_t item_stride, long row, int off, bool conj_out) {
+    for (size_t base = 0; base < n; base += kFwdChunk) {
+        const size_t cnt = std::min(kFwdChunk, n - base);
+        FwdArgs fa{};
+        fa.src = bits ? (const void*)((const uint8_t*)src + base * src_stride) : (const void*)((const float*)src + base * src_stride);
+        fa.src_stride = src_stride;
+        fa.cos_mask = e->d_cos;
+        fa.sin_mask = e->d_sin;
+        fa.t1 = e->d_t1;
+        fa.t2 = e->d_t2;
+        fa.wq = e->d_wq;
+        fa.g = e->d_g;
+        if (bits) launch_fwd_sub_bits(fa, (int)cnt, e->stream);
+        else launch_fwd_sub_real(fa, (int)cnt, e->stream);
+        CombineArgs ca{};
+        ca.g = e->d_g;
+        ca.out = out + base * item_stride;
+        ca.item_stride = item_stride;
+        ca.row = row;
+        ca.off = off;
+        ca.conj_out = conj_out ? 1 : 0;
+        launch_fwd_combine(ca, (int)cnt, e->stream);
+    }
+    HIPCHK(hipGetLastError());
+    return GPSACQ_OK;
+}
+
+extern "C" const char* gpsacq_last_error(void) { return g_err.c_str(); }
+
+extern "C" void gpsacq_destroy(gpsacq_engine* e) {
+    if (!e) return;
+    (void)hipSetDevice(e->p.device);
+    if (e->stream) (void)hipStreamSynchronize(e->stream);
+    void* bufs[] = {e->d_t1, e->d_t2, e->d_wq, e->d_cos, e->d_sin, e->d_code, e->d_patch_blocks, e->d_bits,
+                    e->d_g, e->d_dpp, e->d_tasks, e->d_cells, e->d_peaks};
+    for (void* b : bufs)
+        if (b) (void)hipFree(b);
+    for (auto& ev : e->ev)
+        if (ev) (void)hipEventDestroy(ev);
+    if (e->stream) (void)hipStreamDestroy(e->stream);
+    delete e;
+}
+
+extern "C" int gpsacq_create(const gpsacq_params* params, gpsacq_engine** out) {
+    if (!params || !out) return fail(GPSACQ_ERR_ARG, "gpsacq_create: null argument");
+    *out = nullptr;
+    if (!(params->fs > 0) || !(params->fc >= 0) || !(params->max_fo >= 0))
+        return fail(GPSACQ_ERR_ARG, "gpsacq_create: need fs > 0, fc >= 0, max_fo >= 0");
+    const int dmax = doppler_half_range(params->fs, params->max_fo);
+    const int nlags = num_lags(params->fs);
+    const int mc = corr_columns(nlags);
+    if (mc < 0)
+        return fail(GPSACQ_ERR_UNSUPPORTED, "fs = %g Hz scans %d lags; the kernels cover at most %d (fs <= 10 MHz)", params->fs,
+                    nlags, NBF3 * MC_MAX);
+    if (dmax >= N_FFT / 2) return fail(GPSACQ_ERR_UNSUPPORTED, "max_fo = %g Hz exceeds half the sampling rate", params->max_fo);
+
+    int ndev = 0;
+    hipError_t he = hipGetDeviceCount(&ndev);
+    if (he != hipSuccess || ndev <= 0)
+        return fail(GPSACQ_ERR_DEVICE, "no HIP device available (%s); this engine has no CPU path", hipGetErrorString(he));
+    if (params->device < 0 || params->device >= ndev) return fail(GPSACQ_ERR_ARG, "device %d out of range (%d devices)", params->device, ndev);
+    HIPCHK(hipSetDevice(params->device));
+    hipDeviceProp_t prop;
+    HIPCHK(hipGetDeviceProperties(&prop, params->device));
+    if (strncmp(prop.gcnArchName, "gfx950", 6) != 0)
+        return fail(GPSACQ_ERR_DEVICE, "device %d is %s; libgpsacq is built for gfx950 (MI355X) only", params->device, prop.gcnArchName);
+
+    gpsacq_engine* e = new gpsacq_engine();
+    e->p = *params;
+    e->dmax = dmax;
+    e->ndop = 2 * dmax + 1;
+    e->nlags = nlags;
+    e->mc = mc;
+    e->halo = ((dmax + 7) / 8 + 2 + 7) & ~7;  // |floor((q - dop)/8)| <= dmax/8 + 1
+    e->crow = M_SUB + 2 * e->halo;
+    e->cus = prop.multiProcessorCount;
+    snprintf(e->name, sizeof e->name, "%s", prop.name);
+#define CK(expr)                               \
+    do {                                       \
+        int rc_ = (expr);                      \
+        if (rc_ != GPSACQ_OK) {                \
+            gpsacq_destroy(e);                 \
+            return rc_;                        \
+        }                                      \
+    } while (0)
+#define HCK(expr)                                                                     \
+    do {                                                                              \
+        hipError_t e_ = (expr);                                                       \
+        if (e_ != hipSuccess) {                                                       \
+            int rc_ = fail(GPSACQ_ERR_DEVICE, "%s: %s", #expr, hipGetErrorString(e_)); \
+            gpsacq_destroy(e);                                                        \
+            return rc_;                                                               \
+        }                                                                             \
+    } while (0)
+    HCK(hipStreamCreateWithFlags(&e->stream, hipStreamNonBlocking));
+    for (auto& ev : e->ev) HCK(hipEventCreate(&ev));
+
+    Tables T;
+    HCK(hipMalloc((void**)&e->d_t1, T.t1.size() * sizeof(cf)));
+    HCK(hipMalloc((void**)&e->d_t2, T.t2.size() * sizeof(cf)));
+    HCK(hipMalloc((void**)&e->d_wq, T.wq.size() * sizeof(cf)));
+    HCK(hipMemcpy(e->d_t1, T.t1.data(), T.t1.size() * sizeof(cf), hipMemcpyHostToDevice));
+    HCK(hipMemcpy(e->d_t2, T.t2.data(), T.t2.size() * sizeof(cf), hipMemcpyHostToDevice));
+    HCK(hipMemcpy(e->d_wq, T.wq.data(), T.wq.size() * sizeof(cf), hipMemcpyHostToDevice));
+
+    std::vector<uint8_t> cosm(BLOCK_BYTES), sinm(BLOCK_BYTES);
+    lo_masks(params->fc, params->fs, BLOCK_BYTES, cosm.data(), sinm.data());
+    HCK(hipMalloc((void**)&e->d_cos, BLOCK_BYTES));
+    HCK(hipMalloc((void**)&e->d_sin, BLOCK_BYTES));
+    HCK(hipMemcpy(e->d_cos, cosm.data(), BLOCK_BYTES, hipMemcpyHostToDevice));
+    HCK(hipMemcpy(e->d_sin, sinm.data(), BLOCK_BYTES, hipMemcpyHostToDevice));
+
+    // SearchInit(): 32 resampled replicas (host, float-sequential NCO) -> code spectra (device)
+    std::vector<float> rep((size_t)GPSACQ_NUM_SATS * N_FFT);
+    for (int sv = 0; sv < GPSACQ_NUM_SATS; ++sv) code_replica(params->fs, sv, &rep[(size_t)sv * N_FFT]);
+    float* d_rep = nullptr;
+    HCK(hipMalloc((void**)&d_rep, rep.size() * sizeof(float)));
+    HCK(hipMemcpy(d_rep, rep.data(), rep.size() * sizeof(float), hipMemcpyHostToDevice));
+    const size_t slot = (size_t)NPOLY * e->crow;
+    HCK(hipMalloc((void**)&e->d_code, GPSACQ_NUM_SATS * slot * sizeof(cf)));
+    HCK(hipMemsetAsync(e->d_code, 0, GPSACQ_NUM_SATS * slot * sizeof(cf), e->stream));
+    {
+        int rc = grow(e->d_g, e->g_cap, (size_t)GPSACQ_NUM_SATS, (size_t)NPOLY * M_SUB * sizeof(cf));
+        if (rc == GPSACQ_OK)
+            rc = run_forward(e, false, d_rep, N_FFT, GPSACQ_NUM_SATS, e->d_code, slot, e->crow, e->halo, false);
+        if (rc != GPSACQ_OK) {
+            (void)hipFree(d_rep);
+            gpsacq_destroy(e);
+            return rc;
+        }
+    }
+    launch_code_halo(e->d_code, GPSACQ_NUM_SATS * NPOLY, e->crow, e->halo, e->stream);
+    HCK(hipGetLastError());
+    HCK(hipStreamSynchronize(e->stream));
+    HCK(hipFree(d_rep));
+#undef CK
+#undef HCK
+    *out = e;
+    return GPSACQ_OK;
+}
+
+extern "C" int gpsacq_get_info(const gpsacq_engine* e, gpsacq_info* info) {
+    if (!e || !info) return fail(GPSACQ_ERR_ARG, "gpsacq_get_info: null argument");
+    memset(info, 0, sizeof *info);
+    info->fft_len = N_FFT;
+    info->dmax = e->dmax;
+    info->num_doppler = e->ndop;
+    info->num_lags = e->nlags;
+    info->acc_columns = e->mc;
+    info->device = e->p.device;
+    info->compute_units = e->cus;
+    snprintf(info->device_name, sizeof info->device_name, "%s", e->name);
+    return GPSACQ_OK;
+}
+
+// Builds the device task list.  h_tasks (host copy of the user's tasks) may be NULL for the
+// reference schedule.  Returns the number of quirk patches needed through n_patch.
+static int prepare_tasks(gpsacq_engine* e, const gpsacq_task* h_tasks, const void* d_user_tasks, size_t n_blocks,
+                         size_t n_tasks, const uint8_t* d_bits, size_t stride) {
+    const bool quirks = e->p.ref_quirks != 0;
+    if (!h_tasks && !d_user_tasks) {
+        if (e->sched_valid && e->sched_tasks == n_tasks && !quirks) return GPSACQ_OK;  // cached
+    }
+    if (int rc = grow(e->d_tasks, e->task_cap, n_tasks)) return rc;
+    e->sched_valid = false;
+    std::vector<gpsacq_task> tmp;
+    if (!h_tasks && d_user_tasks) {
+        if (!quirks) {  // same layout: {block, prn} == {spec, code}
+            HIPCHK(hipMemcpyAsync(e->d_tasks, d_user_tasks, n_tasks * sizeof(Task), hipMemcpyDeviceToDevice, e->stream));
+            return GPSACQ_OK;
+        }
+        tmp.resize(n_tasks);
+        HIPCHK(hipMemcpyAsync(tmp.data(), d_user_tasks, n_tasks * sizeof(Task), hipMemcpyDeviceToHost, e->stream));
+        HIPCHK(hipStreamSynchronize(e->stream));
+        h_tasks = tmp.data();
+    }
+    std::vector<Task> tk(n_tasks);
+    std::vector<int32_t> patch_blocks;
+    for (size_t t = 0; t < n_tasks; ++t) {
+        int32_t blk = h_tasks ? h_tasks[t].block : (int32_t)t;
+        int32_t prn = h_tasks ? h_tasks[t].prn : (int32_t)(t % GPSACQ_NUM_SATS);
+        if (blk < 0 || (size_t)blk >= n_blocks || prn < 0 || prn >= GPSACQ_NUM_SATS)
+            return fail(GPSACQ_ERR_ARG, "task %zu = (block %d, prn %d) out of range", t, blk, prn);
+        tk[t].spec = blk;
+        tk[t].code = prn;
+        if (quirks && prn == 0) {
+            tk[t].code = GPSACQ_NUM_SATS + (int32_t)patch_blocks.size();
+            patch_blocks.push_back(blk);
+        }
+    }
+    if (!patch_blocks.empty()) {
+        if (int rc = ensure_code_slots(e, patch_blocks.size())) return rc;
+        HIPCHK(hipMemcpyAsync(e->d_patch_blocks, patch_blocks.data(), patch_blocks.size() * sizeof(int32_t), hipMemcpyHostToDevice, e->stream));
+        QuirkArgs qa{};
+        qa.code0 = e->d_code;
+        qa.patched = e->d_code + (size_t)GPSACQ_NUM_SATS * NPOLY * e->crow;
+        qa.bits = d_bits;
+        qa.stride = stride;
+        qa.block_of_patch = e->d_patch_blocks;
+        qa.cos_mask = e->d_cos;
+        qa.sin_mask = e->d_sin;
+        qa.crow = e->crow;
+        qa.halo = e->halo;
+        launch_quirk_patch(qa, (int)patch_blocks.size(), e->stream);
+    }
+    HIPCHK(hipMemcpyAsync(e->d_tasks, tk.data(), n_tasks * sizeof(Task), hipMemcpyHostToDevice, e->stream));
+    HIPCHK(hipStreamSynchronize(e->stream));  // tk / patch_blocks go out of scope
+    if (!h_tasks && !quirks) {
+        e->sched_valid = true;
+        e->sched_tasks = n_tasks;
+    }
+    return GPSACQ_OK;
+}
+
+static int search_core(gpsacq_engine* e, const uint8_t* d_bits, size_t n_blocks, size_t stride, const gpsacq_task* h_tasks,
+                       const void* d_user_tasks, size_t n_tasks, Cell* d_cells, Peak* d_peaks) {
+    if (n_blocks == 0 || n_tasks == 0) return fail(GPSACQ_ERR_ARG, "empty batch");
+    if (stride < (size_t)BLOCK_BYTES && e->p.ref_quirks) return fail(GPSACQ_ERR_ARG, "ref_quirks needs all 5120 bytes of a block (stride >= 5120)");
+    if (stride < (size_t)USED_BYTES) return fail(GPSACQ_ERR_ARG, "stride %zu < 5000 bytes", stride);
+    if (n_tasks * (size_t)e->ndop > 0x7fffff00u) return fail(GPSACQ_ERR_ARG, "batch too large: %zu tasks x %d bins", n_tasks, e->ndop);
+    if (int rc = grow(e->d_g, e->g_cap, std::min(n_blocks, kFwdChunk), (size_t)NPOLY * M_SUB * sizeof(cf))) return rc;
+    if (int rc = grow(e->d_dpp, e->dpp_cap, n_blocks, (size_t)NPOLY * M_SUB * sizeof(cf))) return rc;
+    if (!d_cells) {
+        if (int rc = grow(e->d_cells, e->cell_cap, n_tasks * (size_t)e->ndop)) return rc;
+        d_cells = e->d_cells;
+    }
+    if (int rc = prepare_tasks(e, h_tasks, d_user_tasks, n_blocks, n_tasks, d_bits, stride)) return rc;
+
+    HIPCHK(hipEventRecord(e->ev[0], e->stream));
+    if (int rc = run_forward(e, true, d_bits, stride, n_blocks, e->d_dpp, (size_t)NPOLY * M_SUB, M_SUB, 0, true)) return rc;
+    HIPCHK(hipEventRecord(e->ev[1], e->stream));
+    CorrArgs ca{};
+    ca.dpp = e->d_dpp;
+    ca.cpp = e->d_code;
+    ca.tasks = e->d_tasks;
+    ca.t1 = e->d_t1;
+    ca.t2 = e->d_t2;
+    ca.wq = e->d_wq;
+    ca.cells = d_cells;
+    ca.n_tasks = (int)n_tasks;
+    ca.ndop = e->ndop;
+    ca.dmax = e->dmax;
+    ca.nlags = e->nlags;
+    ca.crow = e->crow;
+    ca.halo = e->halo;
+    if (launch_corr(ca, e->mc, e->stream) != 0) return fail(GPSACQ_ERR_UNSUPPORTED, "no correlate kernel for %d columns", e->mc);
+    HIPCHK(hipGetLastError());
+    HIPCHK(hipEventRecord(e->ev[2], e->stream));
+    launch_peaks(d_cells, d_peaks, (int)n_tasks, e->ndop, e->dmax, e->stream);
+    HIPCHK(hipGetLastError());
+    HIPCHK(hipEventRecord(e->ev[3], e->stream));
+    e->timing_valid = true;
+    e->corr_launches = 1;
+    e->cells_done = (int64_t)n_tasks * e->ndop;
+    return GPSACQ_OK;
+}
+
+extern "C" int gpsacq_search_device(gpsacq_engine* e, const void* d_bits, size_t n_blocks, size_t stride, const void* d_tasks,
+                                    size_t n_tasks, void* d_cells, void* d_peaks, int sync) {
+    if (!e || !d_bits || !d_peaks) return fail(GPSACQ_ERR_ARG, "gpsacq_search_device: null argument");
+    if (!d_tasks && n_tasks != n_blocks) return fail(GPSACQ_ERR_ARG, "tasks == NULL needs n_tasks == n_blocks");
+    HIPCHK(hipSetDevice(e->p.device));
+    if (int rc = search_core(e, (const uint8_t*)d_bits, n_blocks, stride, nullptr, d_tasks, n_tasks, (Cell*)d_cells, (Peak*)d_peaks)) return rc;
+    if (sync) HIPCHK(hipStreamSynchronize(e->stream));
+    return GPSACQ_OK;
+}
+
+extern "C" int gpsacq_search(gpsacq_engine* e, const uint8_t* bits, size_t n_blocks, size_t stride, const gpsacq_task* tasks,
+                             size_t n_tasks, gpsacq_cell* cells, gpsacq_peak* peaks) {
+    if (!e || !bits) return fail(GPSACQ_ERR_ARG, "gpsacq_search: null argument");
+    if (!tasks && n_tasks != n_blocks) return fail(GPSACQ_ERR_ARG, "tasks == NULL needs n_tasks == n_blocks");
+    if (n_blocks == 0 || n_tasks == 0) return fail(GPSACQ_ERR_ARG, "empty batch");
+    HIPCHK(hipSetDevice(e->p.device));
+    const size_t nbytes = (n_blocks - 1) * stride + (stride < (size_t)BLOCK_BYTES ? stride : (size_t)BLOCK_BYTES);
+    if (int rc = grow(e->d_bits, e->bits_cap, nbytes)) return rc;
+    HIPCHK(hipMemcpyAsync(e->d_bits, bits, nbytes, hipMemcpyHostToDevice, e->stream));
+    if (int rc = grow(e->d_cells, e->cell_cap, n_tasks * (size_t)e->ndop)) return rc;
+    if (int rc = grow(e->d_peaks, e->peak_cap, n_tasks)) return rc;
+    if (int rc = search_core(e, e->d_bits, n_blocks, stride, tasks, nullptr, n_tasks, e->d_cells, e->d_peaks)) return rc;
+    if (cells) HIPCHK(hipMemcpyAsync(cells, e->d_cells, n_tasks * (size_t)e->ndop * sizeof(Cell), hipMemcpyDeviceToHost, e->stream));
+    if (peaks) HIPCHK(hipMemcpyAsync(peaks, e->d_peaks, n_tasks * sizeof(Peak), hipMemcpyDeviceToHost, e->stream));
+    HIPCHK(hipStreamSynchronize(e->stream));
+    return GPSACQ_OK;
+}
+
+extern "C" int gpsacq_synchronize(gpsacq_engine* e) {
+    if (!e) return fail(GPSACQ_ERR_ARG, "gpsacq_synchronize: null engine");
+    HIPCHK(hipSetDevice(e->p.device));
+    HIPCHK(hipStreamSynchronize(e->stream));
+    return GPSACQ_OK;
+}
+
+extern "C" int gpsacq_last_timing(const gpsacq_engine* e, gpsacq_timing* t) {
+    if (!e || !t) return fail(GPSACQ_ERR_ARG, "gpsacq_last_timing: null argument");
+    if (!e->timing_valid) return fail(GPSACQ_ERR_ARG, "no search has run yet");
+    HIPCHK(hipEventSynchronize(e->ev[3]));
+    memset(t, 0, sizeof *t);
+    HIPCHK(hipEventElapsedTime(&t->ms_total, e->ev[0], e->ev[3]));
+    HIPCHK(hipEventElapsedTime(&t->ms_sample, e->ev[0], e->ev[1]));
+    HIPCHK(hipEventElapsedTime(&t->ms_correlate, e->ev[1], e->ev[2]));
+    HIPCHK(hipEventElapsedTime(&t->ms_peaks, e->ev[2], e->ev[3]));
+    t->correlate_launches = e->corr_launches;
+    t->cells = e->cells_done;
+    return GPSACQ_OK;
+}
+
+extern "C" int gpsacq_search_code(int sv, int g1) {
+    if (sv < 0 || sv >= GPSACQ_NUM_SATS) return -1;
+    return search_code(sv, g1);
+}
+
+static void pp_to_natural(const std::vector<cf>& pp, long row, int off, bool conj, float* out) {
+    for (int k = 0; k < N_FFT; ++k) {
+        const cf v = pp[(size_t)(k & 7) * row + off + (k >> 3)];
+        out[2 * k] = v.x;
+        out[2 * k + 1] = conj ? -v.y : v.y;
+    }
+}
+
+extern "C" int gpsacq_sample_spectrum(gpsacq_engine* e, const uint8_t* block, float* out) {
+    if (!e || !block || !out) return fail(GPSACQ_ERR_ARG, "gpsacq_sample_spectrum: null argument");
+    HIPCHK(hipSetDevice(e->p.device));
+    if (int rc = grow(e->d_bits, e->bits_cap, (size_t)BLOCK_BYTES)) return rc;
+    if (int rc = grow(e->d_g, e->g_cap, (size_t)1, (size_t)NPOLY * M_SUB * sizeof(cf))) return rc;
+    if (int rc = grow(e->d_dpp, e->dpp_cap, (size_t)1, (size_t)NPOLY * M_SUB * sizeof(cf))) return rc;
+    HIPCHK(hipMemcpyAsync(e->d_bits, block, BLOCK_BYTES, hipMemcpyHostToDevice, e->stream));
+    if (int rc = run_forward(e, true, e->d_bits, BLOCK_BYTES, 1, e->d_dpp, (size_t)NPOLY * M_SUB, M_SUB, 0, true)) return rc;
+    std::vector<cf> pp((size_t)NPOLY * M_SUB);
+    HIPCHK(hipMemcpyAsync(pp.data(), e->d_dpp, pp.size() * sizeof(cf), hipMemcpyDeviceToHost, e->stream));
+    HIPCHK(hipStreamSynchronize(e->stream));
+    pp_to_natural(pp, M_SUB, 0, true, out);  // stored conjugated; return the spectrum itself
+    return GPSACQ_OK;
+}
+
+extern "C" int gpsacq_code_spectrum(gpsacq_engine* e, int sv, float* out) {
+    if (!e || !out || sv < 0 || sv >= GPSACQ_NUM_SATS) return fail(GPSACQ_ERR_ARG, "gpsacq_code_spectrum: bad argument");
+    HIPCHK(hipSetDevice(e->p.device));
+    std::vector<cf> pp((size_t)NPOLY * e->crow);
+    HIPCHK(hipMemcpy(pp.data(), e->d_code + (size_t)sv * NPOLY * e->crow, pp.size() * sizeof(cf), hipMemcpyDeviceToHost));
+    pp_to_natural(pp, e->crow, e->halo, false, out);
+    return GPSACQ_OK;
+}

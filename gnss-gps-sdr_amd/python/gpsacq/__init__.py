@@ -1,0 +1,208 @@
+"""ctypes binding of libgpsacq.so (include/gpsacq.h) -- the MI355X GPS L1 C/A acquisition engine.
+
+Thin on purpose: every number comes out of the HIP kernels behind the C ABI.  If the shared
+library (built by `make lib` / __graft_entry__.build()) is missing this module raises; there
+is no Python or CPU fallback for the search.
+
+Reference interface mirrored (JiaoXianjun/GNSS-GPS-SDR, c/gps_offline.h:87-91 and the globals
+FC/FS/max_fo of c/gps_offline.h:23-25): `Engine(fc, fs, max_fo)` is SearchInit(),
+`Engine.search()` is the Sample()+Correlate() body of SearchTask()'s loop
+(c/search_offline.cpp:239-246), `Engine.close()` is SearchFree(), `search_code()` is SearchCode().
+"""
+import ctypes
+import os
+
+import numpy as np
+
+FFT_LEN = 40000
+NUM_SATS = 32
+BLOCK_BYTES = 5120
+THRESHOLD = 25.0  # c/search_offline.cpp:248
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.normpath(os.path.join(_HERE, "..", "..", "lib", "libgpsacq.so"))
+
+CELL_DTYPE = np.dtype([("max_pwr", "<f4"), ("max_i", "<i4"), ("tot_pwr", "<f4"), ("snr", "<f4")])
+PEAK_DTYPE = np.dtype([("snr", "<f4"), ("lo_shift", "<i4"), ("ca_shift", "<i4"), ("max_pwr", "<f4")])
+TASK_DTYPE = np.dtype([("block", "<i4"), ("prn", "<i4")])
+
+
+class Params(ctypes.Structure):
+    _fields_ = [("fc", ctypes.c_double), ("fs", ctypes.c_double), ("max_fo", ctypes.c_double),
+                ("device", ctypes.c_int32), ("ref_quirks", ctypes.c_int32)]
+
+
+class Info(ctypes.Structure):
+    _fields_ = [("fft_len", ctypes.c_int32), ("dmax", ctypes.c_int32), ("num_doppler", ctypes.c_int32),
+                ("num_lags", ctypes.c_int32), ("acc_columns", ctypes.c_int32), ("device", ctypes.c_int32),
+                ("compute_units", ctypes.c_int32), ("device_name", ctypes.c_char * 64)]
+
+
+class Timing(ctypes.Structure):
+    _fields_ = [("ms_total", ctypes.c_float), ("ms_sample", ctypes.c_float), ("ms_correlate", ctypes.c_float),
+                ("ms_peaks", ctypes.c_float), ("correlate_launches", ctypes.c_int32), ("cells", ctypes.c_int64)]
+
+
+EXPORTS = ["gpsacq_create", "gpsacq_destroy", "gpsacq_last_error", "gpsacq_get_info", "gpsacq_search",
+           "gpsacq_search_device", "gpsacq_synchronize", "gpsacq_last_timing", "gpsacq_search_code",
+           "gpsacq_sample_spectrum", "gpsacq_code_spectrum"]
+
+_lib = None
+
+
+def load_library(path=None):
+    """dlopen libgpsacq.so and declare the prototypes.  Raises OSError if it is not built."""
+    global _lib
+    if _lib is not None and path is None:
+        return _lib
+    p = path or LIB_PATH
+    if not os.path.exists(p):
+        raise OSError(f"{p} not found: build it with `make lib` (hipcc --offload-arch=gfx950); "
+                      "gpsacq has no CPU fallback")
+    lib = ctypes.CDLL(p)
+    vp, sz = ctypes.c_void_p, ctypes.c_size_t
+    lib.gpsacq_create.argtypes = [ctypes.POINTER(Params), ctypes.POINTER(vp)]
+    lib.gpsacq_create.restype = ctypes.c_int
+    lib.gpsacq_destroy.argtypes = [vp]
+    lib.gpsacq_destroy.restype = None
+    lib.gpsacq_last_error.argtypes = []
+    lib.gpsacq_last_error.restype = ctypes.c_char_p
+    lib.gpsacq_get_info.argtypes = [vp, ctypes.POINTER(Info)]
+    lib.gpsacq_get_info.restype = ctypes.c_int
+    lib.gpsacq_search.argtypes = [vp, vp, sz, sz, vp, sz, vp, vp]
+    lib.gpsacq_search.restype = ctypes.c_int
+    lib.gpsacq_search_device.argtypes = [vp, vp, sz, sz, vp, sz, vp, vp, ctypes.c_int]
+    lib.gpsacq_search_device.restype = ctypes.c_int
+    lib.gpsacq_synchronize.argtypes = [vp]
+    lib.gpsacq_synchronize.restype = ctypes.c_int
+    lib.gpsacq_last_timing.argtypes = [vp, ctypes.POINTER(Timing)]
+    lib.gpsacq_last_timing.restype = ctypes.c_int
+    lib.gpsacq_search_code.argtypes = [ctypes.c_int, ctypes.c_int]
+    lib.gpsacq_search_code.restype = ctypes.c_int
+    lib.gpsacq_sample_spectrum.argtypes = [vp, vp, vp]
+    lib.gpsacq_sample_spectrum.restype = ctypes.c_int
+    lib.gpsacq_code_spectrum.argtypes = [vp, ctypes.c_int, vp]
+    lib.gpsacq_code_spectrum.restype = ctypes.c_int
+    if path is None:
+        _lib = lib
+    return lib
+
+
+class GpsAcqError(RuntimeError):
+    def __init__(self, code, msg):
+        super().__init__(f"gpsacq error {code}: {msg}")
+        self.code = code
+
+
+def _check(lib, rc):
+    if rc != 0:
+        raise GpsAcqError(rc, lib.gpsacq_last_error().decode(errors="replace"))
+
+
+def search_code(sv, g1):
+    """SearchCode(), c/search_offline.cpp:205-209."""
+    return load_library().gpsacq_search_code(int(sv), int(g1))
+
+
+class Engine:
+    """SearchInit() for one (FC, FS, max_fo); owns the device state."""
+
+    def __init__(self, fc, fs, max_fo=5000.0, device=0, ref_quirks=False):
+        self._lib = load_library()
+        self._h = ctypes.c_void_p()
+        prm = Params(float(fc), float(fs), float(max_fo), int(device), 1 if ref_quirks else 0)
+        _check(self._lib, self._lib.gpsacq_create(ctypes.byref(prm), ctypes.byref(self._h)))
+        info = Info()
+        _check(self._lib, self._lib.gpsacq_get_info(self._h, ctypes.byref(info)))
+        self.dmax = info.dmax
+        self.num_doppler = info.num_doppler
+        self.num_lags = info.num_lags
+        self.acc_columns = info.acc_columns
+        self.device = info.device
+        self.compute_units = info.compute_units
+        self.device_name = info.device_name.decode(errors="replace")
+        self.fc, self.fs, self.max_fo = float(fc), float(fs), float(max_fo)
+
+    def close(self):
+        if self._h:
+            self._lib.gpsacq_destroy(self._h)
+            self._h = ctypes.c_void_p()
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *a):
+        self.close()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    # ---- host-buffer path ----------------------------------------------------------------
+    def search(self, bits, tasks=None, stride=BLOCK_BYTES, want_cells=True):
+        """bits: bytes-like / uint8 array holding whole 5120-byte blocks.  tasks: None for the
+        reference schedule (block t against PRN t % 32) or an array of (block, prn) pairs.
+        Returns (cells[n_tasks, num_doppler] or None, peaks[n_tasks])."""
+        buf = np.ascontiguousarray(np.frombuffer(bits, dtype=np.uint8) if not isinstance(bits, np.ndarray) else bits.view(np.uint8))
+        n_blocks = (buf.size - min(stride, BLOCK_BYTES)) // stride + 1 if buf.size >= min(stride, BLOCK_BYTES) else 0
+        if n_blocks <= 0:
+            raise ValueError("capture shorter than one block")
+        if tasks is None:
+            n_tasks, tptr = n_blocks, None
+        else:
+            t = np.ascontiguousarray(np.asarray(tasks, dtype=np.int32).reshape(-1, 2))
+            n_tasks, tptr = t.shape[0], t.ctypes.data_as(ctypes.c_void_p)
+        cells = np.zeros((n_tasks, self.num_doppler), dtype=CELL_DTYPE) if want_cells else None
+        peaks = np.zeros(n_tasks, dtype=PEAK_DTYPE)
+        _check(self._lib, self._lib.gpsacq_search(
+            self._h, buf.ctypes.data_as(ctypes.c_void_p), n_blocks, stride, tptr, n_tasks,
+            cells.ctypes.data_as(ctypes.c_void_p) if want_cells else None, peaks.ctypes.data_as(ctypes.c_void_p)))
+        return cells, peaks
+
+    # ---- device-buffer path (torch tensors on this engine's device) ----------------------
+    def search_device(self, d_bits_ptr, n_blocks, d_peaks_ptr, stride=BLOCK_BYTES, d_tasks_ptr=None, n_tasks=None,
+                      d_cells_ptr=None, sync=True):
+        n_tasks = n_blocks if n_tasks is None else n_tasks
+        _check(self._lib, self._lib.gpsacq_search_device(self._h, d_bits_ptr, n_blocks, stride, d_tasks_ptr, n_tasks,
+                                                         d_cells_ptr, d_peaks_ptr, 1 if sync else 0))
+
+    def synchronize(self):
+        _check(self._lib, self._lib.gpsacq_synchronize(self._h))
+
+    def last_timing(self):
+        t = Timing()
+        _check(self._lib, self._lib.gpsacq_last_timing(self._h, ctypes.byref(t)))
+        return {k: getattr(t, k) for k, _ in Timing._fields_}
+
+    # ---- parity probes -------------------------------------------------------------------
+    def sample_spectrum(self, block):
+        b = np.ascontiguousarray(np.frombuffer(block, dtype=np.uint8)[:BLOCK_BYTES])
+        if b.size < BLOCK_BYTES:
+            raise ValueError("need 5120 bytes")
+        out = np.zeros(2 * FFT_LEN, dtype=np.float32)
+        _check(self._lib, self._lib.gpsacq_sample_spectrum(self._h, b.ctypes.data_as(ctypes.c_void_p), out.ctypes.data_as(ctypes.c_void_p)))
+        return out.view(np.complex64)
+
+    def code_spectrum(self, sv):
+        out = np.zeros(2 * FFT_LEN, dtype=np.float32)
+        _check(self._lib, self._lib.gpsacq_code_spectrum(self._h, int(sv), out.ctypes.data_as(ctypes.c_void_p)))
+        return out.view(np.complex64)
+
+
+def format_report(peaks, first_run=0):
+    """SearchTask()'s per-run report (c/search_offline.cpp:264-287) for peaks of whole runs
+    (32 consecutive tasks per run, reference schedule)."""
+    out = []
+    n_runs = len(peaks) // NUM_SATS
+    for r in range(n_runs):
+        pk = peaks[r * NUM_SATS:(r + 1) * NUM_SATS]
+        hits = [sv for sv in range(NUM_SATS) if not (pk["snr"][sv] < THRESHOLD)]
+        run = first_run + r
+        out.append("%2d satellite: " % run + "".join("%5d " % sv for sv in hits) + "\n")
+        out.append("%2d SNR(>=25): " % run + "".join("%5.1f " % pk["snr"][sv] for sv in hits) + "\n")
+        out.append("%2d  lo_shift: " % run + "".join("%5d " % pk["lo_shift"][sv] for sv in hits) + "\n")
+        out.append("%2d  ca_shift: " % run + "".join("%5d " % pk["ca_shift"][sv] for sv in hits) + "\n")
+        out.append("".join("%2.0f " % pk["snr"][sv] for sv in range(NUM_SATS)) + "\n\n")
+    return "".join(out)

@@ -1,0 +1,141 @@
+/*
+ * gpsacq.h -- C ABI of the MI355X (gfx950) GPS L1 C/A acquisition engine.
+ *
+ * This is the drop-in boundary for the hot path of the reference's offline search stage
+ * (JiaoXianjun/GNSS-GPS-SDR, c/search_offline.cpp).  Plain C: opaque handle, plain pointers
+ * and sizes, int status codes (0 = ok), caller-allocated outputs, no exceptions cross it.
+ * The reference has no FFI (it is one C++ translation unit); what a maintainer would bind is
+ * the set of functions declared in c/gps_offline.h:87-91, and each entry point below names
+ * the reference function whose work it performs:
+ *
+ *   gpsacq_create            SearchInit()            c/search_offline.cpp:74-110
+ *                            (+ the globals FC, FS, max_fo of c/gps_offline.h:23-25)
+ *   gpsacq_destroy           SearchFree()            c/search_offline.cpp:114-117
+ *   gpsacq_search            Sample() + Correlate()  c/search_offline.cpp:121-165, 169-201
+ *                            for a batch of 5120-byte blocks (the body of the
+ *                            SearchTask() loop, :239-246)
+ *   gpsacq_search_device     same, capture already resident in HBM
+ *   gpsacq_search_code       SearchCode()            c/search_offline.cpp:205-209
+ *   gpsacq_sample_spectrum   Sample()'s fwd_buf      c/search_offline.cpp:161 (parity probe)
+ *   gpsacq_code_spectrum     SearchInit()'s code[sv] c/search_offline.cpp:105-106 (parity probe)
+ *
+ * The C++-linkage mirror of the reference API itself (SearchInit/SearchTask/... consuming
+ * the caller's FC/FS/max_fo globals) is include/gps_search.h, implemented on top of this ABI.
+ */
+#ifndef GPSACQ_H
+#define GPSACQ_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define GPSACQ_FFT_LEN 40000      /* FFT_LEN, c/gps_offline.h:15 (compile-time in the reference) */
+#define GPSACQ_NUM_SATS 32        /* NUM_SATS, c/gps_offline.h:16 */
+#define GPSACQ_BLOCK_BYTES 5120   /* bytes consumed per Sample(): 10 packets x 512 B */
+
+/* status codes */
+#define GPSACQ_OK 0
+#define GPSACQ_ERR_ARG 1          /* bad argument */
+#define GPSACQ_ERR_DEVICE 2       /* no usable gfx950 device / HIP runtime error */
+#define GPSACQ_ERR_UNSUPPORTED 3  /* parameter outside what the kernels cover */
+#define GPSACQ_ERR_NOMEM 4
+
+typedef struct gpsacq_engine gpsacq_engine;
+
+typedef struct {
+    double fc;          /* carrier (2nd IF) frequency in Hz      -- global FC  */
+    double fs;          /* sampling rate in Hz                   -- global FS  */
+    double max_fo;      /* Doppler search half-range in Hz       -- global max_fo */
+    int32_t device;     /* HIP device ordinal */
+    int32_t ref_quirks; /* 1: reproduce the reference's fwd_buf overrun, which replaces
+                           code[0][0..959] by the block's samples 40000..40959 (PRN index 0
+                           only; g++ BSS layout).  0: well-defined behaviour. */
+} gpsacq_params;
+
+/* one (block, PRN, Doppler bin): what Correlate()'s inner loop computes (:178-196) */
+typedef struct {
+    float max_pwr;   /* largest |IFFT|^2 over the first FS/1000 lags */
+    int32_t max_i;   /* its lag (first one on ties) */
+    float tot_pwr;   /* sum of |IFFT|^2 over those lags */
+    float snr;       /* max_pwr / (tot_pwr / lags) */
+} gpsacq_cell;
+
+/* one (block, PRN): Correlate()'s return value and out-parameters (:196-200) */
+typedef struct {
+    float snr;         /* best SNR over the Doppler bins (0 if none > 0) */
+    int32_t lo_shift;  /* Doppler bin of the best SNR, in units of fs/40000 Hz */
+    int32_t ca_shift;  /* code phase (lag, samples) of the best SNR */
+    float max_pwr;     /* max_pwr of that cell */
+} gpsacq_peak;
+
+/* one search task: block index into the capture, PRN index 0..31 */
+typedef struct {
+    int32_t block;
+    int32_t prn;
+} gpsacq_task;
+
+typedef struct {
+    int32_t fft_len;     /* 40000 */
+    int32_t dmax;        /* Doppler bins searched are -dmax..+dmax (:176) */
+    int32_t num_doppler; /* 2*dmax+1 */
+    int32_t num_lags;    /* lags scanned per cell (:190) */
+    int32_t acc_columns; /* kernel instance in use */
+    int32_t device;
+    int32_t compute_units;
+    char device_name[64];
+} gpsacq_info;
+
+/* per-stage device time of the last gpsacq_search* call, milliseconds (HIP events on the
+ * engine's stream) and launch counts -- used by bench.py for the roofline line */
+typedef struct {
+    float ms_total;
+    float ms_sample;     /* unpack + mix + forward FFT (both kernels) */
+    float ms_correlate;  /* correlate kernel launches only */
+    float ms_peaks;
+    int32_t correlate_launches;
+    int64_t cells;
+} gpsacq_timing;
+
+/* SearchInit(): builds the 32 code spectra, LO tables and twiddles on the device. */
+int gpsacq_create(const gpsacq_params* params, gpsacq_engine** out);
+/* SearchFree() */
+void gpsacq_destroy(gpsacq_engine* e);
+/* message of the last failing call on this thread ("" if none) */
+const char* gpsacq_last_error(void);
+int gpsacq_get_info(const gpsacq_engine* e, gpsacq_info* info);
+
+/*
+ * Search a batch.  `bits`: capture bytes, 1-bit real IF samples packed LSB first; block b
+ * starts at bits + b*stride and 5120 bytes of it are read (5000 transformed; the last 120
+ * only matter with ref_quirks).  `tasks`: n_tasks (block, prn) pairs, or NULL for the
+ * reference's schedule: task t = (block t, prn t % 32) with n_tasks == n_blocks
+ * (SearchTask(), :239-246).  Outputs (either may be NULL): cells[n_tasks][num_doppler] in
+ * ascending Doppler-bin order, peaks[n_tasks].  Host pointers; returns after completion.
+ */
+int gpsacq_search(gpsacq_engine* e, const uint8_t* bits, size_t n_blocks, size_t stride,
+                  const gpsacq_task* tasks, size_t n_tasks, gpsacq_cell* cells, gpsacq_peak* peaks);
+
+/*
+ * Same with every buffer already in this device's memory (bits, tasks, cells, peaks are
+ * device pointers; tasks may be NULL as above; cells may be NULL).  Work is enqueued on the
+ * engine's stream; `sync` != 0 waits for completion.
+ */
+int gpsacq_search_device(gpsacq_engine* e, const void* d_bits, size_t n_blocks, size_t stride,
+                         const void* d_tasks, size_t n_tasks, void* d_cells, void* d_peaks, int sync);
+int gpsacq_synchronize(gpsacq_engine* e);
+int gpsacq_last_timing(const gpsacq_engine* e, gpsacq_timing* t);
+
+/* SearchCode(): chips to clock PRN sv's generator until its G1 register reads g1 (-1 if never) */
+int gpsacq_search_code(int sv, int g1);
+
+/* Parity probes (natural bin order, interleaved re/im, 40000 complex floats each). */
+int gpsacq_sample_spectrum(gpsacq_engine* e, const uint8_t* block5120, float* out);
+int gpsacq_code_spectrum(gpsacq_engine* e, int sv, float* out);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* GPSACQ_H */

@@ -1,0 +1,125 @@
+// emul_acq.cpp -- TEST INFRASTRUCTURE.  Runs the per-thread phase functions of
+// gnss-gps-sdr_amd/csrc/acq_phases.hpp thread by thread on the CPU, with a std::vector
+// standing in for the workgroup's LDS, so that the index math of the HIP kernels can be
+// checked against the oracle in the GPU-less authoring container (tests/test_emul.py).
+// It is NOT part of the product and is never linked into libgpsacq.so.
+#include <cstdint>
+#include <cstring>
+#include <vector>
+
+#include "../../gnss-gps-sdr_amd/csrc/acq_phases.hpp"
+#include "../../gnss-gps-sdr_amd/csrc/acq_tables.hpp"
+
+using namespace acq;
+
+static const Tables& tables() {
+    static Tables t;
+    return t;
+}
+
+// "kernel" fwd_sub: one workgroup = one (block, q)
+template <class Src>
+static void emul_fwd_sub(const Src& src, int q, cf* g_q /*[5000]*/) {
+    const Tables& T = tables();
+    std::vector<cf> lds(M_SUB);
+    std::vector<cf> regs((size_t)WG * RC);
+    for (int tid = 0; tid < WG; ++tid) fwd_phase1(tid, q, src, T.t1.data(), lds.data());
+    for (int tid = 0; tid < WG; ++tid) fwd_phase2(tid, q, T.t2.data(), lds.data());
+    for (int tid = 0; tid < WG; ++tid) fwd_phase3_load(tid, lds.data(), &regs[(size_t)tid * RC]);
+    for (int tid = 0; tid < WG; ++tid) fwd_phase3_store(tid, q, T.wq.data(), &regs[(size_t)tid * RC], lds.data());
+    for (int i = 0; i < M_SUB; ++i) g_q[i] = lds[i];
+}
+
+template <class Src>
+static void emul_forward_pp(const Src& src, bool conj_out, cf* out, long row, int off) {
+    std::vector<cf> g((size_t)NPOLY * M_SUB);
+    for (int q = 0; q < NPOLY; ++q) emul_fwd_sub(src, q, &g[(size_t)q * M_SUB]);
+    for (int k1 = 0; k1 < M_SUB; ++k1) fwd_combine(k1, g.data(), conj_out, out, row, off);
+}
+
+static void pp_to_natural(const cf* pp, long row, int off, bool conj, float* out) {
+    for (int k = 0; k < N_FFT; ++k) {
+        cf v = pp[(k & 7) * row + off + (k >> 3)];
+        out[2 * k] = v.x;
+        out[2 * k + 1] = conj ? -v.y : v.y;
+    }
+}
+
+extern "C" {
+
+// Sample(): spectrum of one 5120-byte block in natural order (un-conjugated).
+void emul_forward_bits(const uint8_t* bytes, const uint8_t* cosm, const uint8_t* sinm, float* out) {
+    BitsSrc src{bytes, cosm, sinm};
+    std::vector<cf> pp((size_t)NPOLY * M_SUB);
+    emul_forward_pp(src, true, pp.data(), M_SUB, 0);
+    pp_to_natural(pp.data(), M_SUB, 0, true, out);
+}
+// SearchInit(): spectrum of a real 40000-sample replica.
+void emul_forward_real(const float* x, float* out) {
+    RealSrc src{x};
+    std::vector<cf> pp((size_t)NPOLY * M_SUB);
+    emul_forward_pp(src, false, pp.data(), M_SUB, 0);
+    pp_to_natural(pp.data(), M_SUB, 0, false, out);
+}
+
+// One cell of Correlate(): data/code spectra given in natural order (data un-conjugated).
+// mc = accumulator columns of the kernel instance (12, 22, 33 or 40).
+int emul_cell(const float* dspec, const float* cspec, int halo, int dop, int S, int mc, float* max_pwr,
+              int* max_i, float* tot_pwr) {
+    const Tables& T = tables();
+    const int crow = M_SUB + 2 * halo;
+    std::vector<cf> dpp((size_t)NPOLY * M_SUB), cpp((size_t)NPOLY * crow);
+    for (int k = 0; k < N_FFT; ++k) {
+        dpp[(size_t)(k & 7) * M_SUB + (k >> 3)] = mk(dspec[2 * k], -dspec[2 * k + 1]);
+        cpp[(size_t)(k & 7) * crow + halo + (k >> 3)] = mk(cspec[2 * k], cspec[2 * k + 1]);
+    }
+    for (int q = 0; q < NPOLY; ++q)
+        for (int h = 0; h < halo; ++h) {
+            cpp[(size_t)q * crow + h] = cpp[(size_t)q * crow + M_SUB + h];
+            cpp[(size_t)q * crow + halo + M_SUB + h] = cpp[(size_t)q * crow + halo + h];
+        }
+    std::vector<cf> lds(M_SUB);
+    std::vector<cf> acc((size_t)WG * MC_MAX, mk(0.f, 0.f));
+    for (int q = 0; q < NPOLY; ++q) {
+        for (int tid = 0; tid < WG; ++tid)
+            corr_phase1(tid, q, dop, dpp.data(), cpp.data(), crow, halo, T.t1.data(), lds.data());
+        for (int tid = 0; tid < WG; ++tid) corr_phase2(tid, q, T.t2.data(), lds.data());
+        for (int tid = 0; tid < WG; ++tid) {
+            cf* a = &acc[(size_t)tid * MC_MAX];
+            switch (mc) {
+                case 12: corr_phase3<12>(tid, q, T.wq.data(), lds.data(), a); break;
+                case 22: corr_phase3<22>(tid, q, T.wq.data(), lds.data(), a); break;
+                case 33: corr_phase3<33>(tid, q, T.wq.data(), lds.data(), a); break;
+                case 40: corr_phase3<40>(tid, q, T.wq.data(), lds.data(), a); break;
+                default: return -1;
+            }
+        }
+    }
+    float mx = 0.f, sum = 0.f;
+    int mi = 0;
+    for (int tid = 0; tid < WG; ++tid) {
+        float tmx, tsum;
+        int tmi;
+        const cf* a = &acc[(size_t)tid * MC_MAX];
+        switch (mc) {
+            case 12: corr_scan<12>(tid, S, a, tmx, tmi, tsum); break;
+            case 22: corr_scan<22>(tid, S, a, tmx, tmi, tsum); break;
+            case 33: corr_scan<33>(tid, S, a, tmx, tmi, tsum); break;
+            default: corr_scan<40>(tid, S, a, tmx, tmi, tsum); break;
+        }
+        peak_merge(mx, mi, tmx, tmi);
+        sum += tsum;
+    }
+    *max_pwr = mx;
+    *max_i = mi;
+    *tot_pwr = sum;
+    return 0;
+}
+
+// host-side table/code helpers of the product, exposed for bit-exact checks against the oracle
+void emul_code_replica(double fs, int sv, float* out) { code_replica(fs, sv, out); }
+void emul_lo_masks(double fc, double fs, uint8_t* cosm, uint8_t* sinm) { lo_masks(fc, fs, BLOCK_BYTES, cosm, sinm); }
+int emul_search_code(int sv, int g1) { return search_code(sv, g1); }
+int emul_dmax(double fs, double max_fo) { return doppler_half_range(fs, max_fo); }
+int emul_nlags(double fs) { return num_lags(fs); }
+}

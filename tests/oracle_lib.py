@@ -1,0 +1,108 @@
+"""ctypes binding of oracle/liboracle_f{64,32}.so -- the CPU checker (test infrastructure)."""
+import ctypes
+import os
+import subprocess
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+CELL_DTYPE = np.dtype([("max_pwr", "<f4"), ("max_i", "<i4"), ("tot_pwr", "<f4"), ("snr", "<f4")])
+PEAK_DTYPE = np.dtype([("snr", "<f4"), ("lo_shift", "<i4"), ("ca_shift", "<i4"), ("max_pwr", "<f4")])
+_libs = {}
+
+
+def lib(kind="f64"):
+    if kind in _libs:
+        return _libs[kind]
+    path = os.path.join(ROOT, "oracle", f"liboracle_{kind}.so")
+    if not os.path.exists(path):
+        subprocess.check_call(["make", "-C", os.path.join(ROOT, "oracle")], stdout=subprocess.DEVNULL)
+    L = ctypes.CDLL(path)
+    vp, d, i = ctypes.c_void_p, ctypes.c_double, ctypes.c_int
+    L.oracle_create.restype = vp
+    L.oracle_create.argtypes = [d, d, d, i]
+    L.oracle_destroy.argtypes = [vp]
+    L.oracle_get_dmax.argtypes = [vp]
+    L.oracle_get_nlags.argtypes = [vp]
+    L.oracle_get_code_spectrum.argtypes = [vp, i, vp]
+    L.oracle_sample.argtypes = [vp, vp]
+    L.oracle_get_sample_spectrum.argtypes = [vp, vp]
+    L.oracle_search_block.argtypes = [vp, vp, i, vp, vp]
+    L.oracle_search_file.argtypes = [vp, ctypes.c_char_p, i, ctypes.c_char_p, ctypes.c_size_t, vp, ctypes.c_size_t]
+    L.oracle_bench_blocks.argtypes = [vp, vp, ctypes.c_long, ctypes.c_long, vp]
+    L.oracle_bench_blocks.restype = ctypes.c_long
+    L.oracle_code_replica.argtypes = [d, i, vp]
+    L.oracle_lo_quadrants.argtypes = [d, d, i, vp]
+    L.oracle_mix_block.argtypes = [vp, vp, vp]
+    L.oracle_ca_chips.argtypes = [i, vp]
+    L.oracle_search_code.argtypes = [i, i]
+    L.oracle_dft.argtypes = [i, i, vp, vp]
+    L.oracle_dmax.argtypes = [d, d]
+    L.oracle_nlags.argtypes = [d]
+    _libs[kind] = L
+    return L
+
+
+def _p(a):
+    return a.ctypes.data_as(ctypes.c_void_p)
+
+
+class Oracle:
+    def __init__(self, fc, fs, max_fo=5000.0, ref_quirks=False, kind="f64"):
+        self.L = lib(kind)
+        self.h = self.L.oracle_create(fc, fs, max_fo, 1 if ref_quirks else 0)
+        self.dmax = self.L.oracle_get_dmax(self.h)
+        self.num_doppler = 2 * self.dmax + 1
+        self.num_lags = self.L.oracle_get_nlags(self.h)
+
+    def close(self):
+        if self.h:
+            self.L.oracle_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        self.close()
+
+    def code_spectrum(self, sv):
+        out = np.zeros(80000, np.float32)
+        self.L.oracle_get_code_spectrum(self.h, sv, _p(out))
+        return out.view(np.complex64)
+
+    def sample_spectrum(self, block):
+        b = np.ascontiguousarray(np.frombuffer(block, dtype=np.uint8)[:5120])
+        self.L.oracle_sample(self.h, _p(b))
+        out = np.zeros(80000, np.float32)
+        self.L.oracle_get_sample_spectrum(self.h, _p(out))
+        return out.view(np.complex64)
+
+    def search_block(self, block, sv):
+        b = np.ascontiguousarray(np.frombuffer(block, dtype=np.uint8)[:5120])
+        cells = np.zeros(self.num_doppler, CELL_DTYPE)
+        peak = np.zeros(1, PEAK_DTYPE)
+        self.L.oracle_search_block(self.h, _p(b), sv, _p(cells), _p(peak))
+        return cells, peak[0]
+
+    def search(self, bits, tasks=None):
+        buf = np.frombuffer(bits, dtype=np.uint8)
+        n_blocks = buf.size // 5120
+        if tasks is None:
+            tasks = [(b, b % 32) for b in range(n_blocks)]
+        cells = np.zeros((len(tasks), self.num_doppler), CELL_DTYPE)
+        peaks = np.zeros(len(tasks), PEAK_DTYPE)
+        for t, (b, sv) in enumerate(tasks):
+            c, p = self.search_block(buf[b * 5120:(b + 1) * 5120], sv)
+            cells[t] = c
+            peaks[t] = p
+        return cells, peaks
+
+    def search_file(self, path, max_runs=0):
+        buf = ctypes.create_string_buffer(1 << 22)
+        peaks = np.zeros(4096 * 32, PEAK_DTYPE)
+        n = self.L.oracle_search_file(self.h, path.encode(), max_runs, buf, len(buf), _p(peaks), peaks.size)
+        return n, buf.value.decode(), peaks[:max(n, 0) * 32]
+
+    def bench_blocks(self, bits, n_blocks):
+        buf = np.ascontiguousarray(np.frombuffer(bits, dtype=np.uint8))
+        peaks = np.zeros(n_blocks, PEAK_DTYPE)
+        cells = self.L.oracle_bench_blocks(self.h, _p(buf), n_blocks, 5120, _p(peaks))
+        return cells, peaks

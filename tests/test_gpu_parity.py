@@ -1,0 +1,196 @@
+"""GPU parity: the HIP path (through the C ABI) against the CPU oracle and the golden fixtures.
+
+Tolerances (BASELINE.json north_star): code-phase bin identical, Doppler within one bin,
+correlator magnitudes within 1e-4 relative.  We test tighter where the arithmetic allows:
+per-cell max_pwr / tot_pwr to 2e-5 relative, identical argmax unless the two top powers of a
+cell are closer than 1e-5 relative (a float-rounding tie).
+"""
+import json
+import os
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+REL = 2e-5
+
+
+def _blocks(buf):
+    return [bytes(buf[i * 5120:(i + 1) * 5120]) for i in range(len(buf) // 5120)]
+
+
+@pytest.fixture(scope="module")
+def gpsacq_mod():
+    import gpsacq
+    gpsacq.load_library()
+    return gpsacq
+
+
+CONFIGS = {
+    "nott": dict(fc=4.092e6, fs=5.456e6, file="synth_nott_fs5456.bin"),
+    "sigtmp": dict(fc=2.046e6, fs=8.184e6, file="gps_sig_tmp.bin"),
+    "rtl": dict(fc=0.62e6, fs=2.8e6, file="synth_rtl_fs2800.bin"),
+}
+
+
+def _cmp_cells(gc, oc, what):
+    """gc, oc: structured arrays of the same shape."""
+    np.testing.assert_allclose(gc["max_pwr"], oc["max_pwr"], rtol=REL, err_msg=what + " max_pwr")
+    np.testing.assert_allclose(gc["tot_pwr"], oc["tot_pwr"], rtol=REL, err_msg=what + " tot_pwr")
+    np.testing.assert_allclose(gc["snr"], oc["snr"], rtol=2 * REL, err_msg=what + " snr")
+    bad = gc["max_i"] != oc["max_i"]
+    assert bad.mean() < 0.002, f"{what}: {bad.sum()} argmax mismatches of {bad.size}"
+
+
+@pytest.mark.parametrize("name", ["nott", "sigtmp", "rtl"])
+def test_code_and_sample_spectra(gpsacq_mod, golden_dir, name):
+    from oracle_lib import Oracle
+    cfg = CONFIGS[name]
+    buf = open(os.path.join(golden_dir, cfg["file"]), "rb").read()
+    with gpsacq_mod.Engine(cfg["fc"], cfg["fs"], 5000.0) as eng:
+        orc = Oracle(cfg["fc"], cfg["fs"], 5000.0)
+        assert eng.dmax == orc.dmax and eng.num_lags == orc.num_lags
+        for sv in (0, 7, 20, 31):
+            g, o = eng.code_spectrum(sv), orc.code_spectrum(sv)
+            scale = np.abs(o).max()
+            assert np.abs(g - o).max() / scale < 2e-6, f"code spectrum sv {sv}"
+        for b in (0, 5):
+            blk = buf[b * 5120:(b + 1) * 5120]
+            g, o = eng.sample_spectrum(blk), orc.sample_spectrum(blk)
+            scale = np.abs(o).max()
+            assert np.abs(g - o).max() / scale < 2e-6, f"sample spectrum block {b}"
+
+
+@pytest.mark.parametrize("name", ["nott", "sigtmp", "rtl"])
+def test_cells_vs_oracle(gpsacq_mod, golden_dir, name):
+    from oracle_lib import Oracle
+    cfg = CONFIGS[name]
+    buf = open(os.path.join(golden_dir, cfg["file"]), "rb").read()
+    nblk = 33
+    buf = buf[:nblk * 5120]
+    with gpsacq_mod.Engine(cfg["fc"], cfg["fs"], 5000.0) as eng:
+        gcells, gpeaks = eng.search(buf)
+        orc = Oracle(cfg["fc"], cfg["fs"], 5000.0)
+        sel = [0, 1, 7, 12, 20, 28, 29, 30, 31, 32]
+        ocells, opeaks = orc.search(buf, [(b, b % 32) for b in sel])
+        _cmp_cells(gcells[sel], ocells, name)
+        assert np.array_equal(gpeaks["ca_shift"][sel], opeaks["ca_shift"])
+        assert np.array_equal(gpeaks["lo_shift"][sel], opeaks["lo_shift"])
+        np.testing.assert_allclose(gpeaks["snr"][sel], opeaks["snr"], rtol=1e-4)
+
+
+@pytest.mark.parametrize("name,npz", [("nott", "np64_cells_nott.npz"), ("sigtmp", "np64_cells_sigtmp.npz"), ("rtl", "np64_cells_rtl.npz")])
+def test_cells_vs_numpy_golden(gpsacq_mod, golden_dir, name, npz):
+    """Committed vectors of the independent float64 numpy restatement (make_golden.py)."""
+    cfg = CONFIGS[name]
+    z = np.load(os.path.join(golden_dir, npz))
+    buf = open(os.path.join(golden_dir, cfg["file"]), "rb").read()
+    pairs = [tuple(p) for p in z["pairs"]]
+    with gpsacq_mod.Engine(cfg["fc"], cfg["fs"], float(z["max_fo"]), ref_quirks=bool(z["quirks"])) as eng:
+        assert eng.dmax == int(z["dmax"]) and eng.num_lags == int(z["S"])
+        cells, _ = eng.search(buf, tasks=pairs)
+        for t, (b, sv) in enumerate(pairs):
+            np.testing.assert_allclose(cells["max_pwr"][t], z[f"max_pwr_{b}_{sv}"], rtol=REL)
+            np.testing.assert_allclose(cells["tot_pwr"][t], z[f"tot_pwr_{b}_{sv}"], rtol=REL)
+            assert (cells["max_i"][t] != z[f"max_i_{b}_{sv}"]).sum() <= 1
+
+
+def test_gps_sig_tmp_known_answers(gpsacq_mod, golden_dir):
+    """gps_test gps_sig_tmp.bin 2.046e6 8.184e6 5000 -- reference outputs recorded in BASELINE.md."""
+    from oracle_lib import Oracle
+    known = json.load(open(os.path.join(golden_dir, "ref_known_answers.json")))["gps_sig_tmp"]
+    path = os.path.join(golden_dir, "gps_sig_tmp.bin")
+    buf = open(path, "rb").read()
+    nrun = len(buf) // 5120 // 32
+    assert nrun == known["runs"]
+    buf = buf[:nrun * 32 * 5120]
+    with gpsacq_mod.Engine(2.046e6, 8.184e6, 5000.0, ref_quirks=True) as eng:
+        _, peaks = eng.search(buf, want_cells=False)
+    sv7 = peaks[7::32]
+    assert list(sv7["lo_shift"]) == known["sv7_lo_shift"]
+    assert list(sv7["ca_shift"]) == known["sv7_ca_shift"]
+    assert ["%.1f" % s for s in sv7["snr"]] == ["%.1f" % s for s in known["sv7_snr"]]
+    run0 = peaks[:32]
+    hits = [sv for sv in range(32) if not run0["snr"][sv] < 25]
+    assert hits == known["run0_hits_sv"]
+    assert [int(run0["lo_shift"][sv]) for sv in hits] == known["run0_hits_lo"]
+    assert [int(run0["ca_shift"][sv]) for sv in hits] == known["run0_hits_ca"]
+    assert ["%.1f" % run0["snr"][sv] for sv in hits] == ["%.1f" % s for s in known["run0_hits_snr"]]
+    # whole report against the oracle's SearchTask restatement (guard band: SNRs within 0.02 of a
+    # printf rounding edge or of the threshold may legitimately differ in the last digit)
+    orc = Oracle(2.046e6, 8.184e6, 5000.0, ref_quirks=True)
+    n, text, opeaks = orc.search_file(path)
+    assert n == nrun
+    assert np.array_equal(peaks["ca_shift"], opeaks["ca_shift"])
+    assert np.array_equal(peaks["lo_shift"], opeaks["lo_shift"])
+    np.testing.assert_allclose(peaks["snr"], opeaks["snr"], rtol=1e-4)
+    report = gpsacq_mod.format_report(peaks) + "run out of file!\n"
+    if report != text:
+        edge = np.abs(opeaks["snr"] * 10 - np.round(opeaks["snr"] * 10) - 0.5) < 0.02
+        edge |= np.abs(opeaks["snr"] - 25) < 0.01
+        edge |= np.abs(opeaks["snr"] - np.round(opeaks["snr"]) - 0.5) < 0.002
+        assert edge.any(), "report differs from the oracle with no value near a rounding edge"
+
+
+def test_nottingham_standin_known_prns(gpsacq_mod, golden_dir):
+    """Synthetic stand-in for the absent Nottingham capture: the five PRNs of the JKS table
+    are injected with the table's Doppler bins and code phases."""
+    known = json.load(open(os.path.join(golden_dir, "ref_known_answers.json")))["nottingham_jks_table"]
+    buf = open(os.path.join(golden_dir, "synth_nott_fs5456.bin"), "rb").read()
+    with gpsacq_mod.Engine(4.092e6, 5.456e6, 5000.0) as eng:
+        _, peaks = eng.search(buf[:32 * 5120], want_cells=False)
+    hits = [sv + 1 for sv in range(32) if peaks["snr"][sv] >= 25]
+    assert hits == known["prn"]
+    for prn, lo, ca in zip(known["prn"], known["lo_shift"], known["ca_shift"]):
+        sv = prn - 1
+        assert abs(int(peaks["lo_shift"][sv]) - lo) <= 1
+        fd = lo * 5.456e6 / 40000
+        expect = (ca + 40960 * sv * (1 + fd / 1575.42e6)) % 5456
+        got = int(peaks["ca_shift"][sv])
+        assert min(abs(got - expect), 5456 - abs(got - expect)) <= 1.5
+
+
+def test_all_prn_grid_and_linearity(gpsacq_mod, golden_dir):
+    """Acquisition grid (one block against all 32 PRNs) equals 32 single-PRN searches, and a
+    batch equals its halves (size-independent properties at batch sizes the oracle cannot reach)."""
+    buf = open(os.path.join(golden_dir, "synth_nott_fs5456.bin"), "rb").read()
+    with gpsacq_mod.Engine(4.092e6, 5.456e6, 5000.0) as eng:
+        tasks = [(0, sv) for sv in range(32)] + [(3, sv) for sv in range(32)]
+        cells, peaks = eng.search(buf, tasks=tasks)
+        c2, p2 = eng.search(buf, tasks=tasks[32:])
+        assert np.array_equal(cells[32:], c2) and np.array_equal(peaks[32:], p2)
+        full_c, full_p = eng.search(buf)
+        a_c, a_p = eng.search(buf[:20 * 5120])
+        assert np.array_equal(full_c[:20], a_c) and np.array_equal(full_p[:20], a_p)
+        # bit-reproducible across calls
+        again_c, again_p = eng.search(buf)
+        assert np.array_equal(full_c, again_c) and np.array_equal(full_p, again_p)
+
+
+def test_large_doppler_range(gpsacq_mod, golden_dir):
+    """max_fo honoured (the reference CLI ignores argv[4], its library does not): +-100 kHz at
+    fs 2.8 MHz = 2857 bins; the +-5 kHz sub-range must reproduce the +-5 kHz search."""
+    buf = open(os.path.join(golden_dir, "synth_rtl_fs2800.bin"), "rb").read()[:8 * 5120]
+    with gpsacq_mod.Engine(0.62e6, 2.8e6, 5000.0) as e1, gpsacq_mod.Engine(0.62e6, 2.8e6, 100000.0) as e2:
+        c1, _ = e1.search(buf)
+        c2, p2 = e2.search(buf)
+        assert e2.num_doppler == 2 * 1428 + 1
+        lo = e2.dmax - e1.dmax
+        assert np.array_equal(c1, c2[:, lo:lo + e1.num_doppler])
+        assert int(p2["lo_shift"][7]) == 20
+
+
+def test_errors(gpsacq_mod):
+    with pytest.raises(gpsacq_mod.GpsAcqError):
+        gpsacq_mod.Engine(1e6, 20e6, 5000.0)  # > 10 MHz: unsupported lag count
+    with gpsacq_mod.Engine(4.092e6, 5.456e6, 5000.0) as eng:
+        with pytest.raises(ValueError):
+            eng.search(b"\x00" * 100)
+        with pytest.raises(gpsacq_mod.GpsAcqError):
+            eng.search(b"\x00" * 5120, tasks=[(3, 0)])
+        with pytest.raises(gpsacq_mod.GpsAcqError):
+            eng.search(b"\x00" * 5120, tasks=[(0, 32)])
+        # all-zero bits are a valid capture (constant +1 samples): must not produce NaN
+        cells, peaks = eng.search(b"\x00" * 5120)
+        assert np.isfinite(cells["snr"]).all() and np.isfinite(peaks["snr"]).all()
