@@ -108,7 +108,7 @@ __global__ __launch_bounds__(WG) void k_corr(CorrArgs a) {
     const int task = grp * 8 + xcd;
     if (task >= a.n_tasks) return;
     const Task tk = a.tasks[task];
-    const int dop = di - a.dmax;
+    const int dop = di + a.dop_first;
     const cf* dpp = a.dpp + (size_t)tk.spec * NPOLY * M_SUB;
     const cf* cpp = a.cpp + (size_t)tk.code * NPOLY * a.crow;
 
@@ -161,7 +161,7 @@ __global__ __launch_bounds__(WG) void k_corr(CorrArgs a) {
 }
 
 // Best SNR over the Doppler bins of each task, ascending dop, strict '>' (:196-198).
-__global__ void k_peaks(const Cell* cells, Peak* peaks, int n_tasks, int ndop, int dmax) {
+__global__ void k_peaks(const Cell* cells, Peak* peaks, int n_tasks, int ndop, int dop_first) {
     const int task = blockIdx.x * blockDim.x + threadIdx.x;
     if (task >= n_tasks) return;
     const Cell* c = cells + (size_t)task * ndop;
@@ -173,7 +173,7 @@ __global__ void k_peaks(const Cell* cells, Peak* peaks, int n_tasks, int ndop, i
     for (int di = 0; di < ndop; ++di) {
         if (c[di].snr > p.snr) {
             p.snr = c[di].snr;
-            p.lo_shift = di - dmax;
+            p.lo_shift = di + dop_first;
             p.ca_shift = c[di].max_i;
             p.max_pwr = c[di].max_pwr;
         }
@@ -217,8 +217,8 @@ int launch_corr(const CorrArgs& a, int mc, hipStream_t s) {
     }
     return 0;
 }
-void launch_peaks(const Cell* cells, Peak* peaks, int n_tasks, int ndop, int dmax, hipStream_t s) {
-    hipLaunchKernelGGL(k_peaks, dim3((n_tasks + 255) / 256), dim3(256), 0, s, cells, peaks, n_tasks, ndop, dmax);
+void launch_peaks(const Cell* cells, Peak* peaks, int n_tasks, int ndop, int dop_first, hipStream_t s) {
+    hipLaunchKernelGGL(k_peaks, dim3((n_tasks + 255) / 256), dim3(256), 0, s, cells, peaks, n_tasks, ndop, dop_first);
 }
 
 }  // namespace acq

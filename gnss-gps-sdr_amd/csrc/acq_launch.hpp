@@ -43,7 +43,7 @@ struct CorrArgs {
     const cf* t2;
     const cf* wq;
     Cell* cells;       // [n_tasks][ndop]
-    int n_tasks, ndop, dmax, nlags, crow, halo;
+    int n_tasks, ndop, dop_first, nlags, crow, halo;  // bins dop_first .. dop_first+ndop-1
 };
 
 void launch_fwd_sub_bits(const FwdArgs& a, int n_items, hipStream_t s);
@@ -53,6 +53,6 @@ void launch_code_halo(cf* cpp, int n_rows, int crow, int halo, hipStream_t s);
 void launch_quirk_patch(const QuirkArgs& a, int n_patch, hipStream_t s);
 int corr_columns(int nlags);
 int launch_corr(const CorrArgs& a, int mc, hipStream_t s);
-void launch_peaks(const Cell* cells, Peak* peaks, int n_tasks, int ndop, int dmax, hipStream_t s);
+void launch_peaks(const Cell* cells, Peak* peaks, int n_tasks, int ndop, int dop_first, hipStream_t s);
 
 }  // namespace acq

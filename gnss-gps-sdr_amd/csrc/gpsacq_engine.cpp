@@ -39,7 +39,7 @@ static int fail(int code, const char* fmt, ...) {
 
 struct gpsacq_engine {
     gpsacq_params p{};
-    int dmax = 0, ndop = 0, nlags = 0, mc = 0, halo = 0, crow = 0;
+    int dmax = 0, ndop = 0, dop_first = 0, nlags = 0, mc = 0, halo = 0, crow = 0;  // searched bins: dop_first .. +ndop-1
     int cus = 0;
     char name[64] = {0};
     hipStream_t stream = nullptr;
@@ -168,6 +168,7 @@ extern "C" int gpsacq_create(const gpsacq_params* params, gpsacq_engine** out) {
     e->p = *params;
     e->dmax = dmax;
     e->ndop = 2 * dmax + 1;
+    e->dop_first = -dmax;
     e->nlags = nlags;
     e->mc = mc;
     e->halo = ((dmax + 7) / 8 + 2 + 7) & ~7;  // |floor((q - dop)/8)| <= dmax/8 + 1
@@ -244,6 +245,7 @@ extern "C" int gpsacq_get_info(const gpsacq_engine* e, gpsacq_info* info) {
     info->fft_len = N_FFT;
     info->dmax = e->dmax;
     info->num_doppler = e->ndop;
+    info->first_doppler = e->dop_first;
     info->num_lags = e->nlags;
     info->acc_columns = e->mc;
     info->device = e->p.device;
@@ -338,14 +340,14 @@ static int search_core(gpsacq_engine* e, const uint8_t* d_bits, size_t n_blocks,
     ca.cells = d_cells;
     ca.n_tasks = (int)n_tasks;
     ca.ndop = e->ndop;
-    ca.dmax = e->dmax;
+    ca.dop_first = e->dop_first;
     ca.nlags = e->nlags;
     ca.crow = e->crow;
     ca.halo = e->halo;
     if (launch_corr(ca, e->mc, e->stream) != 0) return fail(GPSACQ_ERR_UNSUPPORTED, "no correlate kernel for %d columns", e->mc);
     HIPCHK(hipGetLastError());
     HIPCHK(hipEventRecord(e->ev[2], e->stream));
-    launch_peaks(d_cells, d_peaks, (int)n_tasks, e->ndop, e->dmax, e->stream);
+    launch_peaks(d_cells, d_peaks, (int)n_tasks, e->ndop, e->dop_first, e->stream);
     HIPCHK(hipGetLastError());
     HIPCHK(hipEventRecord(e->ev[3], e->stream));
     e->timing_valid = true;
@@ -379,6 +381,15 @@ extern "C" int gpsacq_search(gpsacq_engine* e, const uint8_t* bits, size_t n_blo
     if (cells) HIPCHK(hipMemcpyAsync(cells, e->d_cells, n_tasks * (size_t)e->ndop * sizeof(Cell), hipMemcpyDeviceToHost, e->stream));
     if (peaks) HIPCHK(hipMemcpyAsync(peaks, e->d_peaks, n_tasks * sizeof(Peak), hipMemcpyDeviceToHost, e->stream));
     HIPCHK(hipStreamSynchronize(e->stream));
+    return GPSACQ_OK;
+}
+
+extern "C" int gpsacq_set_doppler_window(gpsacq_engine* e, int first_bin, int n_bins) {
+    if (!e) return fail(GPSACQ_ERR_ARG, "gpsacq_set_doppler_window: null engine");
+    if (n_bins <= 0 || first_bin < -e->dmax || first_bin + n_bins - 1 > e->dmax)
+        return fail(GPSACQ_ERR_ARG, "Doppler window [%d, %d] outside [-%d, %d]", first_bin, first_bin + n_bins - 1, e->dmax, e->dmax);
+    e->dop_first = first_bin;
+    e->ndop = n_bins;
     return GPSACQ_OK;
 }
 

@@ -34,7 +34,7 @@ class Params(ctypes.Structure):
 
 class Info(ctypes.Structure):
     _fields_ = [("fft_len", ctypes.c_int32), ("dmax", ctypes.c_int32), ("num_doppler", ctypes.c_int32),
-                ("num_lags", ctypes.c_int32), ("acc_columns", ctypes.c_int32), ("device", ctypes.c_int32),
+                ("first_doppler", ctypes.c_int32), ("num_lags", ctypes.c_int32), ("acc_columns", ctypes.c_int32), ("device", ctypes.c_int32),
                 ("compute_units", ctypes.c_int32), ("device_name", ctypes.c_char * 64)]
 
 
@@ -44,7 +44,7 @@ class Timing(ctypes.Structure):
 
 
 EXPORTS = ["gpsacq_create", "gpsacq_destroy", "gpsacq_last_error", "gpsacq_get_info", "gpsacq_search",
-           "gpsacq_search_device", "gpsacq_synchronize", "gpsacq_last_timing", "gpsacq_search_code",
+           "gpsacq_search_device", "gpsacq_set_doppler_window", "gpsacq_synchronize", "gpsacq_last_timing", "gpsacq_search_code",
            "gpsacq_sample_spectrum", "gpsacq_code_spectrum"]
 
 _lib = None
@@ -73,6 +73,8 @@ def load_library(path=None):
     lib.gpsacq_search.restype = ctypes.c_int
     lib.gpsacq_search_device.argtypes = [vp, vp, sz, sz, vp, sz, vp, vp, ctypes.c_int]
     lib.gpsacq_search_device.restype = ctypes.c_int
+    lib.gpsacq_set_doppler_window.argtypes = [vp, ctypes.c_int, ctypes.c_int]
+    lib.gpsacq_set_doppler_window.restype = ctypes.c_int
     lib.gpsacq_synchronize.argtypes = [vp]
     lib.gpsacq_synchronize.restype = ctypes.c_int
     lib.gpsacq_last_timing.argtypes = [vp, ctypes.POINTER(Timing)]
@@ -112,16 +114,25 @@ class Engine:
         self._h = ctypes.c_void_p()
         prm = Params(float(fc), float(fs), float(max_fo), int(device), 1 if ref_quirks else 0)
         _check(self._lib, self._lib.gpsacq_create(ctypes.byref(prm), ctypes.byref(self._h)))
+        self._refresh_info()
+        self.fc, self.fs, self.max_fo = float(fc), float(fs), float(max_fo)
+
+    def _refresh_info(self):
         info = Info()
         _check(self._lib, self._lib.gpsacq_get_info(self._h, ctypes.byref(info)))
         self.dmax = info.dmax
         self.num_doppler = info.num_doppler
+        self.first_doppler = info.first_doppler
         self.num_lags = info.num_lags
         self.acc_columns = info.acc_columns
         self.device = info.device
         self.compute_units = info.compute_units
         self.device_name = info.device_name.decode(errors="replace")
-        self.fc, self.fs, self.max_fo = float(fc), float(fs), float(max_fo)
+
+    def set_doppler_window(self, first_bin, n_bins):
+        """Search only bins first_bin .. first_bin+n_bins-1 (multi-GPU Doppler-slab sharding)."""
+        _check(self._lib, self._lib.gpsacq_set_doppler_window(self._h, int(first_bin), int(n_bins)))
+        self._refresh_info()
 
     def close(self):
         if self._h:

@@ -80,7 +80,8 @@ typedef struct {
 typedef struct {
     int32_t fft_len;     /* 40000 */
     int32_t dmax;        /* Doppler bins searched are -dmax..+dmax (:176) */
-    int32_t num_doppler; /* 2*dmax+1 */
+    int32_t num_doppler; /* bins searched per task: 2*dmax+1 unless a window is set */
+    int32_t first_doppler; /* first bin searched: -dmax unless a window is set */
     int32_t num_lags;    /* lags scanned per cell (:190) */
     int32_t acc_columns; /* kernel instance in use */
     int32_t device;
@@ -125,6 +126,13 @@ int gpsacq_search(gpsacq_engine* e, const uint8_t* bits, size_t n_blocks, size_t
  */
 int gpsacq_search_device(gpsacq_engine* e, const void* d_bits, size_t n_blocks, size_t stride,
                          const void* d_tasks, size_t n_tasks, void* d_cells, void* d_peaks, int sync);
+/*
+ * Restrict the search to Doppler bins first_bin .. first_bin+n_bins-1 (within -dmax..+dmax).
+ * Used to shard one block's PRN x Doppler grid over several GPUs (no reference equivalent: the
+ * reference always scans the full range, :176).  cells rows then hold n_bins entries and
+ * lo_shift stays an absolute bin number.
+ */
+int gpsacq_set_doppler_window(gpsacq_engine* e, int first_bin, int n_bins);
 int gpsacq_synchronize(gpsacq_engine* e);
 int gpsacq_last_timing(const gpsacq_engine* e, gpsacq_timing* t);
 

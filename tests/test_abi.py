@@ -1,0 +1,79 @@
+"""The C-ABI library loads and exports every symbol include/gpsacq.h declares; without a GPU
+the product fails loudly (no CPU fallback).  No compute calls here."""
+import ctypes
+import os
+import re
+import subprocess
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _header_symbols(path):
+    text = open(path).read()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    return sorted(set(re.findall(r"\b(gpsacq_[a-z_]+)\s*\(", text)))
+
+
+def test_exports_match_header():
+    import gpsacq
+    lib = gpsacq.load_library()
+    syms = _header_symbols(os.path.join(ROOT, "include", "gpsacq.h"))
+    assert len(syms) >= 12
+    for s in syms:
+        assert hasattr(lib, s), f"{s} declared in include/gpsacq.h but not exported"
+    assert sorted(gpsacq.EXPORTS) == syms
+
+
+def test_struct_sizes_match_abi():
+    import gpsacq
+    assert gpsacq.CELL_DTYPE.itemsize == 16 and gpsacq.PEAK_DTYPE.itemsize == 16 and gpsacq.TASK_DTYPE.itemsize == 8
+    assert ctypes.sizeof(gpsacq.Params) == 32 and ctypes.sizeof(gpsacq.Info) == 96 and ctypes.sizeof(gpsacq.Timing) == 32
+
+
+def test_search_code_host_only():
+    """SearchCode() (c/search_offline.cpp:205-209) is host arithmetic: check it against the oracle."""
+    import gpsacq
+    from oracle_lib import lib
+    L = lib("f64")
+    for sv in (0, 7, 31):
+        for g1 in (0x3FF, 0x1, 0x2AA, 0x155, 0x3FE):
+            assert gpsacq.search_code(sv, g1) == L.oracle_search_code(sv, g1)
+    assert gpsacq.search_code(40, 1) == -1
+
+
+def test_argument_errors_before_device():
+    import gpsacq
+    with pytest.raises(gpsacq.GpsAcqError) as ei:
+        gpsacq.Engine(1e6, 0.0)
+    assert ei.value.code == 1
+    with pytest.raises(gpsacq.GpsAcqError) as ei:
+        gpsacq.Engine(1e6, 20e6)  # 20000 lags > 10000 supported
+    assert ei.value.code == 3
+
+
+def test_fails_loudly_without_gpu():
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("GPU present")
+    import gpsacq
+    with pytest.raises(gpsacq.GpsAcqError) as ei:
+        gpsacq.Engine(4.092e6, 5.456e6, 5000.0)
+    assert ei.value.code == 2 and "no CPU path" in str(ei.value)
+
+
+def test_product_does_not_touch_oracle():
+    """No file of the product (package, include/) mentions the oracle or the emulation harness."""
+    bad = []
+    for base in ("gnss-gps-sdr_amd", "include"):
+        for dp, _, fns in os.walk(os.path.join(ROOT, base)):
+            for fn in fns:
+                if fn.endswith((".so", ".o", ".pyc")):
+                    continue
+                t = open(os.path.join(dp, fn), errors="replace").read()
+                if re.search(r"oracle/|liboracle|oracle_lib|libemul", t):
+                    bad.append(os.path.join(dp, fn))
+    assert not bad, bad
+    out = subprocess.run(["ldd", os.path.join(ROOT, "gnss-gps-sdr_amd", "lib", "libgpsacq.so")], capture_output=True, text=True).stdout
+    assert "oracle" not in out and "emul" not in out and "amdhip64" in out

@@ -1,0 +1,116 @@
+"""N > 1 path on CPU: world_size-2 gloo processes exercise the sharding helpers and the one
+collective of the path (all-reduce(MAX) of the packed per-PRN peaks).  The reference has no
+multi-process code; the expected values are the single-process results."""
+import os
+import socket
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _fake_peaks(n, seed, dmax=36):
+    rng = np.random.default_rng(seed)
+    pk = np.zeros(n, dtype=[("snr", "<f4"), ("lo", "<i4"), ("ca", "<i4"), ("mp", "<f4")])
+    pk["snr"] = (rng.random(n) * 120).astype(np.float32)
+    pk["snr"][::7] = np.float32(50.0)  # force exact SNR ties across ranks
+    pk["lo"] = rng.integers(-dmax, dmax + 1, n)
+    pk["ca"] = rng.integers(0, 5456, n)
+    pk["mp"] = pk["snr"] * 1e14
+    return pk
+
+
+def _worker(rank, world, port, n_runs, q):
+    import sys
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "gnss-gps-sdr_amd", "python"))
+    from gpsacq import dist as D
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        # --- decomposition by block: contiguous runs per rank ---
+        allpk = _fake_peaks(n_runs * 32, 123)
+        first, n = D.shard_runs(n_runs, rank, world)
+        mine = torch.from_numpy(allpk[first * 32:(first + n) * 32].copy().view(np.int32).reshape(-1, 4))
+        best = D.per_prn_best(D.pack_keys(mine, 36)) if n > 0 else torch.zeros(32, dtype=torch.int64)
+        best = D.allreduce_best(best)
+        gathered = D.gather_peaks(mine)
+        # --- decomposition by Doppler slab: per-cell SNRs of one (block, PRN) from the golden file ---
+        z = np.load(os.path.join(GOLDEN, "np64_cells_nott.npz"))
+        dmax, S = int(z["dmax"]), int(z["S"])
+        slab_best = torch.zeros(32, dtype=torch.int64)
+        f, nb = D.shard_doppler(dmax, rank, world)
+        for b, sv in [tuple(int(v) for v in p) for p in z["pairs"]][:5]:
+            snr = (z[f"max_pwr_{b}_{sv}"] / (z[f"tot_pwr_{b}_{sv}"] / S)).astype(np.float32)
+            mi = z[f"max_i_{b}_{sv}"]
+            p = np.zeros(1, dtype=[("snr", "<f4"), ("lo", "<i4"), ("ca", "<i4"), ("mp", "<f4")])
+            for d in range(f, f + nb):  # Correlate's scan over this rank's slab, strict '>'
+                if snr[d + dmax] > p["snr"][0]:
+                    p["snr"][0], p["lo"][0], p["ca"][0] = snr[d + dmax], d, mi[d + dmax]
+            slab_best[sv] = D.pack_keys(torch.from_numpy(p.view(np.int32).reshape(1, 4)), dmax)[0]
+        slab_best = D.allreduce_best(slab_best)
+        if rank == 0:
+            q.put((best.numpy(), gathered.numpy(), slab_best.numpy()))
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("n_runs", [5, 1])
+def test_two_rank_gloo(n_runs):
+    import sys
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "gnss-gps-sdr_amd", "python"))
+    from gpsacq import dist as D
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, n_runs, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    best, gathered, slab_best = q.get(timeout=120)
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    # expected: single-process results
+    allpk = _fake_peaks(n_runs * 32, 123)
+    t = torch.from_numpy(allpk.copy().view(np.int32).reshape(-1, 4))
+    exp = D.per_prn_best(D.pack_keys(t, 36))
+    assert np.array_equal(best, exp.numpy())
+    assert np.array_equal(gathered, t.numpy())
+    snr, lo, ca = D.unpack_keys(torch.from_numpy(best), 36)
+    for sv in range(32):  # reference order: highest SNR, ties to the lowest Doppler bin
+        cand = allpk[sv::32]
+        top = cand[cand["snr"] == cand["snr"].max()]
+        assert snr[sv].item() == top["snr"][0] and lo[sv].item() == top["lo"].min()
+    # Doppler slabs: equal to the full-range sequential scan
+    z = np.load(os.path.join(GOLDEN, "np64_cells_nott.npz"))
+    dmax, S = int(z["dmax"]), int(z["S"])
+    s2, lo2, ca2 = D.unpack_keys(torch.from_numpy(slab_best), dmax)
+    for b, sv in [tuple(int(v) for v in p) for p in z["pairs"]][:5]:
+        snr_c = (z[f"max_pwr_{b}_{sv}"] / (z[f"tot_pwr_{b}_{sv}"] / S)).astype(np.float32)
+        d = int(np.argmax(snr_c))  # first maximum == strict '>' scan
+        assert lo2[sv].item() == d - dmax and ca2[sv].item() == int(z[f"max_i_{b}_{sv}"][d]) and s2[sv].item() == snr_c[d]
+
+
+def test_shard_helpers():
+    import sys
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "gnss-gps-sdr_amd", "python"))
+    from gpsacq import dist as D
+    for n in (0, 1, 7, 64, 341):
+        for w in (1, 2, 4, 8):
+            parts = [D.shard_runs(n, r, w) for r in range(w)]
+            assert sum(p[1] for p in parts) == n
+            assert all(parts[i][0] + parts[i][1] == parts[i + 1][0] for i in range(w - 1))
+            assert max(p[1] for p in parts) - min(p[1] for p in parts) <= 1
+    assert D.shard_doppler(36, 0, 2) == (-36, 37) and D.shard_doppler(36, 1, 2) == (1, 36)

@@ -1,0 +1,82 @@
+"""CPU check of the HIP kernels' index math: tests/emul runs the per-thread phase functions of
+gnss-gps-sdr_amd/csrc/acq_phases.hpp on the host (test infrastructure) and is compared with
+the oracle.  The real kernels are checked on the GPU by tests/test_gpu_parity.py."""
+import ctypes
+import os
+import subprocess
+
+import numpy as np
+import pytest
+
+from oracle_lib import Oracle, lib, _p
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+@pytest.fixture(scope="module")
+def emul():
+    path = os.path.join(ROOT, "tests", "emul", "libemul_acq.so")
+    if not os.path.exists(path):
+        subprocess.check_call(["make", "-C", ROOT, "emul"], stdout=subprocess.DEVNULL)
+    E = ctypes.CDLL(path)
+    vp, d, i = ctypes.c_void_p, ctypes.c_double, ctypes.c_int
+    E.emul_forward_bits.argtypes = [vp] * 4
+    E.emul_forward_real.argtypes = [vp] * 2
+    E.emul_cell.argtypes = [vp, vp, i, i, i, i, vp, vp, vp]
+    E.emul_code_replica.argtypes = [d, i, vp]
+    E.emul_lo_masks.argtypes = [d, d, vp, vp]
+    E.emul_search_code.argtypes = [i, i]
+    E.emul_dmax.argtypes = [d, d]
+    E.emul_nlags.argtypes = [d]
+    return E
+
+
+def test_host_tables_bit_exact(emul):
+    L = lib("f64")
+    for fs in (5.456e6, 8.184e6, 2.8e6, 10e6):
+        for sv in (0, 7, 31):
+            a, b = np.zeros(40000, np.float32), np.zeros(40000, np.float32)
+            L.oracle_code_replica(fs, sv, _p(a))
+            emul.emul_code_replica(fs, sv, _p(b))
+            assert np.array_equal(a, b)
+    for fc, fs in ((4.092e6, 5.456e6), (2.046e6, 8.184e6), (0.62e6, 2.8e6)):
+        cosm, sinm = np.zeros(5120, np.uint8), np.zeros(5120, np.uint8)
+        emul.emul_lo_masks(fc, fs, _p(cosm), _p(sinm))
+        quad = np.zeros(40960, np.uint8)
+        L.oracle_lo_quadrants(fc, fs, 40960, _p(quad))
+        assert np.array_equal(np.unpackbits(cosm, bitorder="little"), np.array([0, 1, 1, 0], np.uint8)[quad])
+        assert np.array_equal(np.unpackbits(sinm, bitorder="little"), np.array([1, 1, 0, 0], np.uint8)[quad])
+        assert emul.emul_dmax(fs, 5000.0) == L.oracle_dmax(fs, 5000.0)
+        assert emul.emul_nlags(fs) == L.oracle_nlags(fs)
+
+
+@pytest.mark.parametrize("fc,fs,file,mc", [(4.092e6, 5.456e6, "synth_nott_fs5456.bin", 22), (2.046e6, 8.184e6, "gps_sig_tmp.bin", 33),
+                                           (0.62e6, 2.8e6, "synth_rtl_fs2800.bin", 12)])
+def test_emulated_kernels_vs_oracle(emul, golden_dir, fc, fs, file, mc):
+    buf = open(os.path.join(golden_dir, file), "rb").read()
+    blk = np.frombuffer(buf[7 * 5120:8 * 5120], np.uint8).copy()
+    orc = Oracle(fc, fs, 5000.0)
+    cosm, sinm = np.zeros(5120, np.uint8), np.zeros(5120, np.uint8)
+    emul.emul_lo_masks(fc, fs, _p(cosm), _p(sinm))
+    # Sample()
+    d_emul = np.zeros(80000, np.float32)
+    emul.emul_forward_bits(_p(blk), _p(cosm), _p(sinm), _p(d_emul))
+    d_orc = orc.sample_spectrum(blk)
+    assert np.abs(d_emul.view(np.complex64) - d_orc).max() / np.abs(d_orc).max() < 2e-6
+    # SearchInit()
+    rep = np.zeros(40000, np.float32)
+    emul.emul_code_replica(fs, 7, _p(rep))
+    c_emul = np.zeros(80000, np.float32)
+    emul.emul_forward_real(_p(rep), _p(c_emul))
+    c_orc = orc.code_spectrum(7)
+    assert np.abs(c_emul.view(np.complex64) - c_orc).max() / np.abs(c_orc).max() < 2e-6
+    # Correlate() cells at the edges and the middle of the Doppler range
+    cells, _ = orc.search_block(blk, 7)
+    d_in = np.ascontiguousarray(d_orc).view(np.float32)
+    c_in = np.ascontiguousarray(c_orc).view(np.float32)
+    for dop in (-orc.dmax, -9, 0, 1, orc.dmax):
+        mp, mi, tp = ctypes.c_float(), ctypes.c_int(), ctypes.c_float()
+        assert emul.emul_cell(_p(d_in), _p(c_in), 24, dop, orc.num_lags, mc, ctypes.byref(mp), ctypes.byref(mi), ctypes.byref(tp)) == 0
+        ref = cells[dop + orc.dmax]
+        assert abs(mp.value / ref["max_pwr"] - 1) < 2e-5 and abs(tp.value / ref["tot_pwr"] - 1) < 2e-5
+        assert mi.value == ref["max_i"]

@@ -1,0 +1,124 @@
+"""CPU tests of the oracle (the C restatement under oracle/): pinned against the reference
+outputs recorded in BASELINE.md, the bundled capture, and an independent float64 numpy
+restatement (tests/golden/make_golden.py)."""
+import json
+import os
+
+import numpy as np
+import pytest
+
+from oracle_lib import Oracle, lib, _p
+
+
+def test_dft_matches_numpy():
+    L = lib("f64")
+    rng = np.random.default_rng(5)
+    for n in (5, 20, 100, 5000, 40000):
+        x = (rng.standard_normal(n) + 1j * rng.standard_normal(n)).astype(np.complex64)
+        for direction, ref in ((-1, np.fft.fft(x.astype(np.complex128))), (+1, np.fft.ifft(x.astype(np.complex128)) * n)):
+            out = np.zeros(n, np.complex64)
+            assert L.oracle_dft(n, direction, _p(x), _p(out)) == 0
+            assert np.abs(out - ref).max() / np.abs(ref).max() < 2e-7
+    Lf = lib("f32")
+    x = (rng.standard_normal(40000) + 1j * rng.standard_normal(40000)).astype(np.complex64)
+    out = np.zeros(40000, np.complex64)
+    Lf.oracle_dft(40000, -1, _p(x), _p(out))
+    ref = np.fft.fft(x.astype(np.complex128))
+    assert np.abs(out - ref).max() / np.abs(ref).max() < 5e-6
+
+
+def test_ca_code_properties():
+    """c/cacode.h: balanced Gold codes of period 1023, PRN 1 starts 1100100000 (IS-GPS-200 octal 1440)."""
+    L = lib("f64")
+    chips = np.zeros((32, 1023), np.uint8)
+    for sv in range(32):
+        L.oracle_ca_chips(sv, _p(chips[sv]))
+    assert list(chips[0][:10]) == [1, 1, 0, 0, 1, 0, 0, 0, 0, 0]
+    assert all(int(c.sum()) == 512 for c in chips)
+    b = 1.0 - 2.0 * chips
+    # Gold-code cross-correlation takes only the three values -65, -1, 63
+    cc = np.fft.ifft(np.fft.fft(b[0]) * np.conj(np.fft.fft(b[7]))).real.round().astype(int)
+    assert set(cc) <= {-65, -1, 63}
+    ac = np.fft.ifft(np.abs(np.fft.fft(b[20])) ** 2).real.round().astype(int)
+    assert ac[0] == 1023 and set(ac[1:]) <= {-65, -1, 63}
+    # SearchCode(): G1 is all ones after 0 chips and again after 1023
+    assert L.oracle_search_code(3, 0x3FF) == 0
+
+
+def test_grid_sizes():
+    L = lib("f64")
+    L.oracle_dmax.restype = int
+    assert L.oracle_dmax(5.456e6, 5000.0) == 36 and L.oracle_nlags(5.456e6) == 5456
+    assert L.oracle_dmax(8.184e6, 5000.0) == 24 and L.oracle_nlags(8.184e6) == 8184
+    assert L.oracle_dmax(2.8e6, 5000.0) == 71 and L.oracle_nlags(2.8e6) == 2800
+    assert L.oracle_dmax(2.8e6, 100000.0) == 1428
+    assert L.oracle_nlags(2.8001e6) == 2801  # i < FS/1000 with a fractional bound
+
+
+@pytest.mark.parametrize("name,fc,fs,file", [("nott", 4.092e6, 5.456e6, "synth_nott_fs5456.bin"),
+                                             ("sigtmp", 2.046e6, 8.184e6, "gps_sig_tmp.bin"),
+                                             ("rtl", 0.62e6, 2.8e6, "synth_rtl_fs2800.bin")])
+def test_cells_vs_numpy_golden(golden_dir, name, fc, fs, file):
+    z = np.load(os.path.join(golden_dir, f"np64_cells_{name}.npz"))
+    buf = open(os.path.join(golden_dir, file), "rb").read()
+    orc = Oracle(fc, fs, float(z["max_fo"]), ref_quirks=bool(z["quirks"]))
+    assert orc.dmax == int(z["dmax"]) and orc.num_lags == int(z["S"])
+    pairs = [tuple(int(v) for v in p) for p in z["pairs"]][:3]
+    for b, sv in pairs:
+        cells, _ = orc.search_block(buf[b * 5120:(b + 1) * 5120], sv)
+        np.testing.assert_allclose(cells["max_pwr"], z[f"max_pwr_{b}_{sv}"], rtol=5e-6)
+        np.testing.assert_allclose(cells["tot_pwr"], z[f"tot_pwr_{b}_{sv}"], rtol=5e-6)
+        assert np.array_equal(cells["max_i"], z[f"max_i_{b}_{sv}"])
+
+
+def test_reference_known_answers_gps_sig_tmp(golden_dir):
+    """gps_test gps_sig_tmp.bin 2.046e6 8.184e6 5000: the oracle must print what the reference
+    printed.  First 3 runs here (the full 12 run in the GPU suite)."""
+    known = json.load(open(os.path.join(golden_dir, "ref_known_answers.json")))["gps_sig_tmp"]
+    orc = Oracle(2.046e6, 8.184e6, 5000.0, ref_quirks=True)
+    n, text, peaks = orc.search_file(os.path.join(golden_dir, "gps_sig_tmp.bin"), max_runs=3)
+    assert n == 3
+    lines = text.split("\n")
+    assert lines[0].split() == ["0", "satellite:"] + [str(v) for v in known["run0_hits_sv"]]
+    assert lines[1].split()[2:] == ["%.1f" % v for v in known["run0_hits_snr"]]
+    assert lines[2].split()[2:] == [str(v) for v in known["run0_hits_lo"]]
+    assert lines[3].split()[2:] == [str(v) for v in known["run0_hits_ca"]]
+    sv7 = peaks[7::32]
+    assert ["%.1f" % v for v in sv7["snr"]] == ["%.1f" % v for v in known["sv7_snr"][:3]]
+    assert list(sv7["lo_shift"]) == known["sv7_lo_shift"][:3]
+    assert list(sv7["ca_shift"]) == known["sv7_ca_shift"][:3]
+    others = np.delete(peaks["snr"], [7, 39, 71])
+    assert others.min() > known["other_best_snr_range"][0] - 0.5 and others.max() < known["other_best_snr_range"][1] + 0.5
+    # README.md:45,57 known answer: PRN 8 at zero Doppler is the signal in the file
+    assert int(np.argmax(peaks["snr"][:32])) == 7 and int(peaks["lo_shift"][7]) == 0
+
+
+def test_quirk_only_touches_prn_index_0(golden_dir):
+    buf = open(os.path.join(golden_dir, "gps_sig_tmp.bin"), "rb").read()[:32 * 5120]
+    a = Oracle(2.046e6, 8.184e6, 5000.0, ref_quirks=True)
+    b = Oracle(2.046e6, 8.184e6, 5000.0, ref_quirks=False)
+    for blk, sv in ((0, 0), (5, 5)):
+        ca, pa = a.search_block(buf[blk * 5120:(blk + 1) * 5120], sv)
+        cb, pb = b.search_block(buf[blk * 5120:(blk + 1) * 5120], sv)
+        same = np.array_equal(ca, cb)
+        assert same == (sv != 0)
+
+
+def test_short_file_and_missing_file(tmp_path, golden_dir):
+    orc = Oracle(4.092e6, 5.456e6, 5000.0)
+    n, text, _ = orc.search_file(str(tmp_path / "nope.bin"))
+    assert n == -1 and text == "can not open file!\n"
+    p = tmp_path / "short.bin"
+    p.write_bytes(open(os.path.join(golden_dir, "synth_nott_fs5456.bin"), "rb").read()[:31 * 5120 + 100])
+    n, text, _ = orc.search_file(str(p))
+    assert n == 0 and text == "run out of file!\n"
+
+
+def test_f32_port_close_to_f64(golden_dir):
+    buf = open(os.path.join(golden_dir, "synth_nott_fs5456.bin"), "rb").read()
+    a = Oracle(4.092e6, 5.456e6, 5000.0, kind="f64")
+    b = Oracle(4.092e6, 5.456e6, 5000.0, kind="f32")
+    ca, pa = a.search_block(buf[20 * 5120:21 * 5120], 20)
+    cb, pb = b.search_block(buf[20 * 5120:21 * 5120], 20)
+    np.testing.assert_allclose(ca["max_pwr"], cb["max_pwr"], rtol=2e-4)
+    assert pa["ca_shift"] == pb["ca_shift"] and pa["lo_shift"] == pb["lo_shift"]
