@@ -1,13 +1,14 @@
 # Top-level build: HIP engine (gfx950 only), host front end, oracle (test infrastructure).
 HIPCC    ?= /opt/rocm/bin/hipcc
 CXX      ?= g++
+CLANGXX  ?= /opt/rocm/lib/llvm/bin/clang++   # acq_math.hpp uses clang vector types (ext_vector_type)
 ARCH     := gfx950
 PKG      := gnss-gps-sdr_amd
 CSRC     := $(PKG)/csrc
 HOST     := $(PKG)/host
 LIBDIR   := $(PKG)/lib
 BINDIR   := $(PKG)/bin
-HIPFLAGS := --offload-arch=$(ARCH) -O3 -std=c++17 -fPIC -Wall -Wno-unused-function
+HIPFLAGS := --offload-arch=$(ARCH) -O3 -std=c++17 -fPIC -Wall -Wno-unused-function $(HIPFLAGS_EXTRA)
 HOSTFLAGS:= -O2 -std=c++17 -fPIC -Wall -Wno-unknown-pragmas -ffp-contract=off
 
 all: lib host oracle emul
@@ -31,7 +32,7 @@ oracle:
 
 emul: tests/emul/libemul_acq.so
 tests/emul/libemul_acq.so: tests/emul/emul_acq.cpp $(CSRC)/*.hpp
-	$(CXX) $(HOSTFLAGS) -shared -o $@ tests/emul/emul_acq.cpp
+	$(CLANGXX) -x c++ $(HOSTFLAGS) -shared -o $@ tests/emul/emul_acq.cpp
 
 # Drop-in check (authoring container only): the reference's own front end, compiled from where
 # it lies and never copied, linked against our SearchInit/SearchTask.  Output is git-ignored.

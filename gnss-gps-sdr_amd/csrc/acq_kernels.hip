@@ -16,6 +16,8 @@
 // one pair are mapped to one XCD.
 #include <hip/hip_runtime.h>
 
+#include <cstdlib>
+
 #include "acq_launch.hpp"
 #include "acq_phases.hpp"
 
@@ -42,12 +44,12 @@ __global__ __launch_bounds__(WG) void k_fwd_sub(FwdArgs a) {
     const Src src = SrcOf<Src>::make(a, item);
     fwd_phase1(tid, q, src, a.t1, lds);
     __syncthreads();
-    fwd_phase2(tid, q, a.t2, lds);
+    fwd_phase2(tid, a.t2, lds);
     __syncthreads();
     cf y[RC];
     fwd_phase3_load(tid, lds, y);
     __syncthreads();
-    fwd_phase3_store(tid, q, a.wq, y, lds);
+    fwd_phase3_store(tid, q, a.bq, a.wq, y, lds);
     __syncthreads();
     cf* dst = a.g + ((size_t)item * NPOLY + q) * M_SUB;
     for (int i = tid; i < M_SUB; i += WG) dst[i] = lds[i];
@@ -99,9 +101,11 @@ __global__ __launch_bounds__(WG) void k_quirk_patch(QuirkArgs a) {
 // ---------------------------------------------------------------------------------------
 // One workgroup per (task, Doppler bin).  blockIdx -> cell map keeps the 2*dmax+1 cells of a
 // task on one XCD (block b runs on XCD b % 8) so both spectra are read from that XCD's L2.
-template <int MC>
-__global__ __launch_bounds__(WG) void k_corr(CorrArgs a) {
-    __shared__ cf lds[M_SUB];
+template <int MC, int WPS>
+__global__ __launch_bounds__(WG, WPS) void k_corr(CorrArgs a) {
+    __shared__ cf lds_all[2 * M_SUB];  // [0,5000): transform buffer, [5000,10000): pass-2 twiddles
+    cf* lds = lds_all;
+    cf* t2s = lds_all + M_SUB;
     const int tid = threadIdx.x;
     const int g = blockIdx.x, xcd = g & 7, slot = g >> 3;
     const int grp = slot / a.ndop, di = slot - grp * a.ndop;
@@ -112,16 +116,21 @@ __global__ __launch_bounds__(WG) void k_corr(CorrArgs a) {
     const cf* dpp = a.dpp + (size_t)tk.spec * NPOLY * M_SUB;
     const cf* cpp = a.cpp + (size_t)tk.code * NPOLY * a.crow;
 
+    // q-independent twiddles: pass 2's table into LDS (16-byte copies), pass 1's into registers
+    for (int i = tid; i < M_SUB / 2; i += WG) reinterpret_cast<cf2*>(t2s)[i] = reinterpret_cast<const cf2*>(a.t2)[i];
+    cf w1[2][RA - 1];
+    load_tw1(tid, a.t1, w1);
+
     cf acc[MC];
 #pragma unroll
     for (int m = 0; m < MC; ++m) acc[m] = mk(0.f, 0.f);
 
     for (int q = 0; q < NPOLY; ++q) {
-        corr_phase1(tid, q, dop, dpp, cpp, a.crow, a.halo, a.t1, lds);
+        corr_phase1(tid, q, dop, dpp, cpp, a.crow, a.halo, w1, lds);
+        __syncthreads();  // also orders the t2s fill before its first use
+        corr_phase2(tid, t2s, lds);
         __syncthreads();
-        corr_phase2(tid, q, a.t2, lds);
-        __syncthreads();
-        corr_phase3<MC>(tid, q, a.wq, lds, acc);
+        corr_phase3<MC>(tid, q, a.bq, a.wq, lds, acc);
         __syncthreads();
     }
 
@@ -208,11 +217,17 @@ int corr_columns(int nlags) {  // accumulator columns of the smallest instance t
 int launch_corr(const CorrArgs& a, int mc, hipStream_t s) {
     const int groups = (a.n_tasks + 7) / 8;
     const dim3 grid((unsigned)groups * 8u * (unsigned)a.ndop), block(WG);
+    static const int wps = getenv("GPSACQ_WPS") ? atoi(getenv("GPSACQ_WPS")) : 2;  // tuning knob (experiments)
+    static const int pad = getenv("GPSACQ_LDS_PAD") ? atoi(getenv("GPSACQ_LDS_PAD")) : 0;  // occupancy experiments
     switch (mc) {
-        case 12: hipLaunchKernelGGL(k_corr<12>, grid, block, 0, s, a); break;
-        case 22: hipLaunchKernelGGL(k_corr<22>, grid, block, 0, s, a); break;
-        case 33: hipLaunchKernelGGL(k_corr<33>, grid, block, 0, s, a); break;
-        case 40: hipLaunchKernelGGL(k_corr<40>, grid, block, 0, s, a); break;
+        case 12: hipLaunchKernelGGL((k_corr<12, 2>), grid, block, 0, s, a); break;
+        case 22:
+            if (wps == 3) hipLaunchKernelGGL((k_corr<22, 3>), grid, block, pad, s, a);
+            else if (wps == 4) hipLaunchKernelGGL((k_corr<22, 4>), grid, block, pad, s, a);
+            else hipLaunchKernelGGL((k_corr<22, 2>), grid, block, pad, s, a);
+            break;
+        case 33: hipLaunchKernelGGL((k_corr<33, 2>), grid, block, 0, s, a); break;
+        case 40: hipLaunchKernelGGL((k_corr<40, 1>), grid, block, 0, s, a); break;
         default: return -1;
     }
     return 0;

@@ -14,6 +14,7 @@ struct FwdArgs {
     const uint8_t* sin_mask;
     const cf* t1;
     const cf* t2;
+    const cf* bq;
     const cf* wq;
     cf* g;               // [n_items][8][5000]
 };
@@ -41,6 +42,7 @@ struct CorrArgs {
     const Task* tasks; // [n_tasks]
     const cf* t1;
     const cf* t2;
+    const cf* bq;
     const cf* wq;
     Cell* cells;       // [n_tasks][ndop]
     int n_tasks, ndop, dop_first, nlags, crow, halo;  // bins dop_first .. dop_first+ndop-1

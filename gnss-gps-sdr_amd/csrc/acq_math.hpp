@@ -14,14 +14,27 @@
 //   pass 3  radix-20 (Good-Thomas 4x5) on elements j'',             no twiddle
 // with LDS slot(alpha, j'', b) = 500 alpha + 25 j'' + b, and outputs r = 250 n'' + 10 beta + alpha.
 //
-// The functions are plain inline C++ so that tests/emul can run exactly this index math on
-// the CPU (test infrastructure); the product only ever calls them from the HIP kernels.
+// Complex values are 2-vectors of float so that on gfx950 every complex add is one
+// v_pk_add_f32 and every complex multiply two packed instructions: the swap/negate forms
+// (multiply by +-i, complex product) are written with VOP3P op_sel / neg modifiers in inline
+// asm because hipcc otherwise spends a v_xor + v_mov per swap.  A wave64 VALU instruction
+// holds the pipe 2 cycles (4 for v_pk_*), but one wave can only issue one every ~5 cycles
+// (tools/ubench/valu_rate.hip), so at 2-4 waves per SIMD packed math is what fills the pipe.
+//
+// The functions are plain inline C++ outside device code so that tests/emul can run exactly
+// this index math on the CPU (test infrastructure); the product only ever calls them from
+// the HIP kernels.
 #pragma once
 
 #if defined(__HIPCC__)
 #define ACQ_HD __host__ __device__ __forceinline__
 #else
 #define ACQ_HD inline
+#endif
+#if defined(__HIP_DEVICE_COMPILE__)
+#define ACQ_PK_ASM 1
+#else
+#define ACQ_PK_ASM 0
 #endif
 
 namespace acq {
@@ -37,22 +50,91 @@ constexpr int NW160 = N_FFT / NBF3;  // 160
 constexpr int MC_MAX = 40;           // accumulator columns supported: lags n < 250 * MC_MAX (fs <= 10 MHz)
 constexpr int WQ_STRIDE = MC_MAX;    // wq[q][m] = W_160^{q m}
 
-struct cf {
-    float x, y;
-};
+typedef float cf __attribute__((ext_vector_type(2)));  // (re, im); one 64-bit VGPR pair on the device
 
 ACQ_HD cf mk(float x, float y) { cf r; r.x = x; r.y = y; return r; }
-ACQ_HD cf operator+(cf a, cf b) { return mk(a.x + b.x, a.y + b.y); }
-ACQ_HD cf operator-(cf a, cf b) { return mk(a.x - b.x, a.y - b.y); }
-ACQ_HD cf cmul(cf a, cf b) { return mk(a.x * b.x - a.y * b.y, a.x * b.y + a.y * b.x); }
-ACQ_HD cf cmulc(cf a, cf b) { return mk(a.x * b.x + a.y * b.y, a.y * b.x - a.x * b.y); }  // a * conj(b)
-ACQ_HD cf scale(cf a, float s) { return mk(a.x * s, a.y * s); }
+
+// a * w
+ACQ_HD cf cmul(cf a, cf w) {
+#if ACQ_PK_ASM
+    cf t, r;
+    asm("v_pk_mul_f32 %0, %1, %2 op_sel_hi:[0,1]" : "=v"(t) : "v"(a), "v"(w));  // (ax wx, ax wy)
+    asm("v_pk_fma_f32 %0, %1, %2, %3 op_sel:[1,1,0] op_sel_hi:[1,0,1] neg_lo:[0,1,0]" : "=v"(r) : "v"(a), "v"(w), "v"(t));
+    return r;  // (ax wx - ay wy, ax wy + ay wx)
+#else
+    return mk(a.x * w.x - a.y * w.y, a.x * w.y + a.y * w.x);
+#endif
+}
+// a * conj(w)
+ACQ_HD cf cmulc(cf a, cf w) {
+#if ACQ_PK_ASM
+    cf t, r;
+    asm("v_pk_mul_f32 %0, %1, %2 op_sel_hi:[1,0]" : "=v"(t) : "v"(a), "v"(w));  // (ax wx, ay wx)
+    asm("v_pk_fma_f32 %0, %1, %2, %3 op_sel:[1,1,0] op_sel_hi:[0,1,1] neg_hi:[1,0,0]" : "=v"(r) : "v"(a), "v"(w), "v"(t));
+    return r;  // (ax wx + ay wy, ay wx - ax wy)
+#else
+    return mk(a.x * w.x + a.y * w.y, a.y * w.x - a.x * w.y);
+#endif
+}
+// same with a wave-uniform multiplier held in an SGPR pair (compile-time constants, scalar loads)
+ACQ_HD cf cmul_u(cf a, cf w) {
+#if ACQ_PK_ASM
+    cf t, r;
+    asm("v_pk_mul_f32 %0, %1, %2 op_sel_hi:[0,1]" : "=v"(t) : "v"(a), "s"(w));
+    asm("v_pk_fma_f32 %0, %1, %2, %3 op_sel:[1,1,0] op_sel_hi:[1,0,1] neg_lo:[0,1,0]" : "=v"(r) : "v"(a), "s"(w), "v"(t));
+    return r;
+#else
+    return cmul(a, w);
+#endif
+}
+ACQ_HD cf cmulc_u(cf a, cf w) {
+#if ACQ_PK_ASM
+    cf t, r;
+    asm("v_pk_mul_f32 %0, %1, %2 op_sel_hi:[1,0]" : "=v"(t) : "v"(a), "s"(w));
+    asm("v_pk_fma_f32 %0, %1, %2, %3 op_sel:[1,1,0] op_sel_hi:[0,1,1] neg_hi:[1,0,0]" : "=v"(r) : "v"(a), "s"(w), "v"(t));
+    return r;
+#else
+    return cmulc(a, w);
+#endif
+}
+// acc + a * conj(w), w wave-uniform
+ACQ_HD cf cmacc_u(cf acc, cf a, cf w) {
+#if ACQ_PK_ASM
+    cf t, r;
+    asm("v_pk_fma_f32 %0, %1, %2, %3 op_sel_hi:[1,0,1]" : "=v"(t) : "v"(a), "s"(w), "v"(acc));  // acc + (ax wx, ay wx)
+    asm("v_pk_fma_f32 %0, %1, %2, %3 op_sel:[1,1,0] op_sel_hi:[0,1,1] neg_hi:[1,0,0]" : "=v"(r) : "v"(a), "s"(w), "v"(t));
+    return r;
+#else
+    return acc + cmulc(a, w);
+#endif
+}
+// a + i b  and  a - i b
+ACQ_HD cf add_i(cf a, cf b) {
+#if ACQ_PK_ASM
+    cf r;
+    asm("v_pk_add_f32 %0, %1, %2 op_sel:[0,1] op_sel_hi:[1,0] neg_lo:[0,1]" : "=v"(r) : "v"(a), "v"(b));
+    return r;
+#else
+    return mk(a.x - b.y, a.y + b.x);
+#endif
+}
+ACQ_HD cf sub_i(cf a, cf b) {
+#if ACQ_PK_ASM
+    cf r;
+    asm("v_pk_add_f32 %0, %1, %2 op_sel:[0,1] op_sel_hi:[1,0] neg_hi:[0,1]" : "=v"(r) : "v"(a), "v"(b));
+    return r;
+#else
+    return mk(a.x + b.y, a.y - b.x);
+#endif
+}
 
 // DIR = -1: forward transform (exp(-i..)), DIR = +1: backward.  Tables hold the forward value
 // w = exp(-i theta); tw<DIR>(a, w) multiplies by w or conj(w).
 template <int DIR> ACQ_HD cf tw(cf a, cf w) { return DIR < 0 ? cmul(a, w) : cmulc(a, w); }
-// multiply by DIR * i
-template <int DIR> ACQ_HD cf mul_di(cf a) { return DIR > 0 ? mk(-a.y, a.x) : mk(a.y, -a.x); }
+template <int DIR> ACQ_HD cf tw_u(cf a, cf w) { return DIR < 0 ? cmul_u(a, w) : cmulc_u(a, w); }
+// a + DIR*i*b, a - DIR*i*b
+template <int DIR> ACQ_HD cf add_di(cf a, cf b) { return DIR > 0 ? add_i(a, b) : sub_i(a, b); }
+template <int DIR> ACQ_HD cf sub_di(cf a, cf b) { return DIR > 0 ? sub_i(a, b) : add_i(a, b); }
 
 template <int DIR> ACQ_HD void dft2(cf& a, cf& b) {
     cf t = a - b;
@@ -61,44 +143,41 @@ template <int DIR> ACQ_HD void dft2(cf& a, cf& b) {
 }
 
 template <int DIR> ACQ_HD void dft4(cf& a, cf& b, cf& c, cf& d) {
-    cf apc = a + c, amc = a - c, bpd = b + d, bmd = mul_di<DIR>(b - d);
+    cf apc = a + c, amc = a - c, bpd = b + d, bmd = b - d;
     a = apc + bpd;
-    b = amc + bmd;
+    b = add_di<DIR>(amc, bmd);
     c = apc - bpd;
-    d = amc - bmd;
+    d = sub_di<DIR>(amc, bmd);
 }
 
 template <int DIR> ACQ_HD void dft5(cf& x0, cf& x1, cf& x2, cf& x3, cf& x4) {
     constexpr float C1 = 0.30901699437494745f, C2 = -0.8090169943749473f;
     constexpr float S1 = 0.9510565162951535f, S2 = 0.5877852522924732f;
     cf t1 = x1 + x4, t2 = x2 + x3, t3 = x1 - x4, t4 = x2 - x3;
-    cf m1 = mk(x0.x + C1 * t1.x + C2 * t2.x, x0.y + C1 * t1.y + C2 * t2.y);
-    cf m2 = mk(x0.x + C2 * t1.x + C1 * t2.x, x0.y + C2 * t1.y + C1 * t2.y);
-    cf s1 = mul_di<DIR>(mk(S1 * t3.x + S2 * t4.x, S1 * t3.y + S2 * t4.y));
-    cf s2 = mul_di<DIR>(mk(S2 * t3.x - S1 * t4.x, S2 * t3.y - S1 * t4.y));
+    cf m1 = x0 + C1 * t1 + C2 * t2;
+    cf m2 = x0 + C2 * t1 + C1 * t2;
+    cf s1 = S1 * t3 + S2 * t4;
+    cf s2 = S2 * t3 - S1 * t4;
     x0 = x0 + t1 + t2;
-    x1 = m1 + s1;
-    x4 = m1 - s1;
-    x2 = m2 + s2;
-    x3 = m2 - s2;
+    x1 = add_di<DIR>(m1, s1);
+    x4 = sub_di<DIR>(m1, s1);
+    x2 = add_di<DIR>(m2, s2);
+    x3 = sub_di<DIR>(m2, s2);
 }
 
 // 8-point DFT, natural order in and out.
 template <int DIR> ACQ_HD void dft8(cf* x) {
     constexpr float R = 0.7071067811865476f;
-    // even / odd halves (decimation in time)
     cf e0 = x[0], e1 = x[2], e2 = x[4], e3 = x[6];
     cf o0 = x[1], o1 = x[3], o2 = x[5], o3 = x[7];
     dft4<DIR>(e0, e1, e2, e3);
     dft4<DIR>(o0, o1, o2, o3);
-    // o_k *= W_8^{k} (forward exp(-i pi k/4))
-    cf w1 = mk(R, -R), w3 = mk(-R, -R);
-    o1 = tw<DIR>(o1, w1);
-    o2 = mul_di<DIR>(o2);
-    o3 = tw<DIR>(o3, w3);
+    // o_k *= W_8^{k} (forward exp(-i pi k/4)); the k = 2 factor (-+i) is folded into the adds
+    o1 = tw_u<DIR>(o1, mk(R, -R));
+    o3 = tw_u<DIR>(o3, mk(-R, -R));
     x[0] = e0 + o0; x[4] = e0 - o0;
     x[1] = e1 + o1; x[5] = e1 - o1;
-    x[2] = e2 + o2; x[6] = e2 - o2;
+    x[2] = add_di<DIR>(e2, o2); x[6] = sub_di<DIR>(e2, o2);
     x[3] = e3 + o3; x[7] = e3 - o3;
 }
 
@@ -160,14 +239,14 @@ template <int DIR> ACQ_HD void radix25(const cf* x, cf* y) {
         dft5<DIR>(a, b, c, d, e);
         v[0][n2] = a; v[1][n2] = b; v[2][n2] = c; v[3][n2] = d; v[4][n2] = e;
     }
-    v[1][1] = tw<DIR>(v[1][1], w25<1>());  v[1][2] = tw<DIR>(v[1][2], w25<2>());
-    v[1][3] = tw<DIR>(v[1][3], w25<3>());  v[1][4] = tw<DIR>(v[1][4], w25<4>());
-    v[2][1] = tw<DIR>(v[2][1], w25<2>());  v[2][2] = tw<DIR>(v[2][2], w25<4>());
-    v[2][3] = tw<DIR>(v[2][3], w25<6>());  v[2][4] = tw<DIR>(v[2][4], w25<8>());
-    v[3][1] = tw<DIR>(v[3][1], w25<3>());  v[3][2] = tw<DIR>(v[3][2], w25<6>());
-    v[3][3] = tw<DIR>(v[3][3], w25<9>());  v[3][4] = tw<DIR>(v[3][4], w25<12>());
-    v[4][1] = tw<DIR>(v[4][1], w25<4>());  v[4][2] = tw<DIR>(v[4][2], w25<8>());
-    v[4][3] = tw<DIR>(v[4][3], w25<12>()); v[4][4] = tw<DIR>(v[4][4], w25<16>());
+    v[1][1] = tw_u<DIR>(v[1][1], w25<1>());  v[1][2] = tw_u<DIR>(v[1][2], w25<2>());
+    v[1][3] = tw_u<DIR>(v[1][3], w25<3>());  v[1][4] = tw_u<DIR>(v[1][4], w25<4>());
+    v[2][1] = tw_u<DIR>(v[2][1], w25<2>());  v[2][2] = tw_u<DIR>(v[2][2], w25<4>());
+    v[2][3] = tw_u<DIR>(v[2][3], w25<6>());  v[2][4] = tw_u<DIR>(v[2][4], w25<8>());
+    v[3][1] = tw_u<DIR>(v[3][1], w25<3>());  v[3][2] = tw_u<DIR>(v[3][2], w25<6>());
+    v[3][3] = tw_u<DIR>(v[3][3], w25<9>());  v[3][4] = tw_u<DIR>(v[3][4], w25<12>());
+    v[4][1] = tw_u<DIR>(v[4][1], w25<4>());  v[4][2] = tw_u<DIR>(v[4][2], w25<8>());
+    v[4][3] = tw_u<DIR>(v[4][3], w25<12>()); v[4][4] = tw_u<DIR>(v[4][4], w25<16>());
 #pragma unroll
     for (int k1 = 0; k1 < 5; ++k1) {
         dft5<DIR>(v[k1][0], v[k1][1], v[k1][2], v[k1][3], v[k1][4]);
@@ -177,34 +256,53 @@ template <int DIR> ACQ_HD void radix25(const cf* x, cf* y) {
 }
 
 // ---------------------------------------------------------------------------------------
-// LDS passes of one length-5000 transform.  t1/t2 are the twiddle tables built by
-// acq_tables.hpp: t1[alpha*500 + j'] = W_5000^{j' alpha};
-// t2q[beta*200 + e] = W_500^{j'' beta} * W_40000^{q (10 beta + alpha)}, e = 20 alpha + j''.
+// LDS passes of one length-5000 transform.  Twiddle tables (acq_tables.hpp):
+//   t1[alpha*500 + j']  = W_5000^{j' alpha}      pass-1 outputs (q-independent; the correlator
+//                                                keeps its 18 values per thread in registers)
+//   t2[beta*200 + e]    = W_500^{j'' beta}       pass-2 outputs, e = 20 alpha + j'' (q-independent;
+//                                                the correlator keeps the table in LDS)
+//   bq[q*250 + t3]      = W_40000^{q rho(t3)}    rotation of sub-transform q at pass-3 thread t3
+//   wq[q*40 + m]        = W_160^{q m}            the wave-uniform rest of W_40000^{q n}, n = 250 m + rho
 
-// pass 1 for butterfly jp (0..499): x[a] = element jp + 500 a.
-template <int DIR> ACQ_HD void pass1_store(const cf* x, int jp, const cf* __restrict__ t1, cf* lds) {
+// two consecutive complex values with one 16-byte access (p 16-byte aligned / only 8-byte aligned)
+typedef float cf2 __attribute__((ext_vector_type(4)));
+typedef cf2 cf2_a8 __attribute__((aligned(8)));
+ACQ_HD void ld2(const cf* p, cf& a, cf& b) {
+    const cf2 v = *reinterpret_cast<const cf2*>(p);
+    a = v.xy;
+    b = v.zw;
+}
+ACQ_HD void ld2u(const cf* p, cf& a, cf& b) {
+    const cf2 v = *reinterpret_cast<const cf2_a8*>(p);
+    a = v.xy;
+    b = v.zw;
+}
+
+// pass 1 for butterfly jp (0..499): x[a] = element jp + 500 a; w[al-1] = t1[al*500 + jp].
+template <int DIR> ACQ_HD void pass1_store(const cf* x, int jp, const cf* w, cf* lds) {
     cf y[RA];
     radix10<DIR>(x, y);
     const int b = jp / RC, jpp = jp - b * RC;
     cf* dst = lds + RB * jpp + b;
     dst[0] = y[0];
 #pragma unroll
-    for (int al = 1; al < RA; ++al) dst[NBF1 * al] = tw<DIR>(y[al], t1[al * NBF1 + jp]);
+    for (int al = 1; al < RA; ++al) dst[NBF1 * al] = tw<DIR>(y[al], w[al - 1]);
 }
 
-// pass 2 for butterfly e (0..199), in place.
-template <int DIR> ACQ_HD void pass2_inplace(int e, const cf* __restrict__ t2q, cf* lds) {
+// pass 2 for butterfly e (0..199), in place; t2 may live in LDS or global memory.
+template <int DIR> ACQ_HD void pass2_inplace(int e, const cf* t2, cf* lds) {
     const int al = e / RC, jpp = e - al * RC;
     cf* p = lds + NBF1 * al + RB * jpp;
     cf x[RB], y[RB];
 #pragma unroll
     for (int b = 0; b < RB; ++b) x[b] = p[b];
     radix25<DIR>(x, y);
+    p[0] = y[0];
 #pragma unroll
-    for (int be = 0; be < RB; ++be) p[be] = tw<DIR>(y[be], t2q[be * NBF2 + e]);
+    for (int be = 1; be < RB; ++be) p[be] = tw<DIR>(y[be], t2[be * NBF2 + e]);
 }
 
-// pass 3 for butterfly t3 (0..249): y[n''] = F[250 n'' + rho(t3)] (times the folded W_N^{q rho}).
+// pass 3 for butterfly t3 (0..249): y[n''] = F[250 n'' + rho(t3)].
 template <int DIR> ACQ_HD void pass3_load(int t3, const cf* lds, cf* y) {
     const int al = t3 / RB, be = t3 - al * RB;
     const cf* p = lds + NBF1 * al + be;

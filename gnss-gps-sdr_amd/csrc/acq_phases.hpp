@@ -10,6 +10,11 @@
 //                                    H entries on both sides so that the whole-bin Doppler
 //                                    shift (:182) is a plain pointer offset
 //   scratch  "g"    [8][5000]        W_N^{q k1} F_q[k1], input of the radix-8 combine
+//
+// The vector-memory pipe, not the VALU, was the first limiter of the correlator (ablation in
+// DESIGN.md): every global access here is therefore a 16-byte access of two neighbouring
+// elements, and the twiddles come from registers (t1), LDS (t2) or scalar loads (wq), never
+// from per-lane global loads inside the q loop.
 #pragma once
 #include <stdint.h>
 
@@ -39,44 +44,52 @@ struct Task {  // one (block spectrum, code spectrum) pair to search over all Do
     int32_t code;
 };
 
+// Thread tid (< 250) owns the pass-1 butterflies jp = 2 tid and 2 tid + 1.
+// Their 2 x 9 twiddles W_5000^{jp alpha}; loaded once per cell by the correlator.
+ACQ_HD void load_tw1(int tid, const cf* __restrict__ t1, cf (&w)[2][RA - 1]) {
+    if (tid >= NBF3) return;
+#pragma unroll
+    for (int al = 1; al < RA; ++al) ld2(t1 + al * NBF1 + 2 * tid, w[0][al - 1], w[1][al - 1]);
+}
+
 // ---------------------------------------------------------------------------------------
 // Correlate(): prod = conj(data) * shifted code (:181-185) fused into pass 1 of IDFT_5000.
 ACQ_HD void corr_phase1(int tid, int q, int dop, const cf* __restrict__ dpp, const cf* __restrict__ cpp,
-                        int crow, int halo, const cf* __restrict__ t1, cf* lds) {
+                        int crow, int halo, const cf (&w)[2][RA - 1], cf* lds) {
     if (tid >= NBF3) return;
     int qp, c;
     shift_split(q, dop, qp, c);
-    const cf* drow = dpp + q * M_SUB;
-    const cf* crw = cpp + (long)qp * crow + halo + c;
+    const cf* drow = dpp + q * M_SUB + 2 * tid;
+    const cf* crw = cpp + (long)qp * crow + halo + c + 2 * tid;
+    cf x0[RA], x1[RA];
 #pragma unroll
-    for (int h = 0; h < 2; ++h) {
-        const int jp = tid + NBF3 * h;
-        cf x[RA];
-#pragma unroll
-        for (int a = 0; a < RA; ++a) {
-            const int j = jp + NBF1 * a;
-            x[a] = cmul(drow[j], crw[j]);
-        }
-        pass1_store<+1>(x, jp, t1, lds);
+    for (int a = 0; a < RA; ++a) {
+        cf d0, d1, c0, c1;
+        ld2(drow + NBF1 * a, d0, d1);
+        ld2u(crw + NBF1 * a, c0, c1);  // c is arbitrary: 8-byte aligned only
+        x0[a] = cmul(d0, c0);
+        x1[a] = cmul(d1, c1);
     }
+    pass1_store<+1>(x0, 2 * tid, w[0], lds);
+    pass1_store<+1>(x1, 2 * tid + 1, w[1], lds);
 }
 
-ACQ_HD void corr_phase2(int tid, int q, const cf* __restrict__ t2, cf* lds) {
-    if (tid < NBF2) pass2_inplace<+1>(tid, t2 + (long)q * M_SUB, lds);
+ACQ_HD void corr_phase2(int tid, const cf* t2, cf* lds) {
+    if (tid < NBF2) pass2_inplace<+1>(tid, t2, lds);
 }
 
 // acc[m] accumulates y[n] for n = 250 m + rho over the 8 polyphase components:
-// W_N^{-q n} = W_N^{-q rho} (folded into t2) * W_160^{-q m}.
+// W_N^{-q n} = conj(bq[q][tid]) (per thread) * conj(W_160^{q m}) (wave-uniform).
 template <int MC>
-ACQ_HD void corr_phase3(int tid, int q, const cf* __restrict__ wq, const cf* lds, cf* acc) {
+ACQ_HD void corr_phase3(int tid, int q, const cf* __restrict__ bq, const cf* __restrict__ wq, const cf* lds, cf* acc) {
     if (tid >= NBF3) return;
+    const cf b = bq[q * NBF3 + tid];
     cf y[RC];
     pass3_load<+1>(tid, lds, y);
 #pragma unroll
-    for (int m = 0; m < MC; ++m) {
-        const cf w = wq[q * WQ_STRIDE + m];  // W_160^{q m}
-        acc[m] = acc[m] + cmulc(y[m % RC], w);
-    }
+    for (int n = 0; n < RC; ++n) y[n] = cmulc(y[n], b);
+#pragma unroll
+    for (int m = 0; m < MC; ++m) acc[m] = cmacc_u(acc[m], y[m % RC], wq[q * WQ_STRIDE + m]);
 }
 
 // Peak scan over the first S lags (:190-194), this thread's share, ascending n.
@@ -124,28 +137,31 @@ struct RealSrc {
 template <class Src>
 ACQ_HD void fwd_phase1(int tid, int q, const Src& src, const cf* __restrict__ t1, cf* lds) {
     if (tid >= NBF3) return;
+    cf w[2][RA - 1];
+    load_tw1(tid, t1, w);
 #pragma unroll
     for (int h = 0; h < 2; ++h) {
-        const int jp = tid + NBF3 * h;
+        const int jp = 2 * tid + h;
         cf x[RA];
 #pragma unroll
         for (int a = 0; a < RA; ++a) x[a] = src.at(q, jp + NBF1 * a);
-        pass1_store<-1>(x, jp, t1, lds);
+        pass1_store<-1>(x, jp, w[h], lds);
     }
 }
-ACQ_HD void fwd_phase2(int tid, int q, const cf* __restrict__ t2, cf* lds) {
-    if (tid < NBF2) pass2_inplace<-1>(tid, t2 + (long)q * M_SUB, lds);
+ACQ_HD void fwd_phase2(int tid, const cf* __restrict__ t2, cf* lds) {
+    if (tid < NBF2) pass2_inplace<-1>(tid, t2, lds);
 }
 // pass 3 into registers (all threads must finish before fwd_phase3_store overwrites the LDS)
 ACQ_HD void fwd_phase3_load(int tid, const cf* lds, cf* y) {
     if (tid < NBF3) pass3_load<-1>(tid, lds, y);
 }
 // g[k1] = W_N^{q k1} F_q[k1], k1 = 250 n'' + rho, written in natural order
-ACQ_HD void fwd_phase3_store(int tid, int q, const cf* __restrict__ wq, const cf* y, cf* dst) {
+ACQ_HD void fwd_phase3_store(int tid, int q, const cf* __restrict__ bq, const cf* __restrict__ wq, const cf* y, cf* dst) {
     if (tid >= NBF3) return;
     const int rho = pass3_rho(tid);
+    const cf b = bq[q * NBF3 + tid];
 #pragma unroll
-    for (int n = 0; n < RC; ++n) dst[NBF3 * n + rho] = cmul(y[n], wq[q * WQ_STRIDE + n]);
+    for (int n = 0; n < RC; ++n) dst[NBF3 * n + rho] = cmul_u(cmul(y[n], b), wq[q * WQ_STRIDE + n]);
 }
 
 // Radix-8 combine: X[k1 + 5000 s] = sum_q W_8^{q s} g[q][k1]; the result is stored in the

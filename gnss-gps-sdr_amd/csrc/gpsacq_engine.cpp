@@ -45,7 +45,7 @@ struct gpsacq_engine {
     hipStream_t stream = nullptr;
     hipEvent_t ev[4] = {nullptr, nullptr, nullptr, nullptr};
     // constants
-    cf *d_t1 = nullptr, *d_t2 = nullptr, *d_wq = nullptr;
+    cf *d_t1 = nullptr, *d_t2 = nullptr, *d_bq = nullptr, *d_wq = nullptr;
     uint8_t *d_cos = nullptr, *d_sin = nullptr;
     cf* d_code = nullptr;  // [32 + patch_cap][8][crow]
     size_t patch_cap = 0;
@@ -107,6 +107,7 @@ static int run_forward(gpsacq_engine* e, bool bits, const void* src, size_t src_
         fa.sin_mask = e->d_sin;
         fa.t1 = e->d_t1;
         fa.t2 = e->d_t2;
+        fa.bq = e->d_bq;
         fa.wq = e->d_wq;
         fa.g = e->d_g;
         if (bits) launch_fwd_sub_bits(fa, (int)cnt, e->stream);
@@ -130,7 +131,7 @@ extern "C" void gpsacq_destroy(gpsacq_engine* e) {
     if (!e) return;
     (void)hipSetDevice(e->p.device);
     if (e->stream) (void)hipStreamSynchronize(e->stream);
-    void* bufs[] = {e->d_t1, e->d_t2, e->d_wq, e->d_cos, e->d_sin, e->d_code, e->d_patch_blocks, e->d_bits,
+    void* bufs[] = {e->d_t1, e->d_t2, e->d_bq, e->d_wq, e->d_cos, e->d_sin, e->d_code, e->d_patch_blocks, e->d_bits,
                     e->d_g, e->d_dpp, e->d_tasks, e->d_cells, e->d_peaks};
     for (void* b : bufs)
         if (b) (void)hipFree(b);
@@ -199,6 +200,8 @@ extern "C" int gpsacq_create(const gpsacq_params* params, gpsacq_engine** out) {
     HCK(hipMalloc((void**)&e->d_t1, T.t1.size() * sizeof(cf)));
     HCK(hipMalloc((void**)&e->d_t2, T.t2.size() * sizeof(cf)));
     HCK(hipMalloc((void**)&e->d_wq, T.wq.size() * sizeof(cf)));
+    HCK(hipMalloc((void**)&e->d_bq, T.bq.size() * sizeof(cf)));
+    HCK(hipMemcpy(e->d_bq, T.bq.data(), T.bq.size() * sizeof(cf), hipMemcpyHostToDevice));
     HCK(hipMemcpy(e->d_t1, T.t1.data(), T.t1.size() * sizeof(cf), hipMemcpyHostToDevice));
     HCK(hipMemcpy(e->d_t2, T.t2.data(), T.t2.size() * sizeof(cf), hipMemcpyHostToDevice));
     HCK(hipMemcpy(e->d_wq, T.wq.data(), T.wq.size() * sizeof(cf), hipMemcpyHostToDevice));
@@ -336,6 +339,7 @@ static int search_core(gpsacq_engine* e, const uint8_t* d_bits, size_t n_blocks,
     ca.tasks = e->d_tasks;
     ca.t1 = e->d_t1;
     ca.t2 = e->d_t2;
+    ca.bq = e->d_bq;
     ca.wq = e->d_wq;
     ca.cells = d_cells;
     ca.n_tasks = (int)n_tasks;

@@ -24,9 +24,9 @@ static void emul_fwd_sub(const Src& src, int q, cf* g_q /*[5000]*/) {
     std::vector<cf> lds(M_SUB);
     std::vector<cf> regs((size_t)WG * RC);
     for (int tid = 0; tid < WG; ++tid) fwd_phase1(tid, q, src, T.t1.data(), lds.data());
-    for (int tid = 0; tid < WG; ++tid) fwd_phase2(tid, q, T.t2.data(), lds.data());
+    for (int tid = 0; tid < WG; ++tid) fwd_phase2(tid, T.t2.data(), lds.data());
     for (int tid = 0; tid < WG; ++tid) fwd_phase3_load(tid, lds.data(), &regs[(size_t)tid * RC]);
-    for (int tid = 0; tid < WG; ++tid) fwd_phase3_store(tid, q, T.wq.data(), &regs[(size_t)tid * RC], lds.data());
+    for (int tid = 0; tid < WG; ++tid) fwd_phase3_store(tid, q, T.bq.data(), T.wq.data(), &regs[(size_t)tid * RC], lds.data());
     for (int i = 0; i < M_SUB; ++i) g_q[i] = lds[i];
 }
 
@@ -80,17 +80,20 @@ int emul_cell(const float* dspec, const float* cspec, int halo, int dop, int S, 
         }
     std::vector<cf> lds(M_SUB);
     std::vector<cf> acc((size_t)WG * MC_MAX, mk(0.f, 0.f));
+    std::vector<cf> w1((size_t)WG * 2 * (RA - 1));
+    for (int tid = 0; tid < WG; ++tid) load_tw1(tid, T.t1.data(), *reinterpret_cast<cf(*)[2][RA - 1]>(&w1[(size_t)tid * 2 * (RA - 1)]));
     for (int q = 0; q < NPOLY; ++q) {
         for (int tid = 0; tid < WG; ++tid)
-            corr_phase1(tid, q, dop, dpp.data(), cpp.data(), crow, halo, T.t1.data(), lds.data());
-        for (int tid = 0; tid < WG; ++tid) corr_phase2(tid, q, T.t2.data(), lds.data());
+            corr_phase1(tid, q, dop, dpp.data(), cpp.data(), crow, halo,
+                        *reinterpret_cast<cf(*)[2][RA - 1]>(&w1[(size_t)tid * 2 * (RA - 1)]), lds.data());
+        for (int tid = 0; tid < WG; ++tid) corr_phase2(tid, T.t2.data(), lds.data());
         for (int tid = 0; tid < WG; ++tid) {
             cf* a = &acc[(size_t)tid * MC_MAX];
             switch (mc) {
-                case 12: corr_phase3<12>(tid, q, T.wq.data(), lds.data(), a); break;
-                case 22: corr_phase3<22>(tid, q, T.wq.data(), lds.data(), a); break;
-                case 33: corr_phase3<33>(tid, q, T.wq.data(), lds.data(), a); break;
-                case 40: corr_phase3<40>(tid, q, T.wq.data(), lds.data(), a); break;
+                case 12: corr_phase3<12>(tid, q, T.bq.data(), T.wq.data(), lds.data(), a); break;
+                case 22: corr_phase3<22>(tid, q, T.bq.data(), T.wq.data(), lds.data(), a); break;
+                case 33: corr_phase3<33>(tid, q, T.bq.data(), T.wq.data(), lds.data(), a); break;
+                case 40: corr_phase3<40>(tid, q, T.bq.data(), T.wq.data(), lds.data(), a); break;
                 default: return -1;
             }
         }
