@@ -128,6 +128,13 @@ def main():
         value = total_cells / elapsed
         kern_ms = float(np.mean(corr_ms))
         achieved = cells_per_step * ALG_BYTES_PER_CELL / (kern_ms * 1e-3) / 1e9
+        traffic, traffic_src = None, None
+        try:  # HBM bytes per launch from the committed PMC passes (profiles/traffic.json), scaled by cells
+            tj = json.load(open(os.path.join(ROOT, "profiles", "traffic.json")))
+            traffic = (tj["hbm_read_bytes_per_cell"] + tj["hbm_write_bytes_per_cell"]) * cells_per_step
+            traffic_src = f"profiles/{tj['tag']}_summary.md (rocprofv3 --pmc FETCH_SIZE, WRITE_SIZE; bytes per cell x cells per launch)"
+        except Exception:
+            pass
         out = {
             "metric": "(PRN,Doppler) correlation cells/s, 32 PRN @ fs=5.456 MHz",
             "value": value,
@@ -146,7 +153,8 @@ def main():
                        "fs_hz": FS, "if_hz": FC, "blocks_per_gpu": nblk, "cells_per_step_per_gpu": cells_per_step,
                        "parallelism": f"blocks sharded over {world} GPU(s), per-PRN peak all-reduce(MAX)"},
             "roofline": {"bound": "hbm", "kernel": f"k_corr<{eng.acc_columns}>", "achieved": achieved, "peak": HBM_PEAK_GBS,
-                         "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                         "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_src,
+                         "algorithmic_bytes_per_launch": cells_per_step * ALG_BYTES_PER_CELL,
                          "kernel_ms": kern_ms, "algorithmic_bytes_per_cell": ALG_BYTES_PER_CELL,
                          "cells_per_launch": cells_per_step},
             "stage_ms": {k: timing[k] for k in ("ms_total", "ms_sample", "ms_correlate", "ms_peaks")},

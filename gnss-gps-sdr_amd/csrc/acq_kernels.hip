@@ -16,8 +16,6 @@
 // one pair are mapped to one XCD.
 #include <hip/hip_runtime.h>
 
-#include <cstdlib>
-
 #include "acq_launch.hpp"
 #include "acq_phases.hpp"
 
@@ -103,7 +101,7 @@ __global__ __launch_bounds__(WG) void k_quirk_patch(QuirkArgs a) {
 // task on one XCD (block b runs on XCD b % 8) so both spectra are read from that XCD's L2.
 template <int MC, int WPS>
 __global__ __launch_bounds__(WG, WPS) void k_corr(CorrArgs a) {
-    __shared__ cf lds_all[2 * M_SUB];  // [0,5000): transform buffer, [5000,10000): pass-2 twiddles
+    __shared__ cf lds_all[M_SUB + NT2];  // [0,5000): transform buffer, then the 500 pass-2 twiddles
     cf* lds = lds_all;
     cf* t2s = lds_all + M_SUB;
     const int tid = threadIdx.x;
@@ -117,7 +115,7 @@ __global__ __launch_bounds__(WG, WPS) void k_corr(CorrArgs a) {
     const cf* cpp = a.cpp + (size_t)tk.code * NPOLY * a.crow;
 
     // q-independent twiddles: pass 2's table into LDS (16-byte copies), pass 1's into registers
-    for (int i = tid; i < M_SUB / 2; i += WG) reinterpret_cast<cf2*>(t2s)[i] = reinterpret_cast<const cf2*>(a.t2)[i];
+    for (int i = tid; i < NT2; i += WG) t2s[i] = a.t2[i];
     cf w1[2][RA - 1];
     load_tw1(tid, a.t1, w1);
 
@@ -217,17 +215,13 @@ int corr_columns(int nlags) {  // accumulator columns of the smallest instance t
 int launch_corr(const CorrArgs& a, int mc, hipStream_t s) {
     const int groups = (a.n_tasks + 7) / 8;
     const dim3 grid((unsigned)groups * 8u * (unsigned)a.ndop), block(WG);
-    static const int wps = getenv("GPSACQ_WPS") ? atoi(getenv("GPSACQ_WPS")) : 2;  // tuning knob (experiments)
-    static const int pad = getenv("GPSACQ_LDS_PAD") ? atoi(getenv("GPSACQ_LDS_PAD")) : 0;  // occupancy experiments
+    // waves per SIMD the register allocator is held to (k workgroups per CU <=> k waves per SIMD):
+    // LDS (44 KB per workgroup) admits 3 workgroups per CU, so the two common instances ask for 3.
     switch (mc) {
-        case 12: hipLaunchKernelGGL((k_corr<12, 2>), grid, block, 0, s, a); break;
-        case 22:
-            if (wps == 3) hipLaunchKernelGGL((k_corr<22, 3>), grid, block, pad, s, a);
-            else if (wps == 4) hipLaunchKernelGGL((k_corr<22, 4>), grid, block, pad, s, a);
-            else hipLaunchKernelGGL((k_corr<22, 2>), grid, block, pad, s, a);
-            break;
+        case 12: hipLaunchKernelGGL((k_corr<12, 3>), grid, block, 0, s, a); break;
+        case 22: hipLaunchKernelGGL((k_corr<22, 3>), grid, block, 0, s, a); break;
         case 33: hipLaunchKernelGGL((k_corr<33, 2>), grid, block, 0, s, a); break;
-        case 40: hipLaunchKernelGGL((k_corr<40, 1>), grid, block, 0, s, a); break;
+        case 40: hipLaunchKernelGGL((k_corr<40, 2>), grid, block, 0, s, a); break;
         default: return -1;
     }
     return 0;

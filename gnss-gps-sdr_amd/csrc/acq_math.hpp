@@ -47,6 +47,7 @@ constexpr int NBF1 = M_SUB / RA;  // 500 pass-1 butterflies
 constexpr int NBF2 = M_SUB / RB;  // 200 pass-2 butterflies
 constexpr int NBF3 = M_SUB / RC;  // 250 pass-3 butterflies (also the output column height)
 constexpr int NW160 = N_FFT / NBF3;  // 160
+constexpr int NT2 = RB * RC;         // 500 pass-2 twiddles
 constexpr int MC_MAX = 40;           // accumulator columns supported: lags n < 250 * MC_MAX (fs <= 10 MHz)
 constexpr int WQ_STRIDE = MC_MAX;    // wq[q][m] = W_160^{q m}
 
@@ -259,7 +260,7 @@ template <int DIR> ACQ_HD void radix25(const cf* x, cf* y) {
 // LDS passes of one length-5000 transform.  Twiddle tables (acq_tables.hpp):
 //   t1[alpha*500 + j']  = W_5000^{j' alpha}      pass-1 outputs (q-independent; the correlator
 //                                                keeps its 18 values per thread in registers)
-//   t2[beta*200 + e]    = W_500^{j'' beta}       pass-2 outputs, e = 20 alpha + j'' (q-independent;
+//   t2[beta*20 + j'']   = W_500^{j'' beta}       pass-2 outputs (q-independent, 4 KB;
 //                                                the correlator keeps the table in LDS)
 //   bq[q*250 + t3]      = W_40000^{q rho(t3)}    rotation of sub-transform q at pass-3 thread t3
 //   wq[q*40 + m]        = W_160^{q m}            the wave-uniform rest of W_40000^{q n}, n = 250 m + rho
@@ -299,7 +300,7 @@ template <int DIR> ACQ_HD void pass2_inplace(int e, const cf* t2, cf* lds) {
     radix25<DIR>(x, y);
     p[0] = y[0];
 #pragma unroll
-    for (int be = 1; be < RB; ++be) p[be] = tw<DIR>(y[be], t2[be * NBF2 + e]);
+    for (int be = 1; be < RB; ++be) p[be] = tw<DIR>(y[be], t2[be * RC + jpp]);
 }
 
 // pass 3 for butterfly t3 (0..249): y[n''] = F[250 n'' + rho(t3)].

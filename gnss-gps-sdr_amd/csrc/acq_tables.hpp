@@ -22,14 +22,14 @@ inline cf unit_fwd(long long num, long long den) {  // exp(-2 pi i num/den)
 
 struct Tables {
     std::vector<cf> t1;  // [10][500]   W_5000^{j' alpha}
-    std::vector<cf> t2;  // [25][200]   W_500^{j'' beta},  e = 20 alpha + j''
+    std::vector<cf> t2;  // [25][20]    W_500^{j'' beta}
     std::vector<cf> bq;  // [8][250]    W_40000^{q rho(t3)}, rho = 10 (t3 % 25) + t3 / 25
     std::vector<cf> wq;  // [8][40]     W_160^{q m}
-    Tables() : t1(RA * NBF1), t2((size_t)RB * NBF2), bq((size_t)NPOLY * NBF3), wq(NPOLY * WQ_STRIDE) {
+    Tables() : t1(RA * NBF1), t2((size_t)NT2), bq((size_t)NPOLY * NBF3), wq(NPOLY * WQ_STRIDE) {
         for (int al = 0; al < RA; ++al)
             for (int jp = 0; jp < NBF1; ++jp) t1[al * NBF1 + jp] = unit_fwd((long long)jp * al, M_SUB);
         for (int be = 0; be < RB; ++be)
-            for (int e = 0; e < NBF2; ++e) t2[(size_t)be * NBF2 + e] = unit_fwd((long long)(e % RC) * be, NBF1);
+            for (int jpp = 0; jpp < RC; ++jpp) t2[(size_t)be * RC + jpp] = unit_fwd((long long)jpp * be, NBF1);
         for (int q = 0; q < NPOLY; ++q)
             for (int t3 = 0; t3 < NBF3; ++t3) bq[(size_t)q * NBF3 + t3] = unit_fwd((long long)q * pass3_rho(t3), N_FFT);
         for (int q = 0; q < NPOLY; ++q)

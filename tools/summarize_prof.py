@@ -59,5 +59,18 @@ if agg:
         if "SQ_LDS_IDX_ACTIVE" in d:
             lines.append(f"- LDS bank-conflict share of LDS cycles: {d['SQ_LDS_BANK_CONFLICT']/max(d['SQ_LDS_IDX_ACTIVE'],1):.3f}")
         lines.append("")
+# per-cell HBM traffic of the dominant kernel for bench.py's roofline.traffic
+try:
+    d = {c: sum(v) / len(v) for (kk, c), v in agg.items() if "k_corr" in kk}
+    cells = d["_grid"] / 256.0 if "_grid" in d else None  # grid = workgroups*256 threads; one workgroup per cell (padded)
+    if cells and "FETCH_SIZE" in d and "WRITE_SIZE" in d:
+        json.dump({"tag": tag, "kernel": "k_corr", "cells_per_launch_profiled": cells,
+                   "hbm_read_bytes_per_cell": d["FETCH_SIZE"] * 1024 * 2 / cells,
+                   "hbm_write_bytes_per_cell": d["WRITE_SIZE"] * 1024 / cells,
+                   "method": "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate passes; FETCH_SIZE KiB x 2 (gfx950 correction, "
+                             "MI355X_MICROARCH.md section HBM); WRITE_SIZE uncalibrated"},
+                  open(os.path.join(dst, "traffic.json"), "w"), indent=1)
+except Exception as ex:  # noqa
+    print("traffic.json not written:", ex)
 open(os.path.join(dst, f"{tag}_summary.md"), "w").write("\n".join(lines))
 print("\n".join(lines))
