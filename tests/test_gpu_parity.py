@@ -194,3 +194,31 @@ def test_errors(gpsacq_mod):
         # all-zero bits are a valid capture (constant +1 samples): must not produce NaN
         cells, peaks = eng.search(b"\x00" * 5120)
         assert np.isfinite(cells["snr"]).all() and np.isfinite(peaks["snr"]).all()
+
+
+def test_gps_test_cli_stdout(golden_dir):
+    """The C++ front end (same argv handling and printf formats as c/test_search_offline.cpp +
+    SearchTask) against the oracle's SearchTask text on the bundled capture, reference quirk on."""
+    import subprocess
+    from oracle_lib import Oracle
+    from test_host import BANNER, GPS_TEST
+    path = os.path.join(golden_dir, "gps_sig_tmp.bin")
+    env = dict(os.environ, GPSACQ_REF_QUIRKS="1", GPSACQ_BATCH_RUNS="5")
+    r = subprocess.run([GPS_TEST, path, "2.046e6", "8.184e6", "5000"], capture_output=True, text=True, env=env, timeout=300)
+    assert r.returncode == 0, r.stderr
+    assert r.stdout.startswith(BANNER)
+    body = r.stdout[len(BANNER):]
+    orc = Oracle(2.046e6, 8.184e6, 5000.0, ref_quirks=True)
+    n, text, opeaks = orc.search_file(path)
+    assert body.endswith("run out of file!\n") and body.count("satellite:") == n == 12
+    if body != text:  # only last-digit printf rounding of an SNR sitting on an edge may differ
+        a, b = body.split("\n"), text.split("\n")
+        assert len(a) == len(b)
+        diff = [(x, y) for x, y in zip(a, b) if x != y]
+        assert len(diff) <= 3, diff
+        for x, y in diff:
+            xs, ys = x.split(), y.split()
+            assert len(xs) == len(ys) and sum(p != q for p, q in zip(xs, ys)) <= 1
+    # missing file: same message as the reference, exit code 0
+    r = subprocess.run([GPS_TEST, "/nonexistent.bin", "2.046e6", "8.184e6", "5000"], capture_output=True, text=True, timeout=120)
+    assert r.returncode == 0 and r.stdout == BANNER + "can not open file!\n"
