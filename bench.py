@@ -74,16 +74,23 @@ def main():
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU (no CPU fallback)")
-    torch.cuda.set_device(local_rank)
+    # GPSACQ_DIST_BACKEND=gloo lets two ranks share one GPU to smoke-test the N > 1 code path on a
+    # 1-GPU box (collectives then run on CPU copies); the driver's runs use nccl (= RCCL).
+    backend = os.environ.get("GPSACQ_DIST_BACKEND", "nccl")
+    dev_index = local_rank % torch.cuda.device_count() if backend == "gloo" else local_rank
+    torch.cuda.set_device(dev_index)
     dist = None
     if world > 1:
         import torch.distributed as dist
-        dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
+        if backend == "nccl":
+            dist.init_process_group(backend="nccl", device_id=torch.device("cuda", dev_index))
+        else:
+            dist.init_process_group(backend=backend)
 
-    eng = gpsacq.Engine(FC, FS, MAX_FO, device=local_rank)
+    eng = gpsacq.Engine(FC, FS, MAX_FO, device=dev_index)
     nblk = args.blocks
     host_bits = synth_bits(nblk, 1000 + rank)
-    dev = torch.device("cuda", local_rank)
+    dev = torch.device("cuda", dev_index)
     d_bits = torch.from_numpy(host_bits).to(dev)
     d_peaks = torch.zeros((nblk, 4), dtype=torch.int32, device=dev)
     cells_per_step = nblk * eng.num_doppler
@@ -98,7 +105,12 @@ def main():
         key = (snr_bits << 32) | ((0xFFFF - lo) << 16) | ca
         best = key.view(-1, 32).max(dim=0).values
         if dist is not None:
-            dist.all_reduce(best, op=dist.ReduceOp.MAX)  # RCCL over xGMI, 256 bytes
+            if backend == "nccl":
+                dist.all_reduce(best, op=dist.ReduceOp.MAX)  # RCCL over xGMI, 256 bytes
+            else:
+                b = best.cpu()
+                dist.all_reduce(b, op=dist.ReduceOp.MAX)
+                best = b.to(dev)
         return best
 
     def fence():
@@ -117,7 +129,7 @@ def main():
         corr_ms.append(eng.last_timing()["ms_correlate"])
     fence()
     elapsed = time.perf_counter() - t0
-    t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+    t = torch.tensor([elapsed], dtype=torch.float64, device=dev if backend == "nccl" else "cpu")
     if dist is not None:
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
     elapsed = float(t.item())
