@@ -16,10 +16,17 @@
 // one pair are mapped to one XCD.
 #include <hip/hip_runtime.h>
 
+#include <cstdlib>
+
 #include "acq_launch.hpp"
 #include "acq_phases.hpp"
 
 namespace acq {
+
+// wq[q][m] = W_160^{q m}: the wave-uniform part of the radix-8 rotation.  Constant address space
+// so that hipcc reads it with scalar loads and feeds the packed FMAs from SGPR pairs.
+__constant__ cf c_wq[NPOLY * WQ_STRIDE];
+hipError_t upload_wq(const cf* host) { return hipMemcpyToSymbol(HIP_SYMBOL(c_wq), host, sizeof(cf) * NPOLY * WQ_STRIDE); }
 
 // ---------------------------------------------------------------------------------------
 template <class Src> struct SrcOf;
@@ -99,11 +106,10 @@ __global__ __launch_bounds__(WG) void k_quirk_patch(QuirkArgs a) {
 // ---------------------------------------------------------------------------------------
 // One workgroup per (task, Doppler bin).  blockIdx -> cell map keeps the 2*dmax+1 cells of a
 // task on one XCD (block b runs on XCD b % 8) so both spectra are read from that XCD's L2.
-template <int MC, int WPS>
+template <int MC, int WPS, int NB>
 __global__ __launch_bounds__(WG, WPS) void k_corr(CorrArgs a) {
-    __shared__ cf lds_all[M_SUB + NT2];  // [0,5000): transform buffer, then the 500 pass-2 twiddles
-    cf* lds = lds_all;
-    cf* t2s = lds_all + M_SUB;
+    __shared__ cf lds[M_SUB];  // transform buffer
+    __shared__ cf t2s[NT2];    // the 500 pass-2 twiddles
     const int tid = threadIdx.x;
     const int g = blockIdx.x, xcd = g & 7, slot = g >> 3;
     const int grp = slot / a.ndop, di = slot - grp * a.ndop;
@@ -123,12 +129,17 @@ __global__ __launch_bounds__(WG, WPS) void k_corr(CorrArgs a) {
 #pragma unroll
     for (int m = 0; m < MC; ++m) acc[m] = mk(0.f, 0.f);
 
+    const int t3 = tid < NBF3 ? tid : 0;
     for (int q = 0; q < NPOLY; ++q) {
-        corr_phase1(tid, q, dop, dpp, cpp, a.crow, a.halo, w1, lds);
+        const cf b = a.bq[q * NBF3 + t3];  // per-thread rotation of this sub-transform
+        cf wqv[MC];                        // wave-uniform rotations: scalar loads, SGPR operands
+#pragma unroll
+        for (int m = 0; m < MC; ++m) wqv[m] = c_wq[q * WQ_STRIDE + m];
+        corr_phase1<NB>(tid, q, dop, dpp, cpp, a.crow, a.halo, w1, lds);
         __syncthreads();  // also orders the t2s fill before its first use
         corr_phase2(tid, t2s, lds);
         __syncthreads();
-        corr_phase3<MC>(tid, q, a.bq, a.wq, lds, acc);
+        corr_phase3<MC>(tid, b, wqv, lds, acc);
         __syncthreads();
     }
 
@@ -217,11 +228,17 @@ int launch_corr(const CorrArgs& a, int mc, hipStream_t s) {
     const dim3 grid((unsigned)groups * 8u * (unsigned)a.ndop), block(WG);
     // waves per SIMD the register allocator is held to (k workgroups per CU <=> k waves per SIMD):
     // LDS (44 KB per workgroup) admits 3 workgroups per CU, so the two common instances ask for 3.
+    static const int var = getenv("GPSACQ_VAR") ? atoi(getenv("GPSACQ_VAR")) : 0;  // tuning experiments
     switch (mc) {
-        case 12: hipLaunchKernelGGL((k_corr<12, 3>), grid, block, 0, s, a); break;
-        case 22: hipLaunchKernelGGL((k_corr<22, 3>), grid, block, 0, s, a); break;
-        case 33: hipLaunchKernelGGL((k_corr<33, 2>), grid, block, 0, s, a); break;
-        case 40: hipLaunchKernelGGL((k_corr<40, 2>), grid, block, 0, s, a); break;
+        case 12: hipLaunchKernelGGL((k_corr<12, 3, 2>), grid, block, 0, s, a); break;
+        case 22:
+            if (var == 1) hipLaunchKernelGGL((k_corr<22, 2, 1>), grid, block, 0, s, a);
+            else if (var == 2) hipLaunchKernelGGL((k_corr<22, 2, 2>), grid, block, 0, s, a);
+            else if (var == 3) hipLaunchKernelGGL((k_corr<22, 3, 1>), grid, block, 0, s, a);
+            else hipLaunchKernelGGL((k_corr<22, 3, 2>), grid, block, 0, s, a);
+            break;
+        case 33: hipLaunchKernelGGL((k_corr<33, 2, 2>), grid, block, 0, s, a); break;
+        case 40: hipLaunchKernelGGL((k_corr<40, 2, 2>), grid, block, 0, s, a); break;
         default: return -1;
     }
     return 0;

@@ -54,6 +54,7 @@ void launch_fwd_combine(const CombineArgs& a, int n_items, hipStream_t s);
 void launch_code_halo(cf* cpp, int n_rows, int crow, int halo, hipStream_t s);
 void launch_quirk_patch(const QuirkArgs& a, int n_patch, hipStream_t s);
 int corr_columns(int nlags);
+hipError_t upload_wq(const cf* host);  // fills the __constant__ copy of wq on the current device
 int launch_corr(const CorrArgs& a, int mc, hipStream_t s);
 void launch_peaks(const Cell* cells, Peak* peaks, int n_tasks, int ndop, int dop_first, hipStream_t s);
 

@@ -58,10 +58,10 @@ ACQ_HD cf mk(float x, float y) { cf r; r.x = x; r.y = y; return r; }
 // a * w
 ACQ_HD cf cmul(cf a, cf w) {
 #if ACQ_PK_ASM
-    cf t, r;
-    asm("v_pk_mul_f32 %0, %1, %2 op_sel_hi:[0,1]" : "=v"(t) : "v"(a), "v"(w));  // (ax wx, ax wy)
-    asm("v_pk_fma_f32 %0, %1, %2, %3 op_sel:[1,1,0] op_sel_hi:[1,0,1] neg_lo:[0,1,0]" : "=v"(r) : "v"(a), "v"(w), "v"(t));
-    return r;  // (ax wx - ay wy, ax wy + ay wx)
+    cf r;  // t = (ax wx, ax wy);  r = (t.x - ay wy, t.y + ay wx)
+    asm("v_pk_mul_f32 %0, %1, %2 op_sel_hi:[0,1]\n\t"
+        "v_pk_fma_f32 %0, %1, %2, %0 op_sel:[1,1,0] op_sel_hi:[1,0,1] neg_lo:[0,1,0]" : "=&v"(r) : "v"(a), "v"(w));
+    return r;
 #else
     return mk(a.x * w.x - a.y * w.y, a.x * w.y + a.y * w.x);
 #endif
@@ -69,10 +69,10 @@ ACQ_HD cf cmul(cf a, cf w) {
 // a * conj(w)
 ACQ_HD cf cmulc(cf a, cf w) {
 #if ACQ_PK_ASM
-    cf t, r;
-    asm("v_pk_mul_f32 %0, %1, %2 op_sel_hi:[1,0]" : "=v"(t) : "v"(a), "v"(w));  // (ax wx, ay wx)
-    asm("v_pk_fma_f32 %0, %1, %2, %3 op_sel:[1,1,0] op_sel_hi:[0,1,1] neg_hi:[1,0,0]" : "=v"(r) : "v"(a), "v"(w), "v"(t));
-    return r;  // (ax wx + ay wy, ay wx - ax wy)
+    cf r;  // t = (ax wx, ay wx);  r = (t.x + ay wy, t.y - ax wy)
+    asm("v_pk_mul_f32 %0, %1, %2 op_sel_hi:[1,0]\n\t"
+        "v_pk_fma_f32 %0, %1, %2, %0 op_sel:[1,1,0] op_sel_hi:[0,1,1] neg_hi:[1,0,0]" : "=&v"(r) : "v"(a), "v"(w));
+    return r;
 #else
     return mk(a.x * w.x + a.y * w.y, a.y * w.x - a.x * w.y);
 #endif
@@ -80,9 +80,9 @@ ACQ_HD cf cmulc(cf a, cf w) {
 // same with a wave-uniform multiplier held in an SGPR pair (compile-time constants, scalar loads)
 ACQ_HD cf cmul_u(cf a, cf w) {
 #if ACQ_PK_ASM
-    cf t, r;
-    asm("v_pk_mul_f32 %0, %1, %2 op_sel_hi:[0,1]" : "=v"(t) : "v"(a), "s"(w));
-    asm("v_pk_fma_f32 %0, %1, %2, %3 op_sel:[1,1,0] op_sel_hi:[1,0,1] neg_lo:[0,1,0]" : "=v"(r) : "v"(a), "s"(w), "v"(t));
+    cf r;
+    asm("v_pk_mul_f32 %0, %1, %2 op_sel_hi:[0,1]\n\t"
+        "v_pk_fma_f32 %0, %1, %2, %0 op_sel:[1,1,0] op_sel_hi:[1,0,1] neg_lo:[0,1,0]" : "=&v"(r) : "v"(a), "s"(w));
     return r;
 #else
     return cmul(a, w);
@@ -90,9 +90,9 @@ ACQ_HD cf cmul_u(cf a, cf w) {
 }
 ACQ_HD cf cmulc_u(cf a, cf w) {
 #if ACQ_PK_ASM
-    cf t, r;
-    asm("v_pk_mul_f32 %0, %1, %2 op_sel_hi:[1,0]" : "=v"(t) : "v"(a), "s"(w));
-    asm("v_pk_fma_f32 %0, %1, %2, %3 op_sel:[1,1,0] op_sel_hi:[0,1,1] neg_hi:[1,0,0]" : "=v"(r) : "v"(a), "s"(w), "v"(t));
+    cf r;
+    asm("v_pk_mul_f32 %0, %1, %2 op_sel_hi:[1,0]\n\t"
+        "v_pk_fma_f32 %0, %1, %2, %0 op_sel:[1,1,0] op_sel_hi:[0,1,1] neg_hi:[1,0,0]" : "=&v"(r) : "v"(a), "s"(w));
     return r;
 #else
     return cmulc(a, w);
@@ -101,9 +101,9 @@ ACQ_HD cf cmulc_u(cf a, cf w) {
 // acc + a * conj(w), w wave-uniform
 ACQ_HD cf cmacc_u(cf acc, cf a, cf w) {
 #if ACQ_PK_ASM
-    cf t, r;
-    asm("v_pk_fma_f32 %0, %1, %2, %3 op_sel_hi:[1,0,1]" : "=v"(t) : "v"(a), "s"(w), "v"(acc));  // acc + (ax wx, ay wx)
-    asm("v_pk_fma_f32 %0, %1, %2, %3 op_sel:[1,1,0] op_sel_hi:[0,1,1] neg_hi:[1,0,0]" : "=v"(r) : "v"(a), "s"(w), "v"(t));
+    cf r = acc;  // r += (ax wx, ay wx);  r += (ay wy, -ax wy)
+    asm("v_pk_fma_f32 %0, %1, %2, %0 op_sel_hi:[1,0,1]\n\t"
+        "v_pk_fma_f32 %0, %1, %2, %0 op_sel:[1,1,0] op_sel_hi:[0,1,1] neg_hi:[1,0,0]" : "+v"(r) : "v"(a), "s"(w));
     return r;
 #else
     return acc + cmulc(a, w);
@@ -290,8 +290,9 @@ template <int DIR> ACQ_HD void pass1_store(const cf* x, int jp, const cf* w, cf*
     for (int al = 1; al < RA; ++al) dst[NBF1 * al] = tw<DIR>(y[al], w[al - 1]);
 }
 
-// pass 2 for butterfly e (0..199), in place; t2 may live in LDS or global memory.
-template <int DIR> ACQ_HD void pass2_inplace(int e, const cf* t2, cf* lds) {
+// pass 2 for butterfly e (0..199), in place; t2 may live in LDS (its own allocation, so the
+// compiler knows the in-place stores do not alias it) or in global memory.
+template <int DIR> ACQ_HD void pass2_inplace(int e, const cf* __restrict__ t2, cf* lds) {
     const int al = e / RC, jpp = e - al * RC;
     cf* p = lds + NBF1 * al + RB * jpp;
     cf x[RB], y[RB];

@@ -54,6 +54,14 @@ ACQ_HD void load_tw1(int tid, const cf* __restrict__ t1, cf (&w)[2][RA - 1]) {
 
 // ---------------------------------------------------------------------------------------
 // Correlate(): prod = conj(data) * shifted code (:181-185) fused into pass 1 of IDFT_5000.
+// The 20 loads are issued in NB batches; a scheduling barrier after each batch keeps hipcc from
+// sinking them next to their first use (it otherwise emits load, s_waitcnt vmcnt(0), use, load ...).
+#if defined(__HIP_DEVICE_COMPILE__)
+#define ACQ_SCHED_FENCE() __builtin_amdgcn_sched_barrier(0)
+#else
+#define ACQ_SCHED_FENCE() ((void)0)
+#endif
+template <int NB>
 ACQ_HD void corr_phase1(int tid, int q, int dop, const cf* __restrict__ dpp, const cf* __restrict__ cpp,
                         int crow, int halo, const cf (&w)[2][RA - 1], cf* lds) {
     if (tid >= NBF3) return;
@@ -62,13 +70,21 @@ ACQ_HD void corr_phase1(int tid, int q, int dop, const cf* __restrict__ dpp, con
     const cf* drow = dpp + q * M_SUB + 2 * tid;
     const cf* crw = cpp + (long)qp * crow + halo + c + 2 * tid;
     cf x0[RA], x1[RA];
+    constexpr int PER = RA / NB;
 #pragma unroll
-    for (int a = 0; a < RA; ++a) {
-        cf d0, d1, c0, c1;
-        ld2(drow + NBF1 * a, d0, d1);
-        ld2u(crw + NBF1 * a, c0, c1);  // c is arbitrary: 8-byte aligned only
-        x0[a] = cmul(d0, c0);
-        x1[a] = cmul(d1, c1);
+    for (int b = 0; b < NB; ++b) {
+        cf2 d[PER], cc[PER];
+#pragma unroll
+        for (int i = 0; i < PER; ++i) {
+            d[i] = *reinterpret_cast<const cf2*>(drow + NBF1 * (b * PER + i));
+            cc[i] = *reinterpret_cast<const cf2_a8*>(crw + NBF1 * (b * PER + i));  // arbitrary shift: 8-byte aligned only
+        }
+        ACQ_SCHED_FENCE();
+#pragma unroll
+        for (int i = 0; i < PER; ++i) {
+            x0[b * PER + i] = cmul(d[i].xy, cc[i].xy);
+            x1[b * PER + i] = cmul(d[i].zw, cc[i].zw);
+        }
     }
     pass1_store<+1>(x0, 2 * tid, w[0], lds);
     pass1_store<+1>(x1, 2 * tid + 1, w[1], lds);
@@ -79,17 +95,16 @@ ACQ_HD void corr_phase2(int tid, const cf* t2, cf* lds) {
 }
 
 // acc[m] accumulates y[n] for n = 250 m + rho over the 8 polyphase components:
-// W_N^{-q n} = conj(bq[q][tid]) (per thread) * conj(W_160^{q m}) (wave-uniform).
+// W_N^{-q n} = conj(b) (per thread, b = bq[q][tid]) * conj(wqv[m]) (wave-uniform, wqv[m] = W_160^{q m}).
 template <int MC>
-ACQ_HD void corr_phase3(int tid, int q, const cf* __restrict__ bq, const cf* __restrict__ wq, const cf* lds, cf* acc) {
+ACQ_HD void corr_phase3(int tid, cf b, const cf* wqv, const cf* lds, cf* acc) {
     if (tid >= NBF3) return;
-    const cf b = bq[q * NBF3 + tid];
     cf y[RC];
     pass3_load<+1>(tid, lds, y);
 #pragma unroll
     for (int n = 0; n < RC; ++n) y[n] = cmulc(y[n], b);
 #pragma unroll
-    for (int m = 0; m < MC; ++m) acc[m] = cmacc_u(acc[m], y[m % RC], wq[q * WQ_STRIDE + m]);
+    for (int m = 0; m < MC; ++m) acc[m] = cmacc_u(acc[m], y[m % RC], wqv[m]);
 }
 
 // Peak scan over the first S lags (:190-194), this thread's share, ascending n.
@@ -101,13 +116,13 @@ ACQ_HD void corr_scan(int tid, int S, const cf* acc, float& mx, int& mi, float& 
     if (tid >= NBF3) return;
     const int rho = pass3_rho(tid);
 #pragma unroll
-    for (int m = 0; m < MC; ++m) {
+    for (int m = 0; m < MC; ++m) {  // branch-free: lags beyond S contribute a power of 0
         const int n = NBF3 * m + rho;
-        if (n < S) {
-            const float p = acc[m].x * acc[m].x + acc[m].y * acc[m].y;
-            if (p > mx) { mx = p; mi = n; }
-            sum += p;
-        }
+        const float p = (n < S) ? acc[m].x * acc[m].x + acc[m].y * acc[m].y : 0.f;
+        const bool up = p > mx;
+        mx = up ? p : mx;
+        mi = up ? n : mi;
+        sum += p;
     }
 }
 // strict '>' first-wins of the reference == larger power, ties to the lower lag

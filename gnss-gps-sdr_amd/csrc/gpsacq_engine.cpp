@@ -200,6 +200,7 @@ extern "C" int gpsacq_create(const gpsacq_params* params, gpsacq_engine** out) {
     HCK(hipMalloc((void**)&e->d_t1, T.t1.size() * sizeof(cf)));
     HCK(hipMalloc((void**)&e->d_t2, T.t2.size() * sizeof(cf)));
     HCK(hipMalloc((void**)&e->d_wq, T.wq.size() * sizeof(cf)));
+    HCK(upload_wq(T.wq.data()));
     HCK(hipMalloc((void**)&e->d_bq, T.bq.size() * sizeof(cf)));
     HCK(hipMemcpy(e->d_bq, T.bq.data(), T.bq.size() * sizeof(cf), hipMemcpyHostToDevice));
     HCK(hipMemcpy(e->d_t1, T.t1.data(), T.t1.size() * sizeof(cf), hipMemcpyHostToDevice));

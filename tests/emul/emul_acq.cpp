@@ -84,16 +84,16 @@ int emul_cell(const float* dspec, const float* cspec, int halo, int dop, int S, 
     for (int tid = 0; tid < WG; ++tid) load_tw1(tid, T.t1.data(), *reinterpret_cast<cf(*)[2][RA - 1]>(&w1[(size_t)tid * 2 * (RA - 1)]));
     for (int q = 0; q < NPOLY; ++q) {
         for (int tid = 0; tid < WG; ++tid)
-            corr_phase1(tid, q, dop, dpp.data(), cpp.data(), crow, halo,
-                        *reinterpret_cast<cf(*)[2][RA - 1]>(&w1[(size_t)tid * 2 * (RA - 1)]), lds.data());
+            corr_phase1<2>(tid, q, dop, dpp.data(), cpp.data(), crow, halo,
+                           *reinterpret_cast<cf(*)[2][RA - 1]>(&w1[(size_t)tid * 2 * (RA - 1)]), lds.data());
         for (int tid = 0; tid < WG; ++tid) corr_phase2(tid, T.t2.data(), lds.data());
         for (int tid = 0; tid < WG; ++tid) {
             cf* a = &acc[(size_t)tid * MC_MAX];
             switch (mc) {
-                case 12: corr_phase3<12>(tid, q, T.bq.data(), T.wq.data(), lds.data(), a); break;
-                case 22: corr_phase3<22>(tid, q, T.bq.data(), T.wq.data(), lds.data(), a); break;
-                case 33: corr_phase3<33>(tid, q, T.bq.data(), T.wq.data(), lds.data(), a); break;
-                case 40: corr_phase3<40>(tid, q, T.bq.data(), T.wq.data(), lds.data(), a); break;
+                case 12: corr_phase3<12>(tid, T.bq[(size_t)q * NBF3 + (tid < NBF3 ? tid : 0)], &T.wq[(size_t)q * WQ_STRIDE], lds.data(), a); break;
+                case 22: corr_phase3<22>(tid, T.bq[(size_t)q * NBF3 + (tid < NBF3 ? tid : 0)], &T.wq[(size_t)q * WQ_STRIDE], lds.data(), a); break;
+                case 33: corr_phase3<33>(tid, T.bq[(size_t)q * NBF3 + (tid < NBF3 ? tid : 0)], &T.wq[(size_t)q * WQ_STRIDE], lds.data(), a); break;
+                case 40: corr_phase3<40>(tid, T.bq[(size_t)q * NBF3 + (tid < NBF3 ? tid : 0)], &T.wq[(size_t)q * WQ_STRIDE], lds.data(), a); break;
                 default: return -1;
             }
         }
