@@ -16,8 +16,6 @@
 // one pair are mapped to one XCD.
 #include <hip/hip_runtime.h>
 
-#include <cstdlib>
-
 #include "acq_launch.hpp"
 #include "acq_phases.hpp"
 
@@ -228,15 +226,11 @@ int launch_corr(const CorrArgs& a, int mc, hipStream_t s) {
     const dim3 grid((unsigned)groups * 8u * (unsigned)a.ndop), block(WG);
     // waves per SIMD the register allocator is held to (k workgroups per CU <=> k waves per SIMD):
     // LDS (44 KB per workgroup) admits 3 workgroups per CU, so the two common instances ask for 3.
-    static const int var = getenv("GPSACQ_VAR") ? atoi(getenv("GPSACQ_VAR")) : 0;  // tuning experiments
+    // <columns, waves per SIMD the allocator is held to, load batches>.  LDS (44 KB per workgroup)
+    // admits 3 workgroups per CU; the two small instances fit 168 VGPRs without spilling.
     switch (mc) {
         case 12: hipLaunchKernelGGL((k_corr<12, 3, 2>), grid, block, 0, s, a); break;
-        case 22:
-            if (var == 1) hipLaunchKernelGGL((k_corr<22, 2, 1>), grid, block, 0, s, a);
-            else if (var == 2) hipLaunchKernelGGL((k_corr<22, 2, 2>), grid, block, 0, s, a);
-            else if (var == 3) hipLaunchKernelGGL((k_corr<22, 3, 1>), grid, block, 0, s, a);
-            else hipLaunchKernelGGL((k_corr<22, 3, 2>), grid, block, 0, s, a);
-            break;
+        case 22: hipLaunchKernelGGL((k_corr<22, 3, 2>), grid, block, 0, s, a); break;
         case 33: hipLaunchKernelGGL((k_corr<33, 2, 2>), grid, block, 0, s, a); break;
         case 40: hipLaunchKernelGGL((k_corr<40, 2, 2>), grid, block, 0, s, a); break;
         default: return -1;
