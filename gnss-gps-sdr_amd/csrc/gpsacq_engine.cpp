@@ -5,6 +5,7 @@
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
+#include <cmath>
 #include <cstdarg>
 #include <cstdio>
 #include <cstring>
@@ -416,6 +417,24 @@ extern "C" int gpsacq_last_timing(const gpsacq_engine* e, gpsacq_timing* t) {
     HIPCHK(hipEventElapsedTime(&t->ms_peaks, e->ev[2], e->ev[3]));
     t->correlate_launches = e->corr_launches;
     t->cells = e->cells_done;
+    return GPSACQ_OK;
+}
+
+extern "C" int gpsacq_handoff(const gpsacq_peak* peak, double fc, double fs, double secs, gpsacq_handoff_t* out) {
+    if (!peak || !out || !(fs > 0)) return fail(GPSACQ_ERR_ARG, "gpsacq_handoff: bad argument");
+    const double L1 = 1575.42e6, CPS = 1.023e6;  // c/gps_offline.h:22,30
+    const double lo_dop = peak->lo_shift * fs / N_FFT;
+    const double ca_dop = lo_dop / L1 * CPS;
+    out->lo_dop_hz = lo_dop;
+    out->ca_dop_hz = ca_dop;
+    out->lo_rate = (uint32_t)((fc + lo_dop) / fs * 4294967296.0);
+    out->ca_rate = (uint32_t)((CPS + ca_dop) / fs * 4294967296.0);
+    const int spm = num_lags(fs);
+    int ca = peak->ca_shift + (int)nearbyint(ca_dop * secs * fs / CPS);
+    out->ca_shift = ca;
+    int pause = (2 * spm - ca) % spm;
+    if (pause < 0) pause += spm;
+    out->ca_pause = (uint32_t)pause;
     return GPSACQ_OK;
 }
 

@@ -43,7 +43,12 @@ class Timing(ctypes.Structure):
                 ("ms_peaks", ctypes.c_float), ("correlate_launches", ctypes.c_int32), ("cells", ctypes.c_int64)]
 
 
-EXPORTS = ["gpsacq_create", "gpsacq_destroy", "gpsacq_last_error", "gpsacq_get_info", "gpsacq_search",
+class Handoff(ctypes.Structure):
+    _fields_ = [("lo_dop_hz", ctypes.c_double), ("ca_dop_hz", ctypes.c_double), ("lo_rate", ctypes.c_uint32),
+                ("ca_rate", ctypes.c_uint32), ("ca_shift", ctypes.c_int32), ("ca_pause", ctypes.c_uint32)]
+
+
+EXPORTS = ["gpsacq_handoff", "gpsacq_create", "gpsacq_destroy", "gpsacq_last_error", "gpsacq_get_info", "gpsacq_search",
            "gpsacq_search_device", "gpsacq_set_doppler_window", "gpsacq_synchronize", "gpsacq_last_timing", "gpsacq_search_code",
            "gpsacq_sample_spectrum", "gpsacq_code_spectrum"]
 
@@ -79,6 +84,8 @@ def load_library(path=None):
     lib.gpsacq_synchronize.restype = ctypes.c_int
     lib.gpsacq_last_timing.argtypes = [vp, ctypes.POINTER(Timing)]
     lib.gpsacq_last_timing.restype = ctypes.c_int
+    lib.gpsacq_handoff.argtypes = [vp, ctypes.c_double, ctypes.c_double, ctypes.c_double, ctypes.POINTER(Handoff)]
+    lib.gpsacq_handoff.restype = ctypes.c_int
     lib.gpsacq_search_code.argtypes = [ctypes.c_int, ctypes.c_int]
     lib.gpsacq_search_code.restype = ctypes.c_int
     lib.gpsacq_sample_spectrum.argtypes = [vp, vp, vp]
@@ -99,6 +106,16 @@ class GpsAcqError(RuntimeError):
 def _check(lib, rc):
     if rc != 0:
         raise GpsAcqError(rc, lib.gpsacq_last_error().decode(errors="replace"))
+
+
+def handoff(peak, fc, fs, secs_since_sample=0.0):
+    """CHANNEL::Start()'s NCO set-up from a search hit (c/channel.cpp:134-163).  peak: a PEAK_DTYPE record."""
+    lib = load_library()
+    pk = np.zeros(1, dtype=PEAK_DTYPE)
+    pk[0] = peak
+    h = Handoff()
+    _check(lib, lib.gpsacq_handoff(pk.ctypes.data_as(ctypes.c_void_p), float(fc), float(fs), float(secs_since_sample), ctypes.byref(h)))
+    return {k: getattr(h, k) for k, _ in Handoff._fields_}
 
 
 def search_code(sv, g1):

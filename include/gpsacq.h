@@ -16,6 +16,8 @@
  *                            SearchTask() loop, :239-246)
  *   gpsacq_search_device     same, capture already resident in HBM
  *   gpsacq_search_code       SearchCode()            c/search_offline.cpp:205-209
+ *   gpsacq_handoff           CHANNEL::Start()'s NCO set-up from a search hit, c/channel.cpp:134-163
+ *                            (the first consumer of the search result in the online receiver)
  *   gpsacq_sample_spectrum   Sample()'s fwd_buf      c/search_offline.cpp:161 (parity probe)
  *   gpsacq_code_spectrum     SearchInit()'s code[sv] c/search_offline.cpp:105-106 (parity probe)
  *
@@ -135,6 +137,21 @@ int gpsacq_search_device(gpsacq_engine* e, const void* d_bits, size_t n_blocks, 
 int gpsacq_set_doppler_window(gpsacq_engine* e, int first_bin, int n_bins);
 int gpsacq_synchronize(gpsacq_engine* e);
 int gpsacq_last_timing(const gpsacq_engine* e, gpsacq_timing* t);
+
+/*
+ * Acquisition hand-off record: what the tracking channel derives from a search hit
+ * (c/channel.cpp:144-163).  Host arithmetic only; no device needed.
+ */
+typedef struct {
+    double lo_dop_hz;   /* carrier Doppler estimate  = lo_shift * fs / 40000                  (:145) */
+    double ca_dop_hz;   /* code-rate Doppler         = lo_dop / L1 * 1.023e6                  (:146) */
+    uint32_t lo_rate;   /* carrier NCO word          = (fc  + lo_dop) / fs * 2^32             (:149) */
+    uint32_t ca_rate;   /* code NCO word             = (CPS + ca_dop) / fs * 2^32             (:150) */
+    int32_t ca_shift;   /* code phase after creep    = ca_shift + nearbyint(ca_dop*secs*fs/CPS) (:160) */
+    uint32_t ca_pause;  /* NCO pause to align the code generator = (2*spm - ca_shift) % spm, spm = samples
+                           per millisecond (the reference hard-codes 20000 / 10000 for its 10 MHz FPGA, :163) */
+} gpsacq_handoff_t;
+int gpsacq_handoff(const gpsacq_peak* peak, double fc, double fs, double secs_since_sample, gpsacq_handoff_t* out);
 
 /* SearchCode(): chips to clock PRN sv's generator until its G1 register reads g1 (-1 if never) */
 int gpsacq_search_code(int sv, int g1);

@@ -77,3 +77,27 @@ def test_product_does_not_touch_oracle():
     assert not bad, bad
     out = subprocess.run(["ldd", os.path.join(ROOT, "gnss-gps-sdr_amd", "lib", "libgpsacq.so")], capture_output=True, text=True).stdout
     assert "oracle" not in out and "emul" not in out and "amdhip64" in out
+
+
+def test_handoff_matches_channel_start():
+    """gpsacq_handoff against a direct restatement of c/channel.cpp:144-163 (host arithmetic)."""
+    import math
+    import numpy as np
+    import gpsacq
+    L1, CPS, N = 1575.42e6, 1.023e6, 40000
+    for fc, fs, lo, ca, secs in [(4.092e6, 5.456e6, 6, 1465, 0.0), (4.092e6, 5.456e6, -9, 3868, 0.35),
+                                 (2.6e6, 10e6, 12, 9999, 1.25), (0.62e6, 2.8e6, -700, 5, 0.01)]:
+        pk = np.zeros(1, gpsacq.PEAK_DTYPE)[0]
+        pk["lo_shift"], pk["ca_shift"], pk["snr"] = lo, ca, 100.0
+        h = gpsacq.handoff(pk, fc, fs, secs)
+        lo_dop = lo * fs / N
+        ca_dop = lo_dop / L1 * CPS
+        assert h["lo_dop_hz"] == lo_dop and h["ca_dop_hz"] == ca_dop
+        assert h["lo_rate"] == int((fc + lo_dop) / fs * 2 ** 32) and h["ca_rate"] == int((CPS + ca_dop) / fs * 2 ** 32)
+        spm = int(math.ceil(fs / 1000))
+        ca2 = ca + int(np.rint(ca_dop * secs * fs / CPS))
+        assert h["ca_shift"] == ca2 and h["ca_pause"] == (2 * spm - ca2) % spm
+    # fs = 10 MHz reproduces the reference's literal (20000 - ca_shift) % 10000
+    pk = np.zeros(1, gpsacq.PEAK_DTYPE)[0]
+    pk["lo_shift"], pk["ca_shift"] = 3, 1234
+    assert gpsacq.handoff(pk, 2.6e6, 10e6)["ca_pause"] == (20000 - 1234) % 10000
