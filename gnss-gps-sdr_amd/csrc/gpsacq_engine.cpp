@@ -15,6 +15,7 @@
 #include "../../include/gpsacq.h"
 #include "acq_launch.hpp"
 #include "acq_tables.hpp"
+#include "iq_launch.hpp"
 
 using namespace acq;
 
@@ -60,6 +61,12 @@ struct gpsacq_engine {
     Cell* d_cells = nullptr;
     Peak* d_peaks = nullptr;
     size_t task_cap = 0, cell_cap = 0, peak_cap = 0;
+    // 8-bit IQ ingestion scratch
+    uint8_t* d_iq = nullptr;
+    size_t iq_cap = 0;
+    uint8_t* d_iqbits = nullptr;
+    size_t iqbits_cap = 0;
+    unsigned long long* d_sums = nullptr;
     // cached default schedule
     size_t sched_tasks = 0;
     bool sched_valid = false;
@@ -132,7 +139,7 @@ extern "C" void gpsacq_destroy(gpsacq_engine* e) {
     if (!e) return;
     (void)hipSetDevice(e->p.device);
     if (e->stream) (void)hipStreamSynchronize(e->stream);
-    void* bufs[] = {e->d_t1, e->d_t2, e->d_bq, e->d_wq, e->d_cos, e->d_sin, e->d_code, e->d_patch_blocks, e->d_bits,
+    void* bufs[] = {e->d_t1, e->d_t2, e->d_bq, e->d_wq, e->d_cos, e->d_sin, e->d_code, e->d_patch_blocks, e->d_bits, e->d_iq, e->d_iqbits, e->d_sums,
                     e->d_g, e->d_dpp, e->d_tasks, e->d_cells, e->d_peaks};
     for (void* b : bufs)
         if (b) (void)hipFree(b);
@@ -417,6 +424,53 @@ extern "C" int gpsacq_last_timing(const gpsacq_engine* e, gpsacq_timing* t) {
     HIPCHK(hipEventElapsedTime(&t->ms_peaks, e->ev[2], e->ev[3]));
     t->correlate_launches = e->corr_launches;
     t->cells = e->cells_done;
+    return GPSACQ_OK;
+}
+
+// 8-bit IQ -> 1-bit real IF (proc_rtl_bin_for_gps.m / proc_hackrf_bin_for_gps.m), device buffers
+extern "C" int gpsacq_iq8_to_bits_device(gpsacq_engine* e, const void* d_iq, size_t n_samples, int format, int remove_dc,
+                                         double mix_hz, double fs, void* d_bits, int sync) {
+    if (!e || !d_iq || !d_bits || n_samples == 0) return fail(GPSACQ_ERR_ARG, "gpsacq_iq8_to_bits_device: bad argument");
+    if (format != GPSACQ_IQ_U8 && format != GPSACQ_IQ_S8) return fail(GPSACQ_ERR_ARG, "unknown IQ format %d", format);
+    if (((uintptr_t)d_iq & 15) != 0) return fail(GPSACQ_ERR_ARG, "IQ buffer must be 16-byte aligned");
+    if (!(fs > 0)) fs = e->p.fs;
+    HIPCHK(hipSetDevice(e->p.device));
+    IqArgs a{};
+    a.iq = (const uint8_t*)d_iq;
+    a.bits = (uint8_t*)d_bits;
+    a.n_samples = n_samples;
+    a.is_signed = format == GPSACQ_IQ_S8;
+    a.mix = mix_hz != 0.0;
+    a.two_pi_fc = (2.0 * 3.141592653589793) * mix_hz;  // ((1i*2)*pi)*fc, left to right
+    a.inv_fs = 1.0 / fs;
+    if (remove_dc) {
+        if (!e->d_sums) HIPCHK(hipMalloc((void**)&e->d_sums, 2 * sizeof(unsigned long long)));
+        HIPCHK(hipMemsetAsync(e->d_sums, 0, 2 * sizeof(unsigned long long), e->stream));
+        launch_iq_sums(a.iq, n_samples, a.is_signed, e->d_sums, e->stream);
+        HIPCHK(hipGetLastError());
+        long long h[2];
+        HIPCHK(hipMemcpyAsync(h, e->d_sums, sizeof h, hipMemcpyDeviceToHost, e->stream));
+        HIPCHK(hipStreamSynchronize(e->stream));
+        a.mean_i = (double)h[0] / (double)n_samples;  // mean() of integer-valued doubles: exact sums
+        a.mean_q = (double)h[1] / (double)n_samples;
+    }
+    launch_iq_to_bits(a, e->stream);
+    HIPCHK(hipGetLastError());
+    if (sync) HIPCHK(hipStreamSynchronize(e->stream));
+    return GPSACQ_OK;
+}
+
+extern "C" int gpsacq_iq8_to_bits(gpsacq_engine* e, const void* iq, size_t n_samples, int format, int remove_dc, double mix_hz,
+                                  double fs, uint8_t* bits_out) {
+    if (!e || !iq || !bits_out || n_samples == 0) return fail(GPSACQ_ERR_ARG, "gpsacq_iq8_to_bits: bad argument");
+    HIPCHK(hipSetDevice(e->p.device));
+    const size_t n_bytes = (n_samples + 7) / 8;
+    if (int rc = grow(e->d_iq, e->iq_cap, 2 * n_samples + 16)) return rc;
+    if (int rc = grow(e->d_iqbits, e->iqbits_cap, n_bytes)) return rc;
+    HIPCHK(hipMemcpyAsync(e->d_iq, iq, 2 * n_samples, hipMemcpyHostToDevice, e->stream));
+    if (int rc = gpsacq_iq8_to_bits_device(e, e->d_iq, n_samples, format, remove_dc, mix_hz, fs, e->d_iqbits, 0)) return rc;
+    HIPCHK(hipMemcpyAsync(bits_out, e->d_iqbits, n_bytes, hipMemcpyDeviceToHost, e->stream));
+    HIPCHK(hipStreamSynchronize(e->stream));
     return GPSACQ_OK;
 }
 

@@ -1,0 +1,106 @@
+// iq_kernels.hip -- 8-bit IQ capture -> 1-bit real-IF stream, on the device.
+//
+// The reference does this offline in MATLAB before gps_test ever runs:
+//   proc_rtl_bin_for_gps.m:12-26,31-47   rtl-sdr  uint8 I,Q (offset 128): y = y-128; y = I + jQ;
+//                                        y = y - mean(y); [y = real(y .* exp(1i*2*pi*fc*n/fs))];
+//                                        y = (1-sign(y))/2; fwrite(..., 'ubit1')
+//   proc_hackrf_bin_for_gps.m:7-19       HackRF int8 I,Q: same without the offset
+// i.e. DC removal over the whole capture, optional mix to a real IF, sign, LSB-first packing --
+// exactly the byte stream Sample() (c/search_offline.cpp:136-146) unpacks.  HBM-bound byte
+// work: two streaming passes (integer sums for the mean; convert + pack), 16-byte loads, one
+// output byte per thread.
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "iq_launch.hpp"
+
+namespace acq {
+
+// pass 1: exact integer sums of I and Q (MATLAB's mean() of these integer-valued doubles is exact too)
+__global__ __launch_bounds__(256) void k_iq_sums(const uint8_t* __restrict__ iq, size_t n_samples, int is_signed,
+                                                 unsigned long long* sums /* [2] biased sums */) {
+    long long si = 0, sq = 0;
+    const size_t n16 = n_samples / 8;  // 16-byte groups of 8 samples
+    const uint4* p = reinterpret_cast<const uint4*>(iq);
+    for (size_t g = (size_t)blockIdx.x * blockDim.x + threadIdx.x; g < n16; g += (size_t)gridDim.x * blockDim.x) {
+        const uint4 v = p[g];
+        const unsigned w[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            if (is_signed) {
+                si += (int8_t)(w[k] & 0xff) + (int8_t)((w[k] >> 16) & 0xff);
+                sq += (int8_t)((w[k] >> 8) & 0xff) + (int8_t)((w[k] >> 24) & 0xff);
+            } else {
+                si += (int)(w[k] & 0xff) + (int)((w[k] >> 16) & 0xff) - 256;
+                sq += (int)((w[k] >> 8) & 0xff) + (int)((w[k] >> 24) & 0xff) - 256;
+            }
+        }
+    }
+    if (blockIdx.x == 0 && threadIdx.x == 0) {  // tail (< 8 samples)
+        for (size_t s = n16 * 8; s < n_samples; ++s) {
+            si += is_signed ? (int)(int8_t)iq[2 * s] : (int)iq[2 * s] - 128;
+            sq += is_signed ? (int)(int8_t)iq[2 * s + 1] : (int)iq[2 * s + 1] - 128;
+        }
+    }
+    // wave reduction, then one atomic pair per wave
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) {
+        si += __shfl_down(si, off, 64);
+        sq += __shfl_down(sq, off, 64);
+    }
+    if ((threadIdx.x & 63) == 0) {
+        atomicAdd(&sums[0], (unsigned long long)si);
+        atomicAdd(&sums[1], (unsigned long long)sq);
+    }
+}
+
+// pass 2: one output byte (8 samples) per thread
+__global__ __launch_bounds__(256) void k_iq_to_bits(IqArgs a) {
+    const size_t byte = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const size_t n_bytes = (a.n_samples + 7) / 8;
+    if (byte >= n_bytes) return;
+    const size_t s0 = byte * 8;
+    unsigned raw[4] = {0, 0, 0, 0};
+    if (s0 + 8 <= a.n_samples) {
+        const uint4 v = reinterpret_cast<const uint4*>(a.iq)[byte];
+        raw[0] = v.x; raw[1] = v.y; raw[2] = v.z; raw[3] = v.w;
+    } else {
+        for (size_t s = s0; s < a.n_samples; ++s) {
+            const unsigned pair = a.iq[2 * s] | ((unsigned)a.iq[2 * s + 1] << 8);
+            raw[(s - s0) >> 1] |= pair << (16 * ((s - s0) & 1));
+        }
+    }
+    unsigned out = 0;
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+        const size_t n = s0 + k;
+        const unsigned pair = (raw[k >> 1] >> (16 * (k & 1))) & 0xffffu;
+        double yi, yq;
+        if (a.is_signed) { yi = (double)(int8_t)(pair & 0xff); yq = (double)(int8_t)(pair >> 8); }
+        else { yi = (double)(int)(pair & 0xff) - 128.0; yq = (double)(int)(pair >> 8) - 128.0; }
+        yi -= a.mean_i;
+        yq -= a.mean_q;
+        double r = yi;
+        if (a.mix) {
+            // theta in the operation order of proc_rtl_bin_for_gps.m:41: ((((2*pi)*fc)*n)*(1/fs))
+            const double th = (a.two_pi_fc * (double)n) * a.inv_fs;
+            double sn, cs;
+            sincos(th, &sn, &cs);
+            r = yi * cs - yq * sn;
+        }
+        // (1 - sign(r)) / 2 written as ubit1: r > 0 -> 0, r < 0 -> 1, r == 0 -> 0.5 which fwrite rounds to 1
+        const unsigned bit = (n < a.n_samples) ? (r > 0.0 ? 0u : 1u) : 0u;
+        out |= bit << k;
+    }
+    a.bits[byte] = (uint8_t)out;
+}
+
+void launch_iq_sums(const uint8_t* iq, size_t n_samples, int is_signed, unsigned long long* sums, hipStream_t s) {
+    hipLaunchKernelGGL(k_iq_sums, dim3(2048), dim3(256), 0, s, iq, n_samples, is_signed, sums);
+}
+void launch_iq_to_bits(const IqArgs& a, hipStream_t s) {
+    const size_t n_bytes = (a.n_samples + 7) / 8;
+    hipLaunchKernelGGL(k_iq_to_bits, dim3((unsigned)((n_bytes + 255) / 256)), dim3(256), 0, s, a);
+}
+
+}  // namespace acq

@@ -48,7 +48,7 @@ class Handoff(ctypes.Structure):
                 ("ca_rate", ctypes.c_uint32), ("ca_shift", ctypes.c_int32), ("ca_pause", ctypes.c_uint32)]
 
 
-EXPORTS = ["gpsacq_handoff", "gpsacq_create", "gpsacq_destroy", "gpsacq_last_error", "gpsacq_get_info", "gpsacq_search",
+EXPORTS = ["gpsacq_handoff", "gpsacq_iq8_to_bits", "gpsacq_iq8_to_bits_device", "gpsacq_create", "gpsacq_destroy", "gpsacq_last_error", "gpsacq_get_info", "gpsacq_search",
            "gpsacq_search_device", "gpsacq_set_doppler_window", "gpsacq_synchronize", "gpsacq_last_timing", "gpsacq_search_code",
            "gpsacq_sample_spectrum", "gpsacq_code_spectrum"]
 
@@ -84,6 +84,10 @@ def load_library(path=None):
     lib.gpsacq_synchronize.restype = ctypes.c_int
     lib.gpsacq_last_timing.argtypes = [vp, ctypes.POINTER(Timing)]
     lib.gpsacq_last_timing.restype = ctypes.c_int
+    lib.gpsacq_iq8_to_bits.argtypes = [vp, vp, sz, ctypes.c_int, ctypes.c_int, ctypes.c_double, ctypes.c_double, vp]
+    lib.gpsacq_iq8_to_bits.restype = ctypes.c_int
+    lib.gpsacq_iq8_to_bits_device.argtypes = [vp, vp, sz, ctypes.c_int, ctypes.c_int, ctypes.c_double, ctypes.c_double, vp, ctypes.c_int]
+    lib.gpsacq_iq8_to_bits_device.restype = ctypes.c_int
     lib.gpsacq_handoff.argtypes = [vp, ctypes.c_double, ctypes.c_double, ctypes.c_double, ctypes.POINTER(Handoff)]
     lib.gpsacq_handoff.restype = ctypes.c_int
     lib.gpsacq_search_code.argtypes = [ctypes.c_int, ctypes.c_int]
@@ -203,6 +207,18 @@ class Engine:
         t = Timing()
         _check(self._lib, self._lib.gpsacq_last_timing(self._h, ctypes.byref(t)))
         return {k: getattr(t, k) for k, _ in Timing._fields_}
+
+    # ---- 8-bit IQ ingestion --------------------------------------------------------------
+    def iq8_to_bits(self, iq, signed=False, remove_dc=True, mix_hz=0.0, fs=0.0):
+        """proc_rtl_bin_for_gps.m / proc_hackrf_bin_for_gps.m on the device: interleaved 8-bit I,Q
+        (uint8 offset-128 rtl-sdr, or int8 HackRF with signed=True) -> packed 1-bit real-IF bytes."""
+        buf = np.ascontiguousarray(np.asarray(iq).view(np.uint8).ravel())
+        n = buf.size // 2
+        out = np.zeros((n + 7) // 8, dtype=np.uint8)
+        _check(self._lib, self._lib.gpsacq_iq8_to_bits(self._h, buf.ctypes.data_as(ctypes.c_void_p), n, 1 if signed else 0,
+                                                       1 if remove_dc else 0, float(mix_hz), float(fs),
+                                                       out.ctypes.data_as(ctypes.c_void_p)))
+        return out
 
     # ---- parity probes -------------------------------------------------------------------
     def sample_spectrum(self, block):

@@ -16,6 +16,8 @@
  *                            SearchTask() loop, :239-246)
  *   gpsacq_search_device     same, capture already resident in HBM
  *   gpsacq_search_code       SearchCode()            c/search_offline.cpp:205-209
+ *   gpsacq_iq8_to_bits       the MATLAB pre-processing that produces gps_test's input from an 8-bit IQ
+ *                            capture: proc_rtl_bin_for_gps.m:12-26,31-47, proc_hackrf_bin_for_gps.m:7-19
  *   gpsacq_handoff           CHANNEL::Start()'s NCO set-up from a search hit, c/channel.cpp:134-163
  *                            (the first consumer of the search result in the online receiver)
  *   gpsacq_sample_spectrum   Sample()'s fwd_buf      c/search_offline.cpp:161 (parity probe)
@@ -137,6 +139,22 @@ int gpsacq_search_device(gpsacq_engine* e, const void* d_bits, size_t n_blocks, 
 int gpsacq_set_doppler_window(gpsacq_engine* e, int first_bin, int n_bins);
 int gpsacq_synchronize(gpsacq_engine* e);
 int gpsacq_last_timing(const gpsacq_engine* e, gpsacq_timing* t);
+
+/*
+ * 8-bit IQ capture -> the 1-bit real-IF stream gpsacq_search() takes.  format GPSACQ_IQ_U8: rtl-sdr
+ * (unsigned, offset 128, interleaved I,Q; proc_rtl_bin_for_gps.m:12-16), GPSACQ_IQ_S8: HackRF (signed;
+ * proc_hackrf_bin_for_gps.m:7-11).  remove_dc: subtract the complex mean of the whole capture
+ * (`y = y - mean(y)`).  mix_hz != 0: take real(y * exp(2 pi i mix_hz n / fs)) (proc_rtl...m:41),
+ * else the real part.  fs <= 0: the engine's fs.  Output: ceil(n/8) bytes, sample n in bit n%8 of
+ * byte n/8 (MATLAB 'ubit1'), bit = 1 where the value is <= 0.  The _device form takes device
+ * pointers (IQ 16-byte aligned) and runs on the engine's stream.
+ */
+#define GPSACQ_IQ_U8 0
+#define GPSACQ_IQ_S8 1
+int gpsacq_iq8_to_bits(gpsacq_engine* e, const void* iq, size_t n_samples, int format, int remove_dc,
+                       double mix_hz, double fs, uint8_t* bits_out);
+int gpsacq_iq8_to_bits_device(gpsacq_engine* e, const void* d_iq, size_t n_samples, int format, int remove_dc,
+                              double mix_hz, double fs, void* d_bits_out, int sync);
 
 /*
  * Acquisition hand-off record: what the tracking channel derives from a search hit

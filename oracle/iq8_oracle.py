@@ -1,0 +1,30 @@
+"""iq8_oracle.py -- CPU restatement (numpy, float64) of the reference's MATLAB pre-processing
+that turns an 8-bit IQ capture into gps_test's 1-bit input.  TEST INFRASTRUCTURE ONLY.
+
+Restates, operation by operation:
+  proc_rtl_bin_for_gps.m:12-26   uint8 -> y-128 -> I + 1i*Q -> y - mean(y) -> real(y) -> (1-sign)/2 -> ubit1
+  proc_rtl_bin_for_gps.m:31-47   same, with y = real(y.' .* exp(1i.*2.*pi.*fc.*(0:n-1).*(1./fs)))
+  proc_hackrf_bin_for_gps.m:7-19 int8 input, no offset
+MATLAB evaluates `1i.*2.*pi.*fc.*n.*(1./fs)` left to right in double: theta = (((2*pi)*fc)*n)*(1/fs).
+fwrite(..., 'ubit1') rounds the value 0.5 that (1-sign(0))/2 produces to 1 and packs LSB first
+(the bit order Sample() unpacks, c/search_offline.cpp:143-146).
+PIN STATUS: unpinned -- neither MATLAB nor Octave exists in this image and the reference ships no
+converted file; this is a restatement of the script text only.
+"""
+import numpy as np
+
+
+def iq8_to_bits(raw, signed=False, remove_dc=True, mix_hz=0.0, fs=2.8e6):
+    raw = np.asarray(raw).view(np.uint8).ravel()
+    y = raw.view(np.int8).astype(np.float64) if signed else raw.astype(np.float64) - 128.0
+    y = y[0::2] + 1j * y[1::2]
+    if remove_dc:
+        y = y - np.mean(y)
+    if mix_hz != 0.0:
+        n = np.arange(y.size, dtype=np.float64)
+        theta = (((2.0 * np.pi) * mix_hz) * n) * (1.0 / fs)
+        r = y.real * np.cos(theta) - y.imag * np.sin(theta)
+    else:
+        r = y.real
+    bits = np.where(r > 0, 0, 1).astype(np.uint8)
+    return np.packbits(bits, bitorder="little")

@@ -17,6 +17,9 @@ Fixtures:
                              (SURVEY.md section 8d "stand-in set").
   synth_rtl_fs2800.bin       seeded synthetic capture, fs 2.8 MHz, IF 0.62 MHz (inexact float32
                              NCO rates, D=143), 33 blocks.
+  synth_iq8_rtl.bin          seeded synthetic rtl-sdr style capture: uint8 offset-128 interleaved I,Q at
+                             baseband, fs 2.8 MHz, 2 blocks, PRN 5 at +1023 Hz, DC offset added.
+  synth_iq8_rtl_bits.bin     its 1-bit conversion by oracle/iq8_oracle.py (mix 0.62 MHz, DC removed).
   np64_cells_*.npz           per-cell {max_pwr, max_i, tot_pwr} from an INDEPENDENT float64
                              numpy restatement (np.fft / pocketfft) of
                              c/search_offline.cpp:121-201 for a few (block, sv) pairs.
@@ -174,6 +177,24 @@ def main():
     open(os.path.join(HERE, "synth_nott_fs5456.bin"), "wb").write(nott)
     rtl = synth_capture(2.8e6, 0.62e6, 33, [(8, 20, 700), (12, -33, 2100), (1, 3, 5)], 7)
     open(os.path.join(HERE, "synth_rtl_fs2800.bin"), "wb").write(rtl)
+
+    # ---- 8-bit IQ capture ----
+    import sys
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(HERE)), "oracle"))
+    from iq8_oracle import iq8_to_bits
+    rng = np.random.default_rng(99)
+    ns = 2 * 40960
+    m = np.arange(ns, dtype=np.float64)
+    fd = 1023.0
+    chips = 1.0 - 2.0 * ca_chips(*TAPS[4])
+    idx = np.floor((m + 321) * CPS * (1 + fd / L1) / 2.8e6).astype(np.int64) % 1023
+    z = (rng.standard_normal(ns) + 1j * rng.standard_normal(ns)) / np.sqrt(2) + 0.3 * chips[idx] * np.exp(2j * np.pi * (fd / 2.8e6 * m + 0.123))
+    z = 30.0 * z + (3.7 + 1.2j)
+    iq = np.empty(2 * ns, dtype=np.uint8)
+    iq[0::2] = np.clip(np.rint(z.real) + 128, 0, 255).astype(np.uint8)
+    iq[1::2] = np.clip(np.rint(z.imag) + 128, 0, 255).astype(np.uint8)
+    iq.tofile(os.path.join(HERE, "synth_iq8_rtl.bin"))
+    iq8_to_bits(iq, signed=False, remove_dc=True, mix_hz=0.62e6, fs=2.8e6).tofile(os.path.join(HERE, "synth_iq8_rtl_bits.bin"))
 
     def blocks_of(buf):
         return [buf[i * 5120:(i + 1) * 5120] for i in range(len(buf) // 5120)]
