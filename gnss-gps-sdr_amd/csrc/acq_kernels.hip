@@ -104,7 +104,9 @@ __global__ __launch_bounds__(WG) void k_quirk_patch(QuirkArgs a) {
 // ---------------------------------------------------------------------------------------
 // One workgroup per (task, Doppler bin).  blockIdx -> cell map keeps the 2*dmax+1 cells of a
 // task on one XCD (block b runs on XCD b % 8) so both spectra are read from that XCD's L2.
-template <int MC, int WPS, int NB>
+// NC = true: non-coherent mode (no reference equivalent): the powers |y[n]|^2
+// of a.n_acc consecutive block spectra (a.acc_step apart) are summed per lag before the peak scan.
+template <int MC, int WPS, int NB, bool NC>
 __global__ __launch_bounds__(WG, WPS) void k_corr(CorrArgs a) {
     __shared__ cf lds[M_SUB];  // transform buffer
     __shared__ cf t2s[NT2];    // the 500 pass-2 twiddles
@@ -127,23 +129,40 @@ __global__ __launch_bounds__(WG, WPS) void k_corr(CorrArgs a) {
 #pragma unroll
     for (int m = 0; m < MC; ++m) acc[m] = mk(0.f, 0.f);
 
-    const int t3 = tid < NBF3 ? tid : 0;
-    for (int q = 0; q < NPOLY; ++q) {
-        const cf b = a.bq[q * NBF3 + t3];  // per-thread rotation of this sub-transform
-        cf wqv[MC];                        // wave-uniform rotations: scalar loads, SGPR operands
+    float pw[NC ? MC : 1];
+    if (NC) {
 #pragma unroll
-        for (int m = 0; m < MC; ++m) wqv[m] = c_wq[q * WQ_STRIDE + m];
-        corr_phase1<NB>(tid, q, dop, dpp, cpp, a.crow, a.halo, w1, lds);
-        __syncthreads();  // also orders the t2s fill before its first use
-        corr_phase2(tid, t2s, lds);
-        __syncthreads();
-        corr_phase3<MC>(tid, b, wqv, lds, acc);
-        __syncthreads();
+        for (int m = 0; m < MC; ++m) pw[m] = 0.f;
+    }
+    const int t3 = tid < NBF3 ? tid : 0;
+    const int n_acc = NC ? a.n_acc : 1;
+    for (int k = 0; k < n_acc; ++k) {
+        const cf* dk = dpp + (size_t)k * a.acc_step * NPOLY * M_SUB;
+        for (int q = 0; q < NPOLY; ++q) {
+            const cf b = a.bq[q * NBF3 + t3];  // per-thread rotation of this sub-transform
+            cf wqv[MC];                        // wave-uniform rotations: scalar loads, SGPR operands
+#pragma unroll
+            for (int m = 0; m < MC; ++m) wqv[m] = c_wq[q * WQ_STRIDE + m];
+            corr_phase1<NB>(tid, q, dop, dk, cpp, a.crow, a.halo, w1, lds);
+            __syncthreads();  // also orders the t2s fill before its first use
+            corr_phase2(tid, t2s, lds);
+            __syncthreads();
+            corr_phase3<MC>(tid, b, wqv, lds, acc);
+            __syncthreads();
+        }
+        if (NC) {
+#pragma unroll
+            for (int m = 0; m < MC; ++m) {
+                pw[m] += acc[m].x * acc[m].x + acc[m].y * acc[m].y;
+                acc[m] = mk(0.f, 0.f);
+            }
+        }
     }
 
     float mx, sum;
     int mi;
-    corr_scan<MC>(tid, a.nlags, acc, mx, mi, sum);
+    if (NC) corr_scan_power<MC>(tid, a.nlags, pw, mx, mi, sum);
+    else corr_scan<MC>(tid, a.nlags, acc, mx, mi, sum);
     // wave reduction (64 lanes), then across the 4 waves through LDS
 #pragma unroll
     for (int off = 32; off > 0; off >>= 1) {
@@ -229,10 +248,22 @@ int launch_corr(const CorrArgs& a, int mc, hipStream_t s) {
     // <columns, waves per SIMD the allocator is held to, load batches>.  LDS (44 KB per workgroup)
     // admits 3 workgroups per CU; the two small instances fit 168 VGPRs without spilling.
     switch (mc) {
-        case 12: hipLaunchKernelGGL((k_corr<12, 3, 2>), grid, block, 0, s, a); break;
-        case 22: hipLaunchKernelGGL((k_corr<22, 3, 2>), grid, block, 0, s, a); break;
-        case 33: hipLaunchKernelGGL((k_corr<33, 2, 2>), grid, block, 0, s, a); break;
-        case 40: hipLaunchKernelGGL((k_corr<40, 2, 2>), grid, block, 0, s, a); break;
+        case 12:
+            if (a.n_acc > 1) hipLaunchKernelGGL((k_corr<12, 2, 2, true>), grid, block, 0, s, a);
+            else hipLaunchKernelGGL((k_corr<12, 3, 2, false>), grid, block, 0, s, a);
+            break;
+        case 22:
+            if (a.n_acc > 1) hipLaunchKernelGGL((k_corr<22, 2, 2, true>), grid, block, 0, s, a);
+            else hipLaunchKernelGGL((k_corr<22, 3, 2, false>), grid, block, 0, s, a);
+            break;
+        case 33:
+            if (a.n_acc > 1) hipLaunchKernelGGL((k_corr<33, 2, 2, true>), grid, block, 0, s, a);
+            else hipLaunchKernelGGL((k_corr<33, 2, 2, false>), grid, block, 0, s, a);
+            break;
+        case 40:
+            if (a.n_acc > 1) hipLaunchKernelGGL((k_corr<40, 2, 2, true>), grid, block, 0, s, a);
+            else hipLaunchKernelGGL((k_corr<40, 2, 2, false>), grid, block, 0, s, a);
+            break;
         default: return -1;
     }
     return 0;

@@ -46,6 +46,7 @@ struct CorrArgs {
     const cf* wq;
     Cell* cells;       // [n_tasks][ndop]
     int n_tasks, ndop, dop_first, nlags, crow, halo;  // bins dop_first .. dop_first+ndop-1
+    int n_acc, acc_step;  // non-coherent mode: spectra tk.spec + k*acc_step, k < n_acc (n_acc = 1: coherent)
 };
 
 void launch_fwd_sub_bits(const FwdArgs& a, int n_items, hipStream_t s);

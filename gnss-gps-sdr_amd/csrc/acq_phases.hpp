@@ -125,6 +125,24 @@ ACQ_HD void corr_scan(int tid, int S, const cf* acc, float& mx, int& mi, float& 
         sum += p;
     }
 }
+// same scan over summed powers (non-coherent mode)
+template <int MC>
+ACQ_HD void corr_scan_power(int tid, int S, const float* pw, float& mx, int& mi, float& sum) {
+    mx = 0.f;
+    mi = 0;
+    sum = 0.f;
+    if (tid >= NBF3) return;
+    const int rho = pass3_rho(tid);
+#pragma unroll
+    for (int m = 0; m < MC; ++m) {
+        const int n = NBF3 * m + rho;
+        const float p = (n < S) ? pw[m] : 0.f;
+        const bool up = p > mx;
+        mx = up ? p : mx;
+        mi = up ? n : mi;
+        sum += p;
+    }
+}
 // strict '>' first-wins of the reference == larger power, ties to the lower lag
 ACQ_HD void peak_merge(float& mx, int& mi, float omx, int omi) {
     if (omx > mx || (omx == mx && omi < mi)) { mx = omx; mi = omi; }

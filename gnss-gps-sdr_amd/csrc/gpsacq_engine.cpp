@@ -42,6 +42,7 @@ static int fail(int code, const char* fmt, ...) {
 struct gpsacq_engine {
     gpsacq_params p{};
     int dmax = 0, ndop = 0, dop_first = 0, nlags = 0, mc = 0, halo = 0, crow = 0;  // searched bins: dop_first .. +ndop-1
+    int n_acc = 1, acc_step = 0;  // non-coherent accumulation (gpsacq_set_noncoherent)
     int cus = 0;
     char name[64] = {0};
     hipStream_t stream = nullptr;
@@ -272,7 +273,7 @@ static int prepare_tasks(gpsacq_engine* e, const gpsacq_task* h_tasks, const voi
                          size_t n_tasks, const uint8_t* d_bits, size_t stride) {
     const bool quirks = e->p.ref_quirks != 0;
     if (!h_tasks && !d_user_tasks) {
-        if (e->sched_valid && e->sched_tasks == n_tasks && !quirks) return GPSACQ_OK;  // cached
+        if (e->sched_valid && e->sched_tasks == n_tasks && !quirks && e->n_acc == 1) return GPSACQ_OK;  // cached
     }
     if (int rc = grow(e->d_tasks, e->task_cap, n_tasks)) return rc;
     e->sched_valid = false;
@@ -292,8 +293,10 @@ static int prepare_tasks(gpsacq_engine* e, const gpsacq_task* h_tasks, const voi
     for (size_t t = 0; t < n_tasks; ++t) {
         int32_t blk = h_tasks ? h_tasks[t].block : (int32_t)t;
         int32_t prn = h_tasks ? h_tasks[t].prn : (int32_t)(t % GPSACQ_NUM_SATS);
-        if (blk < 0 || (size_t)blk >= n_blocks || prn < 0 || prn >= GPSACQ_NUM_SATS)
-            return fail(GPSACQ_ERR_ARG, "task %zu = (block %d, prn %d) out of range", t, blk, prn);
+        const size_t span = (size_t)(e->n_acc - 1) * (size_t)e->acc_step;  // last spectrum a non-coherent task touches
+        if (blk < 0 || (size_t)blk + span >= n_blocks || prn < 0 || prn >= GPSACQ_NUM_SATS)
+            return fail(GPSACQ_ERR_ARG, "task %zu = (block %d, prn %d) out of range (%zu blocks, %d accumulations %d apart)", t, blk, prn,
+                        n_blocks, e->n_acc, e->acc_step);
         tk[t].spec = blk;
         tk[t].code = prn;
         if (quirks && prn == 0) {
@@ -318,7 +321,7 @@ static int prepare_tasks(gpsacq_engine* e, const gpsacq_task* h_tasks, const voi
     }
     HIPCHK(hipMemcpyAsync(e->d_tasks, tk.data(), n_tasks * sizeof(Task), hipMemcpyHostToDevice, e->stream));
     HIPCHK(hipStreamSynchronize(e->stream));  // tk / patch_blocks go out of scope
-    if (!h_tasks && !quirks) {
+    if (!h_tasks && !quirks && e->n_acc == 1) {
         e->sched_valid = true;
         e->sched_tasks = n_tasks;
     }
@@ -357,6 +360,8 @@ static int search_core(gpsacq_engine* e, const uint8_t* d_bits, size_t n_blocks,
     ca.nlags = e->nlags;
     ca.crow = e->crow;
     ca.halo = e->halo;
+    ca.n_acc = e->n_acc;
+    ca.acc_step = e->acc_step;
     if (launch_corr(ca, e->mc, e->stream) != 0) return fail(GPSACQ_ERR_UNSUPPORTED, "no correlate kernel for %d columns", e->mc);
     HIPCHK(hipGetLastError());
     HIPCHK(hipEventRecord(e->ev[2], e->stream));
@@ -372,7 +377,7 @@ static int search_core(gpsacq_engine* e, const uint8_t* d_bits, size_t n_blocks,
 extern "C" int gpsacq_search_device(gpsacq_engine* e, const void* d_bits, size_t n_blocks, size_t stride, const void* d_tasks,
                                     size_t n_tasks, void* d_cells, void* d_peaks, int sync) {
     if (!e || !d_bits || !d_peaks) return fail(GPSACQ_ERR_ARG, "gpsacq_search_device: null argument");
-    if (!d_tasks && n_tasks != n_blocks) return fail(GPSACQ_ERR_ARG, "tasks == NULL needs n_tasks == n_blocks");
+    if (!d_tasks && n_tasks != n_blocks && e->n_acc == 1) return fail(GPSACQ_ERR_ARG, "tasks == NULL needs n_tasks == n_blocks");
     HIPCHK(hipSetDevice(e->p.device));
     if (int rc = search_core(e, (const uint8_t*)d_bits, n_blocks, stride, nullptr, d_tasks, n_tasks, (Cell*)d_cells, (Peak*)d_peaks)) return rc;
     if (sync) HIPCHK(hipStreamSynchronize(e->stream));
@@ -382,7 +387,7 @@ extern "C" int gpsacq_search_device(gpsacq_engine* e, const void* d_bits, size_t
 extern "C" int gpsacq_search(gpsacq_engine* e, const uint8_t* bits, size_t n_blocks, size_t stride, const gpsacq_task* tasks,
                              size_t n_tasks, gpsacq_cell* cells, gpsacq_peak* peaks) {
     if (!e || !bits) return fail(GPSACQ_ERR_ARG, "gpsacq_search: null argument");
-    if (!tasks && n_tasks != n_blocks) return fail(GPSACQ_ERR_ARG, "tasks == NULL needs n_tasks == n_blocks");
+    if (!tasks && n_tasks != n_blocks && e->n_acc == 1) return fail(GPSACQ_ERR_ARG, "tasks == NULL needs n_tasks == n_blocks");
     if (n_blocks == 0 || n_tasks == 0) return fail(GPSACQ_ERR_ARG, "empty batch");
     HIPCHK(hipSetDevice(e->p.device));
     const size_t nbytes = (n_blocks - 1) * stride + (stride < (size_t)BLOCK_BYTES ? stride : (size_t)BLOCK_BYTES);
@@ -395,6 +400,23 @@ extern "C" int gpsacq_search(gpsacq_engine* e, const uint8_t* bits, size_t n_blo
     if (peaks) HIPCHK(hipMemcpyAsync(peaks, e->d_peaks, n_tasks * sizeof(Peak), hipMemcpyDeviceToHost, e->stream));
     HIPCHK(hipStreamSynchronize(e->stream));
     return GPSACQ_OK;
+}
+
+extern "C" int gpsacq_set_noncoherent(gpsacq_engine* e, int n_acc, int block_step) {
+    if (!e) return fail(GPSACQ_ERR_ARG, "gpsacq_set_noncoherent: null engine");
+    if (n_acc < 1 || n_acc > 1024 || (n_acc > 1 && block_step < 1)) return fail(GPSACQ_ERR_ARG, "need 1 <= n_acc <= 1024 and block_step >= 1");
+    if (n_acc > 1 && e->p.ref_quirks) return fail(GPSACQ_ERR_UNSUPPORTED, "ref_quirks is defined for the reference's coherent search only");
+    e->n_acc = n_acc;
+    e->acc_step = n_acc > 1 ? block_step : 0;
+    e->sched_valid = false;
+    return GPSACQ_OK;
+}
+
+extern "C" int gpsacq_aligned_stride(const gpsacq_engine* e) {
+    if (!e) return -1;
+    if (e->nlags % 8 != 0) return -1;  // a code period is not a whole number of bytes
+    const int per = e->nlags / 8;      // bytes per code period (FS/1000 samples)
+    return per * ((BLOCK_BYTES + per - 1) / per);
 }
 
 extern "C" int gpsacq_set_doppler_window(gpsacq_engine* e, int first_bin, int n_bins) {

@@ -49,7 +49,7 @@ class Handoff(ctypes.Structure):
 
 
 EXPORTS = ["gpsacq_handoff", "gpsacq_iq8_to_bits", "gpsacq_iq8_to_bits_device", "gpsacq_create", "gpsacq_destroy", "gpsacq_last_error", "gpsacq_get_info", "gpsacq_search",
-           "gpsacq_search_device", "gpsacq_set_doppler_window", "gpsacq_synchronize", "gpsacq_last_timing", "gpsacq_search_code",
+           "gpsacq_search_device", "gpsacq_set_doppler_window", "gpsacq_set_noncoherent", "gpsacq_aligned_stride", "gpsacq_synchronize", "gpsacq_last_timing", "gpsacq_search_code",
            "gpsacq_sample_spectrum", "gpsacq_code_spectrum"]
 
 _lib = None
@@ -80,6 +80,10 @@ def load_library(path=None):
     lib.gpsacq_search_device.restype = ctypes.c_int
     lib.gpsacq_set_doppler_window.argtypes = [vp, ctypes.c_int, ctypes.c_int]
     lib.gpsacq_set_doppler_window.restype = ctypes.c_int
+    lib.gpsacq_set_noncoherent.argtypes = [vp, ctypes.c_int, ctypes.c_int]
+    lib.gpsacq_set_noncoherent.restype = ctypes.c_int
+    lib.gpsacq_aligned_stride.argtypes = [vp]
+    lib.gpsacq_aligned_stride.restype = ctypes.c_int
     lib.gpsacq_synchronize.argtypes = [vp]
     lib.gpsacq_synchronize.restype = ctypes.c_int
     lib.gpsacq_last_timing.argtypes = [vp, ctypes.POINTER(Timing)]
@@ -155,6 +159,14 @@ class Engine:
         _check(self._lib, self._lib.gpsacq_set_doppler_window(self._h, int(first_bin), int(n_bins)))
         self._refresh_info()
 
+    def set_noncoherent(self, n_acc, block_step=1):
+        """Sum |IFFT|^2 over n_acc blocks (block_step apart) per cell before the peak scan; 1 = reference."""
+        _check(self._lib, self._lib.gpsacq_set_noncoherent(self._h, int(n_acc), int(block_step)))
+
+    def aligned_stride(self):
+        """Bytes between block starts that keep lags aligned for non-coherent sums (whole C/A periods)."""
+        return self._lib.gpsacq_aligned_stride(self._h)
+
     def close(self):
         if self._h:
             self._lib.gpsacq_destroy(self._h)
@@ -173,7 +185,7 @@ class Engine:
             pass
 
     # ---- host-buffer path ----------------------------------------------------------------
-    def search(self, bits, tasks=None, stride=BLOCK_BYTES, want_cells=True):
+    def search(self, bits, tasks=None, stride=BLOCK_BYTES, want_cells=True, n_tasks=None):
         """bits: bytes-like / uint8 array holding whole 5120-byte blocks.  tasks: None for the
         reference schedule (block t against PRN t % 32) or an array of (block, prn) pairs.
         Returns (cells[n_tasks, num_doppler] or None, peaks[n_tasks])."""
@@ -182,7 +194,7 @@ class Engine:
         if n_blocks <= 0:
             raise ValueError("capture shorter than one block")
         if tasks is None:
-            n_tasks, tptr = n_blocks, None
+            n_tasks, tptr = (n_blocks if n_tasks is None else int(n_tasks)), None
         else:
             t = np.ascontiguousarray(np.asarray(tasks, dtype=np.int32).reshape(-1, 2))
             n_tasks, tptr = t.shape[0], t.ctypes.data_as(ctypes.c_void_p)

@@ -137,6 +137,18 @@ int gpsacq_search_device(gpsacq_engine* e, const void* d_bits, size_t n_blocks, 
  * lo_shift stays an absolute bin number.
  */
 int gpsacq_set_doppler_window(gpsacq_engine* e, int first_bin, int n_bins);
+/*
+ * Non-coherent accumulation (extension; the reference scans one coherent block per cell,
+ * c/search_offline.cpp:176-199): every task then sums |IFFT|^2 per lag over n_acc block spectra
+ * task.block + k*block_step (k < n_acc) before the peak scan; cells/peaks describe the summed power.
+ * Lags only line up if consecutive accumulated blocks start a whole number of C/A periods apart:
+ * lay the capture out with stride = gpsacq_aligned_stride(e) bytes (smallest multiple of
+ * FS/8000 bytes >= 5120; -1 if FS/1000 is not a multiple of 8).  n_acc = 1 restores the
+ * reference behaviour.  With tasks == NULL the schedule is task t = (block t, prn t % 32) for
+ * t < n_tasks <= n_blocks - (n_acc-1)*block_step.
+ */
+int gpsacq_set_noncoherent(gpsacq_engine* e, int n_acc, int block_step);
+int gpsacq_aligned_stride(const gpsacq_engine* e);
 int gpsacq_synchronize(gpsacq_engine* e);
 int gpsacq_last_timing(const gpsacq_engine* e, gpsacq_timing* t);
 

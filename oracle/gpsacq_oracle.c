@@ -351,6 +351,22 @@ float oracle_correlate(oracle_t *o, int sv, int *max_snr_dop, int *max_snr_i, or
     return max_snr;
 }
 
+/* |IFFT|^2 over the scanned lags for one Doppler bin of the block last given to oracle_sample()
+ * (the inner part of Correlate, :181-191).  Used to restate the non-coherent extension:
+ * the caller sums these arrays over blocks and scans the sum like :190-196. */
+void oracle_cell_power(oracle_t *o, int sv, int dop, float *pwr /* nlags */) {
+    const cf32 *data = o->fwd;
+    const cf32 *code = o->code + (size_t)sv * FFT_LEN;
+    cf32 *prod = o->rev;
+    for (int i = 0; i < FFT_LEN; i++) {
+        int j = ((i - dop) % FFT_LEN + FFT_LEN) % FFT_LEN;
+        prod[i].re = data[i].re * code[j].re + data[i].im * code[j].im;
+        prod[i].im = data[i].re * code[j].im - data[i].im * code[j].re;
+    }
+    fft_exec_cf32(o->plan, prod, -1);
+    for (int i = 0; i < o->nlags; i++) pwr[i] = prod[i].re * prod[i].re + prod[i].im * prod[i].im;
+}
+
 /* One (block, sv) search = Sample + Correlate */
 void oracle_search_block(oracle_t *o, const unsigned char *bytes, int sv, oracle_cell *cells, oracle_peak *peak) {
     int lo = 0, ca = 0;

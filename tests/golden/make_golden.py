@@ -20,6 +20,8 @@ Fixtures:
   synth_iq8_rtl.bin          seeded synthetic rtl-sdr style capture: uint8 offset-128 interleaved I,Q at
                              baseband, fs 2.8 MHz, 2 blocks, PRN 5 at +1023 Hz, DC offset added.
   synth_iq8_rtl_bits.bin     its 1-bit conversion by oracle/iq8_oracle.py (mix 0.62 MHz, DC removed).
+  synth_weak_fs5456.bin      seeded weak-signal capture for the non-coherent extension: fs 5.456 MHz,
+                             7 blocks laid out every 5456 bytes (8 whole C/A periods), PRN 12 weak, PRN 3 stronger.
   np64_cells_*.npz           per-cell {max_pwr, max_i, tot_pwr} from an INDEPENDENT float64
                              numpy restatement (np.fft / pocketfft) of
                              c/search_offline.cpp:121-201 for a few (block, sv) pairs.
@@ -195,6 +197,19 @@ def main():
     iq[1::2] = np.clip(np.rint(z.imag) + 128, 0, 255).astype(np.uint8)
     iq.tofile(os.path.join(HERE, "synth_iq8_rtl.bin"))
     iq8_to_bits(iq, signed=False, remove_dc=True, mix_hz=0.62e6, fs=2.8e6).tofile(os.path.join(HERE, "synth_iq8_rtl_bits.bin"))
+
+    # ---- weak-signal capture, block starts a whole number of code periods apart ----
+    rng = np.random.default_rng(4242)
+    ns = 7 * 5456 * 8
+    m = np.arange(ns, dtype=np.float64)
+    y = rng.standard_normal(ns)
+    for prn, lo, ca, amp in [(12, 4, 1000, 0.055), (3, -11, 3333, 0.11)]:
+        fd = lo * 5.456e6 / N
+        chips = 1.0 - 2.0 * ca_chips(*TAPS[prn - 1])
+        idx = np.floor((m + ca) * CPS * (1 + fd / L1) / 5.456e6).astype(np.int64) % 1023
+        nav = np.where((np.floor(m / (20 * 5456)).astype(np.int64) % 2) == 0, 1.0, -1.0)  # a data-bit flip every 20 ms
+        y += amp * nav * chips[idx] * np.cos(2 * np.pi * ((4.092e6 + fd) / 5.456e6 * m + rng.random()))
+    np.packbits((y < 0).astype(np.uint8), bitorder='little').tofile(os.path.join(HERE, "synth_weak_fs5456.bin"))
 
     def blocks_of(buf):
         return [buf[i * 5120:(i + 1) * 5120] for i in range(len(buf) // 5120)]

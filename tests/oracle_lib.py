@@ -28,6 +28,7 @@ def lib(kind="f64"):
     L.oracle_sample.argtypes = [vp, vp]
     L.oracle_get_sample_spectrum.argtypes = [vp, vp]
     L.oracle_search_block.argtypes = [vp, vp, i, vp, vp]
+    L.oracle_cell_power.argtypes = [vp, i, i, vp]
     L.oracle_search_file.argtypes = [vp, ctypes.c_char_p, i, ctypes.c_char_p, ctypes.c_size_t, vp, ctypes.c_size_t]
     L.oracle_bench_blocks.argtypes = [vp, vp, ctypes.c_long, ctypes.c_long, vp]
     L.oracle_bench_blocks.restype = ctypes.c_long
@@ -94,6 +95,29 @@ class Oracle:
             cells[t] = c
             peaks[t] = p
         return cells, peaks
+
+    def search_noncoherent(self, bits, stride, first_block, sv, n_acc, block_step):
+        """Restatement of the non-coherent extension: per Doppler bin, sum |IFFT|^2 per lag over
+        n_acc blocks, then the reference's scan (:190-196) over the sum."""
+        buf = np.frombuffer(bits, dtype=np.uint8)
+        S = self.num_lags
+        power = np.zeros((self.num_doppler, S), np.float32)
+        tmp = np.zeros(S, np.float32)
+        for k in range(n_acc):
+            b = first_block + k * block_step
+            blk = np.ascontiguousarray(buf[b * stride:b * stride + 5120])
+            if blk.size < 5120:
+                blk = np.concatenate([blk, np.zeros(5120 - blk.size, np.uint8)])
+            self.L.oracle_sample(self.h, _p(blk))
+            for d in range(-self.dmax, self.dmax + 1):
+                self.L.oracle_cell_power(self.h, sv, d, _p(tmp))
+                power[d + self.dmax] += tmp
+        cells = np.zeros(self.num_doppler, CELL_DTYPE)
+        cells["max_pwr"] = power.max(axis=1)
+        cells["max_i"] = power.argmax(axis=1)
+        cells["tot_pwr"] = power.sum(axis=1, dtype=np.float64)
+        cells["snr"] = cells["max_pwr"] / (cells["tot_pwr"] / S)
+        return cells
 
     def search_file(self, path, max_runs=0):
         buf = ctypes.create_string_buffer(1 << 22)
