@@ -13,7 +13,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 def _header_symbols(path):
     text = open(path).read()
     text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
-    return sorted(set(re.findall(r"\b(gpsacq_[a-z_]+)\s*\(", text)))
+    return sorted(set(re.findall(r"\b(gpsacq_[a-z0-9_]+)\s*\(", text)))
 
 
 def test_exports_match_header():
