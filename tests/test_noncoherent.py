@@ -42,3 +42,34 @@ def test_noncoherent_vs_oracle(golden_dir):
         c, p = eng.search(buf, stride=stride, n_tasks=3)
         want = orc.search_noncoherent(buf, stride, 2, 2, 3, 2)
         np.testing.assert_allclose(c["max_pwr"][2], want["max_pwr"], rtol=2e-5)
+
+
+def test_bench_size_batch_properties():
+    """At bench.py's batch size the oracle is out of reach; check size-independent properties:
+    a batch equals its halves, a permutation of the blocks permutes the results, peaks equal the
+    reference's Doppler scan (:196-198) over the cells, and reruns are bit-identical."""
+    import gpsacq
+    rng = np.random.default_rng(11)
+    nblk = 2048
+    bits = rng.integers(0, 256, nblk * 5120, dtype=np.uint8)
+    with gpsacq.Engine(4.092e6, 5.456e6, 5000.0) as eng:
+        cells, peaks = eng.search(bits)
+        c1, p1 = eng.search(bits[:1024 * 5120])
+        c2, p2 = eng.search(bits[1024 * 5120:])  # blocks 1024.. keep their PRN (1024 % 32 == 0)
+        assert np.array_equal(cells[:1024], c1) and np.array_equal(cells[1024:], c2)
+        assert np.array_equal(peaks[:1024], p1) and np.array_equal(peaks[1024:], p2)
+        perm = rng.permutation(nblk)
+        tasks = np.stack([perm, perm % 32], axis=1)
+        cp, pp = eng.search(bits, tasks=tasks)
+        assert np.array_equal(cp, cells[perm]) and np.array_equal(pp, peaks[perm])
+        # k_peaks against a host restatement of the scan
+        best = np.zeros(nblk, dtype=np.int64)
+        snr = cells["snr"]
+        for t in range(nblk):
+            best[t] = int(np.argmax(snr[t]))  # first maximum == strict '>' scanning upwards
+        assert np.array_equal(peaks["lo_shift"], best - eng.dmax)
+        assert np.array_equal(peaks["ca_shift"], cells["max_i"][np.arange(nblk), best])
+        assert np.array_equal(peaks["snr"], snr[np.arange(nblk), best])
+        assert np.isfinite(snr).all() and (cells["max_i"] >= 0).all() and (cells["max_i"] < eng.num_lags).all()
+        # noise-only capture: no cell should look like a satellite
+        assert peaks["snr"].max() < 25
