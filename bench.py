@@ -62,6 +62,11 @@ def main():
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--blocks", type=int, default=2048, help="5120-byte blocks per GPU per step (64 runs)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--mode", choices=["blocks", "grid"], default="blocks",
+                    help="blocks (default, the metric's config): reference schedule, blocks sharded over ranks, weak scaling. "
+                         "grid (BASELINE configs[4]): --grid-blocks blocks x 32 PRN x +-100 kHz fine grid, Doppler slabs "
+                         "sharded over ranks, per-(block, PRN) peak all-reduce, strong scaling")
+    ap.add_argument("--grid-blocks", type=int, default=4)
     args = ap.parse_args()
 
     import torch
@@ -87,23 +92,38 @@ def main():
         else:
             dist.init_process_group(backend=backend)
 
-    eng = gpsacq.Engine(FC, FS, MAX_FO, device=dev_index)
-    nblk = args.blocks
-    host_bits = synth_bits(nblk, 1000 + rank)
+    from gpsacq import dist as gdist
+    grid = args.mode == "grid"
+    eng = gpsacq.Engine(FC, FS, 100000.0 if grid else MAX_FO, device=dev_index)
     dev = torch.device("cuda", dev_index)
+    if grid:
+        # every rank holds the same few blocks, searches all 32 PRNs over ITS slab of Doppler bins
+        nblk = args.grid_blocks
+        host_bits = synth_bits(nblk, 77)
+        first, nbins = gdist.shard_doppler(eng.dmax, rank, world)
+        total_bins = 2 * eng.dmax + 1
+        eng.set_doppler_window(first, nbins)
+        tasks = np.array([(b, sv) for b in range(nblk) for sv in range(32)], dtype=np.int32)
+        d_tasks = torch.from_numpy(tasks).to(dev)
+        n_tasks = tasks.shape[0]
+        cells_per_step = n_tasks * nbins          # this rank's share
+        job_cells_per_step = n_tasks * total_bins  # whole job, fixed as N grows
+    else:
+        nblk = args.blocks
+        host_bits = synth_bits(nblk, 1000 + rank)
+        d_tasks, n_tasks = None, nblk
+        cells_per_step = nblk * eng.num_doppler
+        job_cells_per_step = cells_per_step * world
     d_bits = torch.from_numpy(host_bits).to(dev)
-    d_peaks = torch.zeros((nblk, 4), dtype=torch.int32, device=dev)
-    cells_per_step = nblk * eng.num_doppler
+    d_peaks = torch.zeros((n_tasks, 4), dtype=torch.int32, device=dev)
 
     def step():
-        eng.search_device(d_bits.data_ptr(), nblk, d_peaks.data_ptr(), sync=True)
-        # per-PRN best peak of this rank's capture, packed so that integer MAX reproduces the
-        # reference's ordering (higher SNR; ties -> lower Doppler bin, :198)
-        snr_bits = d_peaks[:, 0].to(torch.int64)
-        lo = d_peaks[:, 1].to(torch.int64) + eng.dmax
-        ca = d_peaks[:, 2].to(torch.int64)
-        key = (snr_bits << 32) | ((0xFFFF - lo) << 16) | ca
-        best = key.view(-1, 32).max(dim=0).values
+        eng.search_device(d_bits.data_ptr(), nblk, d_peaks.data_ptr(), d_tasks_ptr=d_tasks.data_ptr() if grid else None,
+                          n_tasks=n_tasks, sync=True)
+        # best peak per PRN (blocks mode) / per (block, PRN) (grid mode), packed so that integer MAX
+        # reproduces the reference's ordering (higher SNR; ties -> lower Doppler bin, :198)
+        key = gdist.pack_keys(d_peaks, eng.dmax)
+        best = key if grid else gdist.per_prn_best(key)
         if dist is not None:
             if backend == "nccl":
                 dist.all_reduce(best, op=dist.ReduceOp.MAX)  # RCCL over xGMI, 256 bytes
@@ -136,7 +156,7 @@ def main():
     timing = eng.last_timing()
 
     if rank == 0:
-        total_cells = cells_per_step * world * args.steps
+        total_cells = job_cells_per_step * args.steps
         value = total_cells / elapsed
         kern_ms = float(np.mean(corr_ms))
         achieved = cells_per_step * ALG_BYTES_PER_CELL / (kern_ms * 1e-3) / 1e9
@@ -156,14 +176,17 @@ def main():
             "warmup": args.warmup,
             "ms_per_step": 1e3 * elapsed / args.steps,
             "higher_is_better": True,
-            "scaling": "weak",
+            "scaling": "strong" if grid else "weak",
             "vs_baseline": None,
             "dtype": "f32",
             "data": "synthetic",
-            "config": {"workload": "BASELINE configs[1]: 32 PRN x 73 Doppler bins (+-5 kHz, fs/N = 136.4 Hz), N=40000, "
-                                   "5456 lags, reference schedule block->PRN (block % 32)",
+            "config": {"workload": (f"BASELINE configs[4]: {args.grid_blocks} blocks x 32 PRN x {2 * eng.dmax + 1} Doppler bins (+-100 kHz, "
+                                    "fs/N = 136.4 Hz), N=40000, 5456 lags") if grid else
+                                   ("BASELINE configs[1]: 32 PRN x 73 Doppler bins (+-5 kHz, fs/N = 136.4 Hz), N=40000, "
+                                    "5456 lags, reference schedule block->PRN (block % 32)"),
                        "fs_hz": FS, "if_hz": FC, "blocks_per_gpu": nblk, "cells_per_step_per_gpu": cells_per_step,
-                       "parallelism": f"blocks sharded over {world} GPU(s), per-PRN peak all-reduce(MAX)"},
+                       "parallelism": (f"Doppler slabs sharded over {world} GPU(s), per-(block, PRN) peak all-reduce(MAX)" if grid else
+                                       f"blocks sharded over {world} GPU(s), per-PRN peak all-reduce(MAX)")},
             "roofline": {"bound": "hbm", "kernel": f"k_corr<{eng.acc_columns}>", "achieved": achieved, "peak": HBM_PEAK_GBS,
                          "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_src,
                          "algorithmic_bytes_per_launch": cells_per_step * ALG_BYTES_PER_CELL,

@@ -73,3 +73,29 @@ def test_bench_size_batch_properties():
         assert np.isfinite(snr).all() and (cells["max_i"] >= 0).all() and (cells["max_i"] < eng.num_lags).all()
         # noise-only capture: no cell should look like a satellite
         assert peaks["snr"].max() < 25
+
+
+def test_doppler_slabs_merge_to_full_search(golden_dir):
+    """Multi-GPU decomposition by Doppler slab, emulated on one GPU: two windows searched separately
+    and merged with the packed-key MAX (gpsacq.dist) must equal the full-range search."""
+    import torch
+    import gpsacq
+    from gpsacq import dist as D
+    buf = open(os.path.join(golden_dir, "synth_nott_fs5456.bin"), "rb").read()[:5 * 5120]
+    tasks = [(b, sv) for b in (0, 4) for sv in range(32)]
+    with gpsacq.Engine(4.092e6, 5.456e6, 20000.0) as eng:
+        full_cells, full_peaks = eng.search(buf, tasks=tasks)
+        merged = None
+        for rank in range(3):
+            first, n = D.shard_doppler(eng.dmax, rank, 3)
+            eng.set_doppler_window(first, n)
+            cells, peaks = eng.search(buf, tasks=tasks)
+            assert cells.shape[1] == n
+            assert np.array_equal(cells, full_cells[:, first + eng.dmax:first + eng.dmax + n])
+            key = D.pack_keys(torch.from_numpy(peaks.view(np.int32).reshape(-1, 4).copy()), eng.dmax)
+            merged = key if merged is None else torch.maximum(merged, key)
+        snr, lo, ca = D.unpack_keys(merged, eng.dmax)
+        assert np.array_equal(snr.numpy(), full_peaks["snr"])
+        assert np.array_equal(lo.numpy(), full_peaks["lo_shift"]) and np.array_equal(ca.numpy(), full_peaks["ca_shift"])
+        with pytest.raises(gpsacq.GpsAcqError):
+            eng.set_doppler_window(-eng.dmax - 1, 3)
