@@ -99,3 +99,19 @@ def test_doppler_slabs_merge_to_full_search(golden_dir):
         assert np.array_equal(lo.numpy(), full_peaks["lo_shift"]) and np.array_equal(ca.numpy(), full_peaks["ca_shift"])
         with pytest.raises(gpsacq.GpsAcqError):
             eng.set_doppler_window(-eng.dmax - 1, 3)
+
+
+def test_forward_chunking_beyond_8192_blocks():
+    """More blocks than one forward-transform launch covers (8192): the chunk seam must be invisible."""
+    import gpsacq
+    rng = np.random.default_rng(5)
+    nblk = 8192 + 40
+    bits = rng.integers(0, 256, nblk * 5120, dtype=np.uint8)
+    with gpsacq.Engine(2.046e6, 8.184e6, 5000.0) as eng:  # the 33-column kernel instance
+        tasks = np.array([(b, b % 32) for b in list(range(8180, nblk)) + [0, 1, 4095]], dtype=np.int32)
+        cells, peaks = eng.search(bits, tasks=tasks)
+        tail = bits[8180 * 5120:]
+        c2, p2 = eng.search(tail, tasks=np.array([(b - 8180, b % 32) for b in range(8180, nblk)], dtype=np.int32))
+        assert np.array_equal(cells[:nblk - 8180], c2) and np.array_equal(peaks[:nblk - 8180], p2)
+        c3, p3 = eng.search(bits[:4096 * 5120], tasks=np.array([(0, 0), (1, 1), (4095, 4095 % 32)], dtype=np.int32))
+        assert np.array_equal(cells[nblk - 8180:], c3)
