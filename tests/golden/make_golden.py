@@ -22,6 +22,8 @@ Fixtures:
   synth_iq8_rtl_bits.bin     its 1-bit conversion by oracle/iq8_oracle.py (mix 0.62 MHz, DC removed).
   synth_weak_fs5456.bin      seeded weak-signal capture for the non-coherent extension: fs 5.456 MHz,
                              7 blocks laid out every 5456 bytes (8 whole C/A periods), PRN 12 weak, PRN 3 stronger.
+  synth_weak_rtl_fs2800.bin  BASELINE configs[3] shape: fs 2.8 MHz, IF 0.62 MHz, 6 blocks every 5250 bytes (15 C/A
+                             periods), PRN 9 weak at +40 kHz (receiver LO offset, bin 571 of +-1428).
   np64_cells_*.npz           per-cell {max_pwr, max_i, tot_pwr} from an INDEPENDENT float64
                              numpy restatement (np.fft / pocketfft) of
                              c/search_offline.cpp:121-201 for a few (block, sv) pairs.
@@ -210,6 +212,16 @@ def main():
         nav = np.where((np.floor(m / (20 * 5456)).astype(np.int64) % 2) == 0, 1.0, -1.0)  # a data-bit flip every 20 ms
         y += amp * nav * chips[idx] * np.cos(2 * np.pi * ((4.092e6 + fd) / 5.456e6 * m + rng.random()))
     np.packbits((y < 0).astype(np.uint8), bitorder='little').tofile(os.path.join(HERE, "synth_weak_fs5456.bin"))
+
+    rng = np.random.default_rng(2800)
+    ns = 6 * 5250 * 8
+    m = np.arange(ns, dtype=np.float64)
+    y = rng.standard_normal(ns)
+    fo = 571 * 2.8e6 / N  # LO offset: shifts the carrier, not the code rate
+    chips = 1.0 - 2.0 * ca_chips(*TAPS[8])
+    idx = np.floor((m + 777) * CPS / 2.8e6).astype(np.int64) % 1023
+    y += 0.06 * chips[idx] * np.cos(2 * np.pi * ((0.62e6 + fo) / 2.8e6 * m + 0.4))
+    np.packbits((y < 0).astype(np.uint8), bitorder='little').tofile(os.path.join(HERE, "synth_weak_rtl_fs2800.bin"))
 
     def blocks_of(buf):
         return [buf[i * 5120:(i + 1) * 5120] for i in range(len(buf) // 5120)]

@@ -96,12 +96,14 @@ class Oracle:
             peaks[t] = p
         return cells, peaks
 
-    def search_noncoherent(self, bits, stride, first_block, sv, n_acc, block_step):
+    def search_noncoherent(self, bits, stride, first_block, sv, n_acc, block_step, first_bin=None, n_bins=None):
         """Restatement of the non-coherent extension: per Doppler bin, sum |IFFT|^2 per lag over
         n_acc blocks, then the reference's scan (:190-196) over the sum."""
         buf = np.frombuffer(bits, dtype=np.uint8)
         S = self.num_lags
-        power = np.zeros((self.num_doppler, S), np.float32)
+        first_bin = -self.dmax if first_bin is None else first_bin
+        n_bins = self.num_doppler if n_bins is None else n_bins
+        power = np.zeros((n_bins, S), np.float32)
         tmp = np.zeros(S, np.float32)
         for k in range(n_acc):
             b = first_block + k * block_step
@@ -109,10 +111,10 @@ class Oracle:
             if blk.size < 5120:
                 blk = np.concatenate([blk, np.zeros(5120 - blk.size, np.uint8)])
             self.L.oracle_sample(self.h, _p(blk))
-            for d in range(-self.dmax, self.dmax + 1):
+            for d in range(first_bin, first_bin + n_bins):
                 self.L.oracle_cell_power(self.h, sv, d, _p(tmp))
-                power[d + self.dmax] += tmp
-        cells = np.zeros(self.num_doppler, CELL_DTYPE)
+                power[d - first_bin] += tmp
+        cells = np.zeros(n_bins, CELL_DTYPE)
         cells["max_pwr"] = power.max(axis=1)
         cells["max_i"] = power.argmax(axis=1)
         cells["tot_pwr"] = power.sum(axis=1, dtype=np.float64)

@@ -115,3 +115,25 @@ def test_forward_chunking_beyond_8192_blocks():
         assert np.array_equal(cells[:nblk - 8180], c2) and np.array_equal(peaks[:nblk - 8180], p2)
         c3, p3 = eng.search(bits[:4096 * 5120], tasks=np.array([(0, 0), (1, 1), (4095, 4095 % 32)], dtype=np.int32))
         assert np.array_equal(cells[nblk - 8180:], c3)
+
+
+def test_config4_weak_signal_rtl_path(golden_dir):
+    """BASELINE configs[3] ("weak-signal ... +-100 kHz ... rtl_sdr 2.8 Msps path") as built here:
+    fs 2.8 MHz, IF 0.62 MHz, max_fo 100 kHz honoured (2857 bins of 70 Hz, N = 40000 = 14.3 ms
+    coherent), 5 non-coherent sums over blocks 15 C/A periods apart."""
+    import gpsacq
+    from oracle_lib import Oracle
+    buf = open(os.path.join(golden_dir, "synth_weak_rtl_fs2800.bin"), "rb").read()
+    with gpsacq.Engine(0.62e6, 2.8e6, 100000.0) as eng:
+        assert eng.num_doppler == 2857 and eng.num_lags == 2800 and eng.aligned_stride() == 5250
+        eng.set_noncoherent(5, 1)
+        cells, peaks = eng.search(buf, tasks=[(0, 8), (0, 30)], stride=5250)  # PRN 9 present, PRN 31 absent
+        assert int(peaks["lo_shift"][0]) == 571 and abs(int(peaks["ca_shift"][0]) - 777) <= 1
+        assert peaks["snr"][0] > 1.8 * peaks["snr"][1]
+        # a window of the grid against the oracle's restatement
+        orc = Oracle(0.62e6, 2.8e6, 100000.0)
+        want = orc.search_noncoherent(buf, 5250, 0, 8, 5, 1, first_bin=540, n_bins=60)
+        got = cells[0][540 + eng.dmax:600 + eng.dmax]
+        np.testing.assert_allclose(got["max_pwr"], want["max_pwr"], rtol=2e-5)
+        np.testing.assert_allclose(got["tot_pwr"], want["tot_pwr"], rtol=2e-5)
+        assert (got["max_i"] != want["max_i"]).sum() <= 1
