@@ -58,12 +58,34 @@ __global__ __launch_bounds__(WG) void k_fwd_sub(FwdArgs a) {
     for (int i = tid; i < M_SUB; i += WG) dst[i] = lds[i];
 }
 
-// grid (ceil(5000/256), n_items)
+// grid (ceil(5000/256), n_items).  The polyphase destination of X[k1 + 5000 s] is row k1 & 7, column
+// (k1 >> 3) + 625 s: written straight from the butterfly every lane would hit its own cache line, so
+// the 256 x 8 results of a workgroup are transposed through LDS and leave as 256-byte row segments.
 __global__ __launch_bounds__(WG) void k_fwd_combine(CombineArgs a) {
-    const int k1 = blockIdx.x * WG + threadIdx.x, item = blockIdx.y;
-    if (k1 >= M_SUB) return;
-    fwd_combine(k1, a.g + (size_t)item * NPOLY * M_SUB, a.conj_out != 0, a.out + (size_t)item * a.item_stride,
-                a.row, a.off);
+    __shared__ cf tile[NPOLY][NPOLY][WG / NPOLY + 1];  // [s][k1 & 7][(k1 - k0) >> 3], padded
+    const int tid = threadIdx.x, k0 = blockIdx.x * WG, k1 = k0 + tid, item = blockIdx.y;
+    if (k1 < M_SUB) {
+        const cf* g = a.g + (size_t)item * NPOLY * M_SUB;
+        cf x[NPOLY];
+#pragma unroll
+        for (int q = 0; q < NPOLY; ++q) x[q] = g[q * M_SUB + k1];
+        dft8<-1>(x);
+#pragma unroll
+        for (int s = 0; s < NPOLY; ++s) {
+            cf v = x[s];
+            if (a.conj_out) v.y = -v.y;
+            tile[s][tid & 7][tid >> 3] = v;
+        }
+    }
+    __syncthreads();
+    cf* out = a.out + (size_t)item * a.item_stride;
+    const int j0 = k0 >> 3;
+#pragma unroll
+    for (int r = 0; r < NPOLY; ++r) {
+        const int idx = r * WG + tid, row = idx >> 5, i = idx & 31;
+        const int s = row >> 3, qp = row & 7;
+        if (k0 + NPOLY * i + qp < M_SUB) out[qp * a.row + a.off + j0 + i + (M_SUB / NPOLY) * s] = tile[s][qp][i];
+    }
 }
 
 // cyclic halo of the code rows: grid (8 * n_codes), any block size
