@@ -1,7 +1,7 @@
 // acq_kernels.hip -- gfx950 kernels of the GPS L1 C/A acquisition engine.
 //
 // Replaces the hot loops of c/search_offline.cpp (reference, /root/reference):
-//   k_fwd_sub + k_fwd_combine   Sample()    :141-161  (unpack, XOR mix, FFT-40000)
+//   k_fwd<bits>                 Sample()    :141-161  (unpack, XOR mix, FFT-40000)
 //                               SearchInit():101-106  (code replica -> code spectrum)
 //   k_corr<MC>                  Correlate() :181-196  (shifted conj-multiply, IFFT-40000,
 //                                                      |.|^2 max/argmax/sum over FS/1000 lags)
@@ -27,65 +27,30 @@ __constant__ cf c_wq[NPOLY * WQ_STRIDE];
 hipError_t upload_wq(const cf* host) { return hipMemcpyToSymbol(HIP_SYMBOL(c_wq), host, sizeof(cf) * NPOLY * WQ_STRIDE); }
 
 // ---------------------------------------------------------------------------------------
-template <class Src> struct SrcOf;
-template <> struct SrcOf<BitsSrc> {
-    static __device__ BitsSrc make(const FwdArgs& a, int item) {
-        return BitsSrc{(const uint8_t*)a.src + (size_t)item * a.src_stride, a.cos_mask, a.sin_mask};
-    }
-};
-template <> struct SrcOf<RealSrc> {
-    static __device__ RealSrc make(const FwdArgs& a, int item) {
-        return RealSrc{(const float*)a.src + (size_t)item * a.src_stride};
-    }
-};
-
-// grid (8, n_items): polyphase component q of item -> g[item][q][0..5000)
-template <class Src>
-__global__ __launch_bounds__(WG) void k_fwd_sub(FwdArgs a) {
+// Forward transform (Sample() :141-161 / SearchInit() :101-106): grid (8, n_items), one workgroup per
+// (item, kappa) computes row kappa of the item's polyphase spectrum and writes it once, coalesced.
+template <bool BITS>
+__global__ __launch_bounds__(WG) void k_fwd(FwdArgs a) {
     __shared__ cf lds[M_SUB];
-    const int tid = threadIdx.x, q = blockIdx.x, item = blockIdx.y;
-    const Src src = SrcOf<Src>::make(a, item);
-    fwd_phase1(tid, q, src, a.t1, lds);
+    __shared__ uint8_t ibits[BITS ? USED_BYTES + 8 : 8], qbits[BITS ? USED_BYTES + 8 : 8];
+    const int tid = threadIdx.x, kappa = blockIdx.x, item = blockIdx.y;
+    if (BITS) {
+        fwd_stage_bits(tid, (const uint8_t*)a.src + (size_t)item * a.src_stride, a.cos_mask, a.sin_mask, ibits, qbits);
+        __syncthreads();
+        fwd_phase1(tid, kappa, BitsSrc{ibits, qbits}, a.tn, a.t1, lds);
+    } else {
+        fwd_phase1(tid, kappa, RealSrc{(const float*)a.src + (size_t)item * a.src_stride}, a.tn, a.t1, lds);
+    }
     __syncthreads();
     fwd_phase2(tid, a.t2, lds);
     __syncthreads();
     cf y[RC];
     fwd_phase3_load(tid, lds, y);
     __syncthreads();
-    fwd_phase3_store(tid, q, a.bq, a.wq, y, lds);
+    fwd_phase3_store(tid, a.conj_out != 0, y, lds);
     __syncthreads();
-    cf* dst = a.g + ((size_t)item * NPOLY + q) * M_SUB;
-    for (int i = tid; i < M_SUB; i += WG) dst[i] = lds[i];
-}
-
-// grid (ceil(5000/256), n_items).  The polyphase destination of X[k1 + 5000 s] is row k1 & 7, column
-// (k1 >> 3) + 625 s: written straight from the butterfly every lane would hit its own cache line, so
-// the 256 x 8 results of a workgroup are transposed through LDS and leave as 256-byte row segments.
-__global__ __launch_bounds__(WG) void k_fwd_combine(CombineArgs a) {
-    __shared__ cf tile[NPOLY][NPOLY][WG / NPOLY + 1];  // [s][k1 & 7][(k1 - k0) >> 3], padded
-    const int tid = threadIdx.x, k0 = blockIdx.x * WG, k1 = k0 + tid, item = blockIdx.y;
-    if (k1 < M_SUB) {
-        const cf* g = a.g + (size_t)item * NPOLY * M_SUB;
-        cf x[NPOLY];
-#pragma unroll
-        for (int q = 0; q < NPOLY; ++q) x[q] = g[q * M_SUB + k1];
-        dft8<-1>(x);
-#pragma unroll
-        for (int s = 0; s < NPOLY; ++s) {
-            cf v = x[s];
-            if (a.conj_out) v.y = -v.y;
-            tile[s][tid & 7][tid >> 3] = v;
-        }
-    }
-    __syncthreads();
-    cf* out = a.out + (size_t)item * a.item_stride;
-    const int j0 = k0 >> 3;
-#pragma unroll
-    for (int r = 0; r < NPOLY; ++r) {
-        const int idx = r * WG + tid, row = idx >> 5, i = idx & 31;
-        const int s = row >> 3, qp = row & 7;
-        if (k0 + NPOLY * i + qp < M_SUB) out[qp * a.row + a.off + j0 + i + (M_SUB / NPOLY) * s] = tile[s][qp][i];
-    }
+    cf* dst = a.out + (size_t)item * a.item_stride + (size_t)kappa * a.row + a.off;
+    for (int i = tid; i < M_SUB / 2; i += WG) reinterpret_cast<cf2*>(dst)[i] = reinterpret_cast<const cf2*>(lds)[i];
 }
 
 // cyclic halo of the code rows: grid (8 * n_codes), any block size
@@ -240,14 +205,11 @@ __global__ void k_peaks(const Cell* cells, Peak* peaks, int n_tasks, int ndop, i
 
 // ---------------------------------------------------------------------------------------
 // launchers (host)
-void launch_fwd_sub_bits(const FwdArgs& a, int n_items, hipStream_t s) {
-    hipLaunchKernelGGL(k_fwd_sub<BitsSrc>, dim3(NPOLY, n_items), dim3(WG), 0, s, a);
+void launch_fwd_bits(const FwdArgs& a, int n_items, hipStream_t s) {
+    hipLaunchKernelGGL(k_fwd<true>, dim3(NPOLY, n_items), dim3(WG), 0, s, a);
 }
-void launch_fwd_sub_real(const FwdArgs& a, int n_items, hipStream_t s) {
-    hipLaunchKernelGGL(k_fwd_sub<RealSrc>, dim3(NPOLY, n_items), dim3(WG), 0, s, a);
-}
-void launch_fwd_combine(const CombineArgs& a, int n_items, hipStream_t s) {
-    hipLaunchKernelGGL(k_fwd_combine, dim3((M_SUB + WG - 1) / WG, n_items), dim3(WG), 0, s, a);
+void launch_fwd_real(const FwdArgs& a, int n_items, hipStream_t s) {
+    hipLaunchKernelGGL(k_fwd<false>, dim3(NPOLY, n_items), dim3(WG), 0, s, a);
 }
 void launch_code_halo(cf* cpp, int n_rows, int crow, int halo, hipStream_t s) {
     hipLaunchKernelGGL(k_code_halo, dim3(n_rows), dim3(WG), 0, s, cpp, crow, halo);

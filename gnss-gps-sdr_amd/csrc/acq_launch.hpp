@@ -8,19 +8,14 @@
 namespace acq {
 
 struct FwdArgs {
-    const void* src;     // BitsSrc: packed capture bytes; RealSrc: float replicas
+    const void* src;     // bits: packed capture bytes; real: float replicas
     size_t src_stride;   // per item: bytes (bits) or floats (real)
     const uint8_t* cos_mask;
     const uint8_t* sin_mask;
     const cf* t1;
     const cf* t2;
-    const cf* bq;
-    const cf* wq;
-    cf* g;               // [n_items][8][5000]
-};
-struct CombineArgs {
-    const cf* g;         // [n_items][8][5000]
-    cf* out;             // [n_items][item_stride]
+    const cf* tn;
+    cf* out;             // [n_items][item_stride], polyphase rows
     size_t item_stride;  // complex elements per item in out
     long row;            // elements per polyphase row in out
     int off;             // halo offset inside a row
@@ -43,15 +38,13 @@ struct CorrArgs {
     const cf* t1;
     const cf* t2;
     const cf* bq;
-    const cf* wq;
     Cell* cells;       // [n_tasks][ndop]
     int n_tasks, ndop, dop_first, nlags, crow, halo;  // bins dop_first .. dop_first+ndop-1
     int n_acc, acc_step;  // non-coherent mode: spectra tk.spec + k*acc_step, k < n_acc (n_acc = 1: coherent)
 };
 
-void launch_fwd_sub_bits(const FwdArgs& a, int n_items, hipStream_t s);
-void launch_fwd_sub_real(const FwdArgs& a, int n_items, hipStream_t s);
-void launch_fwd_combine(const CombineArgs& a, int n_items, hipStream_t s);
+void launch_fwd_bits(const FwdArgs& a, int n_items, hipStream_t s);
+void launch_fwd_real(const FwdArgs& a, int n_items, hipStream_t s);
 void launch_code_halo(cf* cpp, int n_rows, int crow, int halo, hipStream_t s);
 void launch_quirk_patch(const QuirkArgs& a, int n_patch, hipStream_t s);
 int corr_columns(int nlags);

@@ -109,6 +109,17 @@ ACQ_HD cf cmacc_u(cf acc, cf a, cf w) {
     return acc + cmulc(a, w);
 #endif
 }
+// acc + a * w, w wave-uniform
+ACQ_HD cf cmadd_u(cf acc, cf a, cf w) {
+#if ACQ_PK_ASM
+    cf r = acc;  // r += (ax wx, ax wy);  r += (-ay wy, ay wx)
+    asm("v_pk_fma_f32 %0, %1, %2, %0 op_sel_hi:[0,1,1]\n\t"
+        "v_pk_fma_f32 %0, %1, %2, %0 op_sel:[1,1,0] op_sel_hi:[1,0,1] neg_lo:[0,1,0]" : "+v"(r) : "v"(a), "s"(w));
+    return r;
+#else
+    return acc + cmul(a, w);
+#endif
+}
 // a + i b  and  a - i b
 ACQ_HD cf add_i(cf a, cf b) {
 #if ACQ_PK_ASM
@@ -164,6 +175,28 @@ template <int DIR> ACQ_HD void dft5(cf& x0, cf& x1, cf& x2, cf& x3, cf& x4) {
     x4 = sub_di<DIR>(m1, s1);
     x2 = add_di<DIR>(m2, s2);
     x3 = sub_di<DIR>(m2, s2);
+}
+
+// forward value of W_8^m = exp(-2 pi i m / 8), m taken mod 8
+ACQ_HD cf w8(int m) {
+    constexpr float R = 0.7071067811865476f;
+    switch (m & 7) {
+        case 0: return mk(1.f, 0.f);
+        case 1: return mk(R, -R);
+        case 2: return mk(0.f, -1.f);
+        case 3: return mk(-R, -R);
+        case 4: return mk(-1.f, 0.f);
+        case 5: return mk(-R, R);
+        case 6: return mk(0.f, 1.f);
+        default: return mk(R, R);
+    }
+}
+// Output kappa of an 8-point forward DFT: sum_nu x[nu] W_8^{nu kappa}, with the three wave-uniform
+// rotations c4 = W_8^{4 kappa} (= +-1), c2 = W_8^{2 kappa}, c1 = W_8^{kappa} supplied by the caller.
+ACQ_HD cf dft8_one(const cf* x, cf c4, cf c2, cf c1) {
+    cf u0 = x[0] + c4.x * x[4], u1 = x[1] + c4.x * x[5], u2 = x[2] + c4.x * x[6], u3 = x[3] + c4.x * x[7];
+    cf v0 = cmadd_u(u0, u2, c2), v1 = cmadd_u(u1, u3, c2);
+    return cmadd_u(v0, v1, c1);
 }
 
 // 8-point DFT, natural order in and out.

@@ -149,37 +149,64 @@ ACQ_HD void peak_merge(float& mx, int& mi, float omx, int omi) {
 }
 
 // ---------------------------------------------------------------------------------------
-// Sample(): 1-bit unpack + XOR quadrature mix (:143-153) fused into pass 1 of DFT_5000.
-// Polyphase component q of the sample stream is bit q of every byte.
-struct BitsSrc {
-    const uint8_t* bytes;     // this block, >= 5000 bytes
-    const uint8_t* cos_mask;  // [5120]
-    const uint8_t* sin_mask;  // [5120]
-    ACQ_HD cf at(int q, int j) const {
-        const unsigned b = bytes[j];
-        const unsigned ib = ((b ^ cos_mask[j]) >> q) & 1u, qb = ((b ^ sin_mask[j]) >> q) & 1u;
-        return mk(ib ? -1.f : 1.f, qb ? -1.f : 1.f);
+// Forward transform of Sample() (:141-161) and SearchInit() (:101-106), decimation in frequency:
+//   X[8 k' + kappa] = DFT_5000( z_kappa )[k'],
+//   z_kappa[n'] = W_N^{n' kappa} * sum_{nu<8} x[n' + 5000 nu] W_8^{nu kappa}
+// One workgroup per (block, kappa): row kappa of the polyphase spectrum layout comes out in natural
+// order and is written once, already conjugated -- no scratch round trip.  The eight samples of a
+// term sit in bytes (n' >> 3) + 625 nu at bit n' & 7 (5000 = 8 * 625).
+ACQ_HD float pm1(unsigned bit) {  // 0 -> +1.0f, 1 -> -1.0f   (Bipolar(), :68-70)
+    union { unsigned u; float f; } v;
+    v.u = 0x3f800000u | (bit << 31);
+    return v.f;
+}
+struct BitsSrc {            // 1-bit unpack + XOR quadrature mix (:143-153)
+    const uint8_t* ibits;   // [5000] capture bytes ^ cos mask  (workgroup-local copy)
+    const uint8_t* qbits;   // [5000] capture bytes ^ sin mask
+    ACQ_HD void gather(int np, cf* x) const {  // x[nu] = sample n' + 5000 nu
+        const int byte = np >> 3, sh = np & 7;
+#pragma unroll
+        for (int nu = 0; nu < NPOLY; ++nu)
+            x[nu] = mk(pm1((ibits[byte + 625 * nu] >> sh) & 1u), pm1((qbits[byte + 625 * nu] >> sh) & 1u));
     }
 };
-// SearchInit(): real code replica (:101-102), imag = 0.
-struct RealSrc {
-    const float* x;  // [40000]
-    ACQ_HD cf at(int q, int j) const { return mk(x[NPOLY * j + q], 0.f); }
+struct RealSrc {            // real code replica, imag = 0 (:101-102)
+    const float* x;         // [40000]
+    ACQ_HD void gather(int np, cf* v) const {
+#pragma unroll
+        for (int nu = 0; nu < NPOLY; ++nu) v[nu] = mk(x[np + M_SUB * nu], 0.f);
+    }
 };
 
+// workgroup-local copy of one block's bytes with the LO masks applied (thread tid's share)
+ACQ_HD void fwd_stage_bits(int tid, const uint8_t* __restrict__ bytes, const uint8_t* __restrict__ cos_mask,
+                           const uint8_t* __restrict__ sin_mask, uint8_t* ibits, uint8_t* qbits) {
+    for (int i = tid; i < USED_BYTES; i += WG) {
+        const uint8_t b = bytes[i];
+        ibits[i] = b ^ cos_mask[i];
+        qbits[i] = b ^ sin_mask[i];
+    }
+}
+
 template <class Src>
-ACQ_HD void fwd_phase1(int tid, int q, const Src& src, const cf* __restrict__ t1, cf* lds) {
+ACQ_HD void fwd_phase1(int tid, int kappa, const Src& src, const cf* __restrict__ tn, const cf* __restrict__ t1, cf* lds) {
     if (tid >= NBF3) return;
     cf w[2][RA - 1];
     load_tw1(tid, t1, w);
+    const cf c4 = w8(4 * kappa), c2 = w8(2 * kappa), c1 = w8(kappa);
+    const cf* tk = tn + kappa * M_SUB + 2 * tid;
+    cf x0[RA], x1[RA];
 #pragma unroll
-    for (int h = 0; h < 2; ++h) {
-        const int jp = 2 * tid + h;
-        cf x[RA];
-#pragma unroll
-        for (int a = 0; a < RA; ++a) x[a] = src.at(q, jp + NBF1 * a);
-        pass1_store<-1>(x, jp, w[h], lds);
+    for (int a = 0; a < RA; ++a) {
+        cf g[NPOLY], tw0, tw1;
+        ld2(tk + NBF1 * a, tw0, tw1);
+        src.gather(2 * tid + NBF1 * a, g);
+        x0[a] = cmul(dft8_one(g, c4, c2, c1), tw0);
+        src.gather(2 * tid + 1 + NBF1 * a, g);
+        x1[a] = cmul(dft8_one(g, c4, c2, c1), tw1);
     }
+    pass1_store<-1>(x0, 2 * tid, w[0], lds);
+    pass1_store<-1>(x1, 2 * tid + 1, w[1], lds);
 }
 ACQ_HD void fwd_phase2(int tid, const cf* __restrict__ t2, cf* lds) {
     if (tid < NBF2) pass2_inplace<-1>(tid, t2, lds);
@@ -188,29 +215,15 @@ ACQ_HD void fwd_phase2(int tid, const cf* __restrict__ t2, cf* lds) {
 ACQ_HD void fwd_phase3_load(int tid, const cf* lds, cf* y) {
     if (tid < NBF3) pass3_load<-1>(tid, lds, y);
 }
-// g[k1] = W_N^{q k1} F_q[k1], k1 = 250 n'' + rho, written in natural order
-ACQ_HD void fwd_phase3_store(int tid, int q, const cf* __restrict__ bq, const cf* __restrict__ wq, const cf* y, cf* dst) {
+// natural order k' = 250 n'' + rho; conjugated for block spectra (Correlate multiplies by conj(data), :183-184)
+ACQ_HD void fwd_phase3_store(int tid, bool conj_out, const cf* y, cf* dst) {
     if (tid >= NBF3) return;
     const int rho = pass3_rho(tid);
-    const cf b = bq[q * NBF3 + tid];
 #pragma unroll
-    for (int n = 0; n < RC; ++n) dst[NBF3 * n + rho] = cmul_u(cmul(y[n], b), wq[q * WQ_STRIDE + n]);
-}
-
-// Radix-8 combine: X[k1 + 5000 s] = sum_q W_8^{q s} g[q][k1]; the result is stored in the
-// polyphase layout out[(k mod 8) * row + off + k / 8], conjugated for block spectra
-// (Correlate multiplies by conj(data), :183-184).
-ACQ_HD void fwd_combine(int k1, const cf* __restrict__ g, bool conj_out, cf* out, long row, int off) {
-    cf x[NPOLY];
-#pragma unroll
-    for (int q = 0; q < NPOLY; ++q) x[q] = g[q * M_SUB + k1];
-    dft8<-1>(x);
-    const int qp = k1 & 7, j0 = k1 >> 3;
-#pragma unroll
-    for (int s = 0; s < NPOLY; ++s) {
-        cf v = x[s];
+    for (int n = 0; n < RC; ++n) {
+        cf v = y[n];
         if (conj_out) v.y = -v.y;
-        out[qp * row + off + j0 + (M_SUB / NPOLY) * s] = v;
+        dst[NBF3 * n + rho] = v;
     }
 }
 

@@ -25,7 +25,10 @@ struct Tables {
     std::vector<cf> t2;  // [25][20]    W_500^{j'' beta}
     std::vector<cf> bq;  // [8][250]    W_40000^{q rho(t3)}, rho = 10 (t3 % 25) + t3 / 25
     std::vector<cf> wq;  // [8][40]     W_160^{q m}
-    Tables() : t1(RA * NBF1), t2((size_t)NT2), bq((size_t)NPOLY * NBF3), wq(NPOLY * WQ_STRIDE) {
+    std::vector<cf> tn;  // [8][5000]   W_40000^{n' kappa}: forward transform's decimation-in-frequency twiddle
+    Tables() : t1(RA * NBF1), t2((size_t)NT2), bq((size_t)NPOLY * NBF3), wq(NPOLY * WQ_STRIDE), tn((size_t)NPOLY * M_SUB) {
+        for (int ka = 0; ka < NPOLY; ++ka)
+            for (int n = 0; n < M_SUB; ++n) tn[(size_t)ka * M_SUB + n] = unit_fwd((long long)n * ka, N_FFT);
         for (int al = 0; al < RA; ++al)
             for (int jp = 0; jp < NBF1; ++jp) t1[al * NBF1 + jp] = unit_fwd((long long)jp * al, M_SUB);
         for (int be = 0; be < RB; ++be)

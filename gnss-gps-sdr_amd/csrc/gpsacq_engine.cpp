@@ -48,7 +48,7 @@ struct gpsacq_engine {
     hipStream_t stream = nullptr;
     hipEvent_t ev[4] = {nullptr, nullptr, nullptr, nullptr};
     // constants
-    cf *d_t1 = nullptr, *d_t2 = nullptr, *d_bq = nullptr, *d_wq = nullptr;
+    cf *d_t1 = nullptr, *d_t2 = nullptr, *d_bq = nullptr, *d_tn = nullptr;
     uint8_t *d_cos = nullptr, *d_sin = nullptr;
     cf* d_code = nullptr;  // [32 + patch_cap][8][crow]
     size_t patch_cap = 0;
@@ -56,8 +56,8 @@ struct gpsacq_engine {
     // scratch (grown on demand)
     uint8_t* d_bits = nullptr;
     size_t bits_cap = 0;
-    cf *d_g = nullptr, *d_dpp = nullptr;
-    size_t g_cap = 0, dpp_cap = 0;  // in blocks
+    cf* d_dpp = nullptr;
+    size_t dpp_cap = 0;  // in blocks
     Task* d_tasks = nullptr;
     Cell* d_cells = nullptr;
     Peak* d_peaks = nullptr;
@@ -76,7 +76,7 @@ struct gpsacq_engine {
     int64_t cells_done = 0;
 };
 
-static const size_t kFwdChunk = 8192;  // blocks per forward-transform launch (grid.y and scratch bound)
+static const size_t kFwdChunk = 32768;  // blocks per forward-transform launch (grid.y bound)
 
 template <class T> static int grow(T*& p, size_t& cap, size_t need, size_t elem_bytes = sizeof(T)) {
     if (need <= cap) return GPSACQ_OK;
@@ -104,10 +104,10 @@ static int ensure_code_slots(gpsacq_engine* e, size_t n_patch) {
     return GPSACQ_OK;
 }
 
-// forward transforms of n items into out (polyphase layout), chunked over the g scratch
+// forward transforms of n items into out (polyphase layout)
 static int run_forward(gpsacq_engine* e, bool bits, const void* src, size_t src_stride, size_t n, cf* out,
                        size_t item_stride, long row, int off, bool conj_out) {
-    for (size_t base = 0; base < n; base += kFwdChunk) {
+    for (size_t base = 0; base < n; base += kFwdChunk) {  // grid.y bound
         const size_t cnt = std::min(kFwdChunk, n - base);
         FwdArgs fa{};
         fa.src = bits ? (const void*)((const uint8_t*)src + base * src_stride) : (const void*)((const float*)src + base * src_stride);
@@ -116,19 +116,14 @@ static int run_forward(gpsacq_engine* e, bool bits, const void* src, size_t src_
         fa.sin_mask = e->d_sin;
         fa.t1 = e->d_t1;
         fa.t2 = e->d_t2;
-        fa.bq = e->d_bq;
-        fa.wq = e->d_wq;
-        fa.g = e->d_g;
-        if (bits) launch_fwd_sub_bits(fa, (int)cnt, e->stream);
-        else launch_fwd_sub_real(fa, (int)cnt, e->stream);
-        CombineArgs ca{};
-        ca.g = e->d_g;
-        ca.out = out + base * item_stride;
-        ca.item_stride = item_stride;
-        ca.row = row;
-        ca.off = off;
-        ca.conj_out = conj_out ? 1 : 0;
-        launch_fwd_combine(ca, (int)cnt, e->stream);
+        fa.tn = e->d_tn;
+        fa.out = out + base * item_stride;
+        fa.item_stride = item_stride;
+        fa.row = row;
+        fa.off = off;
+        fa.conj_out = conj_out ? 1 : 0;
+        if (bits) launch_fwd_bits(fa, (int)cnt, e->stream);
+        else launch_fwd_real(fa, (int)cnt, e->stream);
     }
     HIPCHK(hipGetLastError());
     return GPSACQ_OK;
@@ -140,8 +135,8 @@ extern "C" void gpsacq_destroy(gpsacq_engine* e) {
     if (!e) return;
     (void)hipSetDevice(e->p.device);
     if (e->stream) (void)hipStreamSynchronize(e->stream);
-    void* bufs[] = {e->d_t1, e->d_t2, e->d_bq, e->d_wq, e->d_cos, e->d_sin, e->d_code, e->d_patch_blocks, e->d_bits, e->d_iq, e->d_iqbits, e->d_sums,
-                    e->d_g, e->d_dpp, e->d_tasks, e->d_cells, e->d_peaks};
+    void* bufs[] = {e->d_t1, e->d_t2, e->d_bq, e->d_tn, e->d_cos, e->d_sin, e->d_code, e->d_patch_blocks, e->d_bits, e->d_iq, e->d_iqbits, e->d_sums,
+                    e->d_dpp, e->d_tasks, e->d_cells, e->d_peaks};
     for (void* b : bufs)
         if (b) (void)hipFree(b);
     for (auto& ev : e->ev)
@@ -208,13 +203,13 @@ extern "C" int gpsacq_create(const gpsacq_params* params, gpsacq_engine** out) {
     Tables T;
     HCK(hipMalloc((void**)&e->d_t1, T.t1.size() * sizeof(cf)));
     HCK(hipMalloc((void**)&e->d_t2, T.t2.size() * sizeof(cf)));
-    HCK(hipMalloc((void**)&e->d_wq, T.wq.size() * sizeof(cf)));
+    HCK(hipMalloc((void**)&e->d_tn, T.tn.size() * sizeof(cf)));
+    HCK(hipMemcpy(e->d_tn, T.tn.data(), T.tn.size() * sizeof(cf), hipMemcpyHostToDevice));
     HCK(upload_wq(T.wq.data()));
     HCK(hipMalloc((void**)&e->d_bq, T.bq.size() * sizeof(cf)));
     HCK(hipMemcpy(e->d_bq, T.bq.data(), T.bq.size() * sizeof(cf), hipMemcpyHostToDevice));
     HCK(hipMemcpy(e->d_t1, T.t1.data(), T.t1.size() * sizeof(cf), hipMemcpyHostToDevice));
     HCK(hipMemcpy(e->d_t2, T.t2.data(), T.t2.size() * sizeof(cf), hipMemcpyHostToDevice));
-    HCK(hipMemcpy(e->d_wq, T.wq.data(), T.wq.size() * sizeof(cf), hipMemcpyHostToDevice));
 
     std::vector<uint8_t> cosm(BLOCK_BYTES), sinm(BLOCK_BYTES);
     lo_masks(params->fc, params->fs, BLOCK_BYTES, cosm.data(), sinm.data());
@@ -233,9 +228,7 @@ extern "C" int gpsacq_create(const gpsacq_params* params, gpsacq_engine** out) {
     HCK(hipMalloc((void**)&e->d_code, GPSACQ_NUM_SATS * slot * sizeof(cf)));
     HCK(hipMemsetAsync(e->d_code, 0, GPSACQ_NUM_SATS * slot * sizeof(cf), e->stream));
     {
-        int rc = grow(e->d_g, e->g_cap, (size_t)GPSACQ_NUM_SATS, (size_t)NPOLY * M_SUB * sizeof(cf));
-        if (rc == GPSACQ_OK)
-            rc = run_forward(e, false, d_rep, N_FFT, GPSACQ_NUM_SATS, e->d_code, slot, e->crow, e->halo, false);
+        int rc = run_forward(e, false, d_rep, N_FFT, GPSACQ_NUM_SATS, e->d_code, slot, e->crow, e->halo, false);
         if (rc != GPSACQ_OK) {
             (void)hipFree(d_rep);
             gpsacq_destroy(e);
@@ -334,7 +327,6 @@ static int search_core(gpsacq_engine* e, const uint8_t* d_bits, size_t n_blocks,
     if (stride < (size_t)BLOCK_BYTES && e->p.ref_quirks) return fail(GPSACQ_ERR_ARG, "ref_quirks needs all 5120 bytes of a block (stride >= 5120)");
     if (stride < (size_t)USED_BYTES) return fail(GPSACQ_ERR_ARG, "stride %zu < 5000 bytes", stride);
     if (n_tasks * (size_t)e->ndop > 0x7fffff00u) return fail(GPSACQ_ERR_ARG, "batch too large: %zu tasks x %d bins", n_tasks, e->ndop);
-    if (int rc = grow(e->d_g, e->g_cap, std::min(n_blocks, kFwdChunk), (size_t)NPOLY * M_SUB * sizeof(cf))) return rc;
     if (int rc = grow(e->d_dpp, e->dpp_cap, n_blocks, (size_t)NPOLY * M_SUB * sizeof(cf))) return rc;
     if (!d_cells) {
         if (int rc = grow(e->d_cells, e->cell_cap, n_tasks * (size_t)e->ndop)) return rc;
@@ -352,7 +344,6 @@ static int search_core(gpsacq_engine* e, const uint8_t* d_bits, size_t n_blocks,
     ca.t1 = e->d_t1;
     ca.t2 = e->d_t2;
     ca.bq = e->d_bq;
-    ca.wq = e->d_wq;
     ca.cells = d_cells;
     ca.n_tasks = (int)n_tasks;
     ca.ndop = e->ndop;
@@ -531,7 +522,6 @@ extern "C" int gpsacq_sample_spectrum(gpsacq_engine* e, const uint8_t* block, fl
     if (!e || !block || !out) return fail(GPSACQ_ERR_ARG, "gpsacq_sample_spectrum: null argument");
     HIPCHK(hipSetDevice(e->p.device));
     if (int rc = grow(e->d_bits, e->bits_cap, (size_t)BLOCK_BYTES)) return rc;
-    if (int rc = grow(e->d_g, e->g_cap, (size_t)1, (size_t)NPOLY * M_SUB * sizeof(cf))) return rc;
     if (int rc = grow(e->d_dpp, e->dpp_cap, (size_t)1, (size_t)NPOLY * M_SUB * sizeof(cf))) return rc;
     HIPCHK(hipMemcpyAsync(e->d_bits, block, BLOCK_BYTES, hipMemcpyHostToDevice, e->stream));
     if (int rc = run_forward(e, true, e->d_bits, BLOCK_BYTES, 1, e->d_dpp, (size_t)NPOLY * M_SUB, M_SUB, 0, true)) return rc;

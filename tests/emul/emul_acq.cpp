@@ -17,24 +17,22 @@ static const Tables& tables() {
     return t;
 }
 
-// "kernel" fwd_sub: one workgroup = one (block, q)
+// "kernel" k_fwd: one workgroup = one (item, kappa) -> row kappa of the polyphase spectrum
 template <class Src>
-static void emul_fwd_sub(const Src& src, int q, cf* g_q /*[5000]*/) {
+static void emul_fwd_row(const Src& src, int kappa, bool conj_out, cf* row /*[5000]*/) {
     const Tables& T = tables();
     std::vector<cf> lds(M_SUB);
     std::vector<cf> regs((size_t)WG * RC);
-    for (int tid = 0; tid < WG; ++tid) fwd_phase1(tid, q, src, T.t1.data(), lds.data());
+    for (int tid = 0; tid < WG; ++tid) fwd_phase1(tid, kappa, src, T.tn.data(), T.t1.data(), lds.data());
     for (int tid = 0; tid < WG; ++tid) fwd_phase2(tid, T.t2.data(), lds.data());
     for (int tid = 0; tid < WG; ++tid) fwd_phase3_load(tid, lds.data(), &regs[(size_t)tid * RC]);
-    for (int tid = 0; tid < WG; ++tid) fwd_phase3_store(tid, q, T.bq.data(), T.wq.data(), &regs[(size_t)tid * RC], lds.data());
-    for (int i = 0; i < M_SUB; ++i) g_q[i] = lds[i];
+    for (int tid = 0; tid < WG; ++tid) fwd_phase3_store(tid, conj_out, &regs[(size_t)tid * RC], lds.data());
+    for (int i = 0; i < M_SUB; ++i) row[i] = lds[i];
 }
 
 template <class Src>
 static void emul_forward_pp(const Src& src, bool conj_out, cf* out, long row, int off) {
-    std::vector<cf> g((size_t)NPOLY * M_SUB);
-    for (int q = 0; q < NPOLY; ++q) emul_fwd_sub(src, q, &g[(size_t)q * M_SUB]);
-    for (int k1 = 0; k1 < M_SUB; ++k1) fwd_combine(k1, g.data(), conj_out, out, row, off);
+    for (int kappa = 0; kappa < NPOLY; ++kappa) emul_fwd_row(src, kappa, conj_out, out + kappa * row + off);
 }
 
 static void pp_to_natural(const cf* pp, long row, int off, bool conj, float* out) {
@@ -49,7 +47,9 @@ extern "C" {
 
 // Sample(): spectrum of one 5120-byte block in natural order (un-conjugated).
 void emul_forward_bits(const uint8_t* bytes, const uint8_t* cosm, const uint8_t* sinm, float* out) {
-    BitsSrc src{bytes, cosm, sinm};
+    std::vector<uint8_t> ib(USED_BYTES), qb(USED_BYTES);
+    for (int tid = 0; tid < WG; ++tid) fwd_stage_bits(tid, bytes, cosm, sinm, ib.data(), qb.data());
+    BitsSrc src{ib.data(), qb.data()};
     std::vector<cf> pp((size_t)NPOLY * M_SUB);
     emul_forward_pp(src, true, pp.data(), M_SUB, 0);
     pp_to_natural(pp.data(), M_SUB, 0, true, out);
