@@ -23,10 +23,10 @@ $(LIBDIR)/libgpsacq.so: $(CSRC)/acq_kernels.hip $(CSRC)/iq_kernels.hip $(CSRC)/g
 
 host: $(LIBDIR)/libgps_search.so $(BINDIR)/gps_test
 $(LIBDIR)/libgps_search.so: $(HOST)/search_api.cpp include/gps_search.h include/gpsacq.h $(LIBDIR)/libgpsacq.so
-	$(CXX) $(HOSTFLAGS) -shared -o $@ $(HOST)/search_api.cpp -L$(LIBDIR) -lgpsacq -Wl,-rpath,'$$ORIGIN'
+	$(CXX) $(HOSTFLAGS) -pthread -shared -o $@ $(HOST)/search_api.cpp -L$(LIBDIR) -lgpsacq -Wl,-rpath,'$$ORIGIN'
 $(BINDIR)/gps_test: $(HOST)/gps_test.cpp include/gps_search.h $(LIBDIR)/libgps_search.so
 	@mkdir -p $(BINDIR)
-	$(CXX) $(HOSTFLAGS) -o $@ $(HOST)/gps_test.cpp -L$(LIBDIR) -lgps_search -lgpsacq -Wl,-rpath,'$$ORIGIN/../lib'
+	$(CXX) $(HOSTFLAGS) -pthread -o $@ $(HOST)/gps_test.cpp -L$(LIBDIR) -lgps_search -lgpsacq -Wl,-rpath,'$$ORIGIN/../lib'
 
 oracle:
 	$(MAKE) -C oracle

@@ -137,3 +137,45 @@ def test_config4_weak_signal_rtl_path(golden_dir):
         np.testing.assert_allclose(got["max_pwr"], want["max_pwr"], rtol=2e-5)
         np.testing.assert_allclose(got["tot_pwr"], want["tot_pwr"], rtol=2e-5)
         assert (got["max_i"] != want["max_i"]).sum() <= 1
+
+
+@pytest.mark.parametrize("fc,fs,max_fo", [(2.6e6, 10e6, 5000.0), (1.023e6, 4.092e6, 3000.0), (3.5e6, 9.9987e6, 5000.0),
+                                          (0.0, 1.1e6, 1000.0)])
+def test_other_sampling_rates(fc, fs, max_fo):
+    """Every kernel instance (12/22/33/40 accumulator columns), lag counts that are not multiples of
+    250 or of 8, a zero IF: cells against the oracle on a seeded noise + signal capture."""
+    import gpsacq
+    from oracle_lib import Oracle
+    rng = np.random.default_rng(int(fs) % 1000 + 17)
+    ns = 3 * 40960
+    m = np.arange(ns, dtype=np.float64)
+    chips = np.where(rng.integers(0, 2, 1023) == 1, -1.0, 1.0)  # any +-1 sequence will do as interference
+    y = rng.standard_normal(ns) + 0.2 * chips[np.floor(m * 1.023e6 / fs).astype(np.int64) % 1023] * np.cos(2 * np.pi * (fc + 700.0) / fs * m)
+    bits = np.packbits((y < 0).astype(np.uint8), bitorder="little").tobytes()
+    orc = Oracle(fc, fs, max_fo)
+    with gpsacq.Engine(fc, fs, max_fo) as eng:
+        assert eng.dmax == orc.dmax and eng.num_lags == orc.num_lags
+        tasks = [(0, 0), (1, 17), (2, 31)]
+        cells, peaks = eng.search(bits, tasks=tasks)
+        ocells, opeaks = orc.search(bits, tasks)
+        np.testing.assert_allclose(cells["max_pwr"], ocells["max_pwr"], rtol=2e-5)
+        np.testing.assert_allclose(cells["tot_pwr"], ocells["tot_pwr"], rtol=2e-5)
+        assert (cells["max_i"] != ocells["max_i"]).mean() < 0.01
+        assert np.array_equal(peaks["lo_shift"], opeaks["lo_shift"]) and np.array_equal(peaks["ca_shift"], opeaks["ca_shift"])
+
+
+def test_cli_multi_engine_threads(golden_dir):
+    """GPSACQ_DEVICES splits each batch of runs over one host thread + engine per listed device.  With
+    one GPU the list '0,0,0' exercises exactly that code path; stdout must not change."""
+    import subprocess
+    from test_host import GPS_TEST
+    path = os.path.join(golden_dir, "gps_sig_tmp.bin")
+    base = dict(os.environ, GPSACQ_BATCH_RUNS="2")
+    one = subprocess.run([GPS_TEST, path, "2.046e6", "8.184e6", "5000"], capture_output=True, text=True, env=base, timeout=300)
+    many = subprocess.run([GPS_TEST, path, "2.046e6", "8.184e6", "5000"], capture_output=True, text=True,
+                          env=dict(base, GPSACQ_DEVICES="0,0,0"), timeout=300)
+    assert one.returncode == 0 and many.returncode == 0, many.stderr
+    assert one.stdout == many.stdout and one.stdout.count("satellite:") == 12
+    bad = subprocess.run([GPS_TEST, path, "2.046e6", "8.184e6", "5000"], capture_output=True, text=True,
+                         env=dict(base, GPSACQ_DEVICES="0,99"), timeout=300)
+    assert bad.returncode == 1 and "SearchInit() returned 1" in bad.stdout
