@@ -80,7 +80,7 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=2)
-    ap.add_argument("--blocks", type=int, default=2048, help="5120-byte blocks per GPU per step (64 runs)")
+    ap.add_argument("--blocks", type=int, default=4096, help="5120-byte blocks per GPU per step (128 runs)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--mode", choices=["blocks", "grid"], default="blocks",
                     help="blocks (default, the metric's config): reference schedule, blocks sharded over ranks, weak scaling. "
