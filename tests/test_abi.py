@@ -101,3 +101,30 @@ def test_handoff_matches_channel_start():
     pk = np.zeros(1, gpsacq.PEAK_DTYPE)[0]
     pk["lo_shift"], pk["ca_shift"] = 3, 1234
     assert gpsacq.handoff(pk, 2.6e6, 10e6)["ca_pause"] == (20000 - 1234) % 10000
+
+
+def _build_c_client(tmp_path):
+    exe = str(tmp_path / "abi_smoke")
+    libdir = os.path.join(ROOT, "gnss-gps-sdr_amd", "lib")
+    subprocess.check_call(["gcc", "-std=c99", "-Wall", "-Werror", "-pedantic", "-I", os.path.join(ROOT, "include"),
+                           os.path.join(ROOT, "tests", "c", "abi_smoke.c"), "-o", exe, "-L", libdir, "-lgpsacq",
+                           "-Wl,-rpath," + libdir])
+    return exe
+
+
+def test_c99_client_compiles_and_fails_loudly_without_gpu(tmp_path):
+    """include/gpsacq.h is valid C99 (-pedantic -Werror) and a plain C program links against the library."""
+    import torch
+    exe = _build_c_client(tmp_path)
+    if torch.cuda.is_available():
+        pytest.skip("GPU present: covered by the gpu-marked test")
+    r = subprocess.run([exe, os.path.join(ROOT, "tests", "golden", "gps_sig_tmp.bin"), "2.046e6", "8.184e6"], capture_output=True, text=True)
+    assert r.returncode == 2 and "no CPU path" in r.stderr
+
+
+@pytest.mark.gpu
+def test_c99_client_on_gpu(tmp_path):
+    exe = _build_c_client(tmp_path)
+    r = subprocess.run([exe, os.path.join(ROOT, "tests", "golden", "gps_sig_tmp.bin"), "2.046e6", "8.184e6"], capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr
+    assert r.stdout.startswith("bins 49 lags 8184 best sv 7 snr 713.6 lo_shift 0 ca_shift 260 doppler 0.0 Hz")
