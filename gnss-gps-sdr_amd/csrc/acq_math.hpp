@@ -1,12 +1,13 @@
 // acq_math.hpp -- butterfly math and index maps of the gfx950 acquisition kernels.
 //
 // The length-40000 transforms of the reference (fftwf_execute at c/search_offline.cpp:161,187)
-// are computed here as 8 polyphase sub-transforms of length M = 5000 = 10 x 25 x 20 that live
-// entirely in one workgroup's LDS (40 KB), combined by a radix-8 step:
+// are computed here as 8 sub-transforms of length M = 5000 = 10 x 25 x 20 that live entirely in
+// one workgroup's LDS (40 KB), plus one radix-8 step (decimation in time for the inverse, whose
+// outputs are pruned; decimation in frequency for the forward, whose output rows are independent):
 //
 //   inverse (Correlate, :187)  y[n] = sum_{q<8} W_N^{-q n} F_q[n mod 5000],
 //                              F_q  = IDFT_5000( prod[8 j + q] ),  only n < FS/1000 is formed
-//   forward (Sample, :161)     X[k1 + 5000 s] = sum_{q<8} W_8^{q s} ( W_N^{q k1} F_q[k1] )
+//   forward (Sample, :161)     X[8 k' + kappa] = DFT_5000( W_N^{n' kappa} sum_{nu<8} x[n' + 5000 nu] W_8^{nu kappa} )[k']
 //
 // Each length-5000 transform is three in-place LDS passes (decimation in frequency):
 //   pass 1  radix-10 (Good-Thomas 2x5) on elements j' + 500 a,      twiddle W_5000^{j' alpha}
