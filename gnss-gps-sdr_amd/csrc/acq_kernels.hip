@@ -129,7 +129,7 @@ __global__ __launch_bounds__(WG, WPS) void k_corr(CorrArgs a) {
             const cf b = a.bq[q * NBF3 + t3];  // per-thread rotation of this sub-transform
             cf wqv[MC];                        // wave-uniform rotations: scalar loads, SGPR operands
 #pragma unroll
-            for (int m = 0; m < MC; ++m) wqv[m] = c_wq[q * WQ_STRIDE + m];
+            for (int m = 0; m < MC; ++m) wqv[m] = c_wq[q * WQ_STRIDE + a.m0 + m];
             corr_phase1<NB>(tid, q, dop, dk, cpp, a.crow, a.halo, w1, lds);
             __syncthreads();  // also orders the t2s fill before its first use
             corr_phase2(tid, t2s, lds);
@@ -148,8 +148,8 @@ __global__ __launch_bounds__(WG, WPS) void k_corr(CorrArgs a) {
 
     float mx, sum;
     int mi;
-    if (NC) corr_scan_power<MC>(tid, a.nlags, pw, mx, mi, sum);
-    else corr_scan<MC>(tid, a.nlags, acc, mx, mi, sum);
+    if (NC) corr_scan_power<MC>(tid, a.nlags, a.m0, pw, mx, mi, sum);
+    else corr_scan<MC>(tid, a.nlags, a.m0, acc, mx, mi, sum);
     // wave reduction (64 lanes), then across the 4 waves through LDS
 #pragma unroll
     for (int off = 32; off > 0; off >>= 1) {
@@ -180,6 +180,22 @@ __global__ __launch_bounds__(WG, WPS) void k_corr(CorrArgs a) {
         c.snr = (sum > 0.f) ? mx / ave : 0.f;    // :196; 0/0 of the reference defined as 0
         a.cells[(size_t)task * a.ndop + di] = c;
     }
+}
+
+// More than 10000 lags (fs > 10 MHz) take several k_corr passes of 40 columns each; this folds the
+// partial cells (ascending lag ranges, so strict '>' keeps the first maximum) and sets the SNR.
+__global__ void k_merge_cells(const Cell* parts, Cell* cells, size_t n_cells, int n_parts, int nlags) {
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n_cells) return;
+    Cell c = parts[i];
+    for (int p = 1; p < n_parts; ++p) {
+        const Cell o = parts[(size_t)p * n_cells + i];
+        if (o.max_pwr > c.max_pwr) { c.max_pwr = o.max_pwr; c.max_i = o.max_i; }
+        c.tot_pwr += o.tot_pwr;
+    }
+    const float ave = c.tot_pwr / (float)nlags;
+    c.snr = (c.tot_pwr > 0.f) ? c.max_pwr / ave : 0.f;
+    cells[i] = c;
 }
 
 // Best SNR over the Doppler bins of each task, ascending dop, strict '>' (:196-198).
@@ -222,7 +238,7 @@ int corr_columns(int nlags) {  // accumulator columns of the smallest instance t
     const int have[] = {12, 22, 33, 40};
     for (int m : have)
         if (need <= m) return m;
-    return -1;
+    return MC_MAX;  // several passes of 40 columns
 }
 int launch_corr(const CorrArgs& a, int mc, hipStream_t s) {
     const int groups = (a.n_tasks + 7) / 8;
@@ -251,6 +267,9 @@ int launch_corr(const CorrArgs& a, int mc, hipStream_t s) {
         default: return -1;
     }
     return 0;
+}
+void launch_merge_cells(const Cell* parts, Cell* cells, size_t n_cells, int n_parts, int nlags, hipStream_t s) {
+    hipLaunchKernelGGL(k_merge_cells, dim3((unsigned)((n_cells + 255) / 256)), dim3(256), 0, s, parts, cells, n_cells, n_parts, nlags);
 }
 void launch_peaks(const Cell* cells, Peak* peaks, int n_tasks, int ndop, int dop_first, hipStream_t s) {
     hipLaunchKernelGGL(k_peaks, dim3((n_tasks + 255) / 256), dim3(256), 0, s, cells, peaks, n_tasks, ndop, dop_first);

@@ -40,6 +40,7 @@ struct CorrArgs {
     const cf* bq;
     Cell* cells;       // [n_tasks][ndop]
     int n_tasks, ndop, dop_first, nlags, crow, halo;  // bins dop_first .. dop_first+ndop-1
+    int m0;               // first accumulator column of this pass (multiple of 40; 0 unless fs > 10 MHz)
     int n_acc, acc_step;  // non-coherent mode: spectra tk.spec + k*acc_step, k < n_acc (n_acc = 1: coherent)
 };
 
@@ -50,6 +51,7 @@ void launch_quirk_patch(const QuirkArgs& a, int n_patch, hipStream_t s);
 int corr_columns(int nlags);
 hipError_t upload_wq(const cf* host);  // fills the __constant__ copy of wq on the current device
 int launch_corr(const CorrArgs& a, int mc, hipStream_t s);
+void launch_merge_cells(const Cell* parts, Cell* cells, size_t n_cells, int n_parts, int nlags, hipStream_t s);
 void launch_peaks(const Cell* cells, Peak* peaks, int n_tasks, int ndop, int dop_first, hipStream_t s);
 
 }  // namespace acq

@@ -49,8 +49,8 @@ constexpr int NBF2 = M_SUB / RB;  // 200 pass-2 butterflies
 constexpr int NBF3 = M_SUB / RC;  // 250 pass-3 butterflies (also the output column height)
 constexpr int NW160 = N_FFT / NBF3;  // 160
 constexpr int NT2 = RB * RC;         // 500 pass-2 twiddles
-constexpr int MC_MAX = 40;           // accumulator columns supported: lags n < 250 * MC_MAX (fs <= 10 MHz)
-constexpr int WQ_STRIDE = MC_MAX;    // wq[q][m] = W_160^{q m}
+constexpr int MC_MAX = 40;           // accumulator columns per pass: 10000 lags; more lags take more passes
+constexpr int WQ_STRIDE = NW160;     // wq[q][m] = W_160^{q m}, all 160 columns (40000 lags)
 
 typedef float cf __attribute__((ext_vector_type(2)));  // (re, im); one 64-bit VGPR pair on the device
 

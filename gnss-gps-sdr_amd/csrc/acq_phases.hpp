@@ -94,7 +94,8 @@ ACQ_HD void corr_phase2(int tid, const cf* t2, cf* lds) {
     if (tid < NBF2) pass2_inplace<+1>(tid, t2, lds);
 }
 
-// acc[m] accumulates y[n] for n = 250 m + rho over the 8 polyphase components:
+// acc[m] accumulates y[n] for n = 250 (m0 + m) + rho over the 8 polyphase components (m0, the first
+// column of this pass, is a multiple of 20 so that column m0 + m reads radix-20 output m % 20):
 // W_N^{-q n} = conj(b) (per thread, b = bq[q][tid]) * conj(wqv[m]) (wave-uniform, wqv[m] = W_160^{q m}).
 template <int MC>
 ACQ_HD void corr_phase3(int tid, cf b, const cf* wqv, const cf* lds, cf* acc) {
@@ -109,7 +110,7 @@ ACQ_HD void corr_phase3(int tid, cf b, const cf* wqv, const cf* lds, cf* acc) {
 
 // Peak scan over the first S lags (:190-194), this thread's share, ascending n.
 template <int MC>
-ACQ_HD void corr_scan(int tid, int S, const cf* acc, float& mx, int& mi, float& sum) {
+ACQ_HD void corr_scan(int tid, int S, int m0, const cf* acc, float& mx, int& mi, float& sum) {
     mx = 0.f;
     mi = 0;
     sum = 0.f;
@@ -117,7 +118,7 @@ ACQ_HD void corr_scan(int tid, int S, const cf* acc, float& mx, int& mi, float& 
     const int rho = pass3_rho(tid);
 #pragma unroll
     for (int m = 0; m < MC; ++m) {  // branch-free: lags beyond S contribute a power of 0
-        const int n = NBF3 * m + rho;
+        const int n = NBF3 * (m0 + m) + rho;
         const float p = (n < S) ? acc[m].x * acc[m].x + acc[m].y * acc[m].y : 0.f;
         const bool up = p > mx;
         mx = up ? p : mx;
@@ -127,7 +128,7 @@ ACQ_HD void corr_scan(int tid, int S, const cf* acc, float& mx, int& mi, float& 
 }
 // same scan over summed powers (non-coherent mode)
 template <int MC>
-ACQ_HD void corr_scan_power(int tid, int S, const float* pw, float& mx, int& mi, float& sum) {
+ACQ_HD void corr_scan_power(int tid, int S, int m0, const float* pw, float& mx, int& mi, float& sum) {
     mx = 0.f;
     mi = 0;
     sum = 0.f;
@@ -135,7 +136,7 @@ ACQ_HD void corr_scan_power(int tid, int S, const float* pw, float& mx, int& mi,
     const int rho = pass3_rho(tid);
 #pragma unroll
     for (int m = 0; m < MC; ++m) {
-        const int n = NBF3 * m + rho;
+        const int n = NBF3 * (m0 + m) + rho;
         const float p = (n < S) ? pw[m] : 0.f;
         const bool up = p > mx;
         mx = up ? p : mx;

@@ -60,8 +60,9 @@ struct gpsacq_engine {
     size_t dpp_cap = 0;  // in blocks
     Task* d_tasks = nullptr;
     Cell* d_cells = nullptr;
+    Cell* d_parts = nullptr;  // partial cells of multi-pass searches (more than 10000 lags)
     Peak* d_peaks = nullptr;
-    size_t task_cap = 0, cell_cap = 0, peak_cap = 0;
+    size_t task_cap = 0, cell_cap = 0, peak_cap = 0, parts_cap = 0;
     // 8-bit IQ ingestion scratch
     uint8_t* d_iq = nullptr;
     size_t iq_cap = 0;
@@ -136,7 +137,7 @@ extern "C" void gpsacq_destroy(gpsacq_engine* e) {
     (void)hipSetDevice(e->p.device);
     if (e->stream) (void)hipStreamSynchronize(e->stream);
     void* bufs[] = {e->d_t1, e->d_t2, e->d_bq, e->d_tn, e->d_cos, e->d_sin, e->d_code, e->d_patch_blocks, e->d_bits, e->d_iq, e->d_iqbits, e->d_sums,
-                    e->d_dpp, e->d_tasks, e->d_cells, e->d_peaks};
+                    e->d_dpp, e->d_parts, e->d_tasks, e->d_cells, e->d_peaks};
     for (void* b : bufs)
         if (b) (void)hipFree(b);
     for (auto& ev : e->ev)
@@ -153,9 +154,6 @@ extern "C" int gpsacq_create(const gpsacq_params* params, gpsacq_engine** out) {
     const int dmax = doppler_half_range(params->fs, params->max_fo);
     const int nlags = num_lags(params->fs);
     const int mc = corr_columns(nlags);
-    if (mc < 0)
-        return fail(GPSACQ_ERR_UNSUPPORTED, "fs = %g Hz scans %d lags; the kernels cover at most %d (fs <= 10 MHz)", params->fs,
-                    nlags, NBF3 * MC_MAX);
     if (dmax >= N_FFT / 2) return fail(GPSACQ_ERR_UNSUPPORTED, "max_fo = %g Hz exceeds half the sampling rate", params->max_fo);
 
     int ndev = 0;
@@ -353,14 +351,28 @@ static int search_core(gpsacq_engine* e, const uint8_t* d_bits, size_t n_blocks,
     ca.halo = e->halo;
     ca.n_acc = e->n_acc;
     ca.acc_step = e->acc_step;
-    if (launch_corr(ca, e->mc, e->stream) != 0) return fail(GPSACQ_ERR_UNSUPPORTED, "no correlate kernel for %d columns", e->mc);
+    const int n_cols = (e->nlags + NBF3 - 1) / NBF3;
+    const int n_pass = (n_cols + MC_MAX - 1) / MC_MAX;  // 1 up to 10000 lags (fs <= 10 MHz)
+    if (n_pass == 1) {
+        ca.m0 = 0;
+        if (launch_corr(ca, e->mc, e->stream) != 0) return fail(GPSACQ_ERR_UNSUPPORTED, "no correlate kernel for %d columns", e->mc);
+    } else {
+        const size_t n_cells = n_tasks * (size_t)e->ndop;
+        if (int rc = grow(e->d_parts, e->parts_cap, n_cells * (size_t)n_pass)) return rc;
+        for (int p = 0; p < n_pass; ++p) {
+            ca.m0 = p * MC_MAX;
+            ca.cells = e->d_parts + (size_t)p * n_cells;
+            if (launch_corr(ca, MC_MAX, e->stream) != 0) return fail(GPSACQ_ERR_UNSUPPORTED, "no correlate kernel for %d columns", MC_MAX);
+        }
+        launch_merge_cells(e->d_parts, d_cells, n_cells, n_pass, e->nlags, e->stream);
+    }
     HIPCHK(hipGetLastError());
     HIPCHK(hipEventRecord(e->ev[2], e->stream));
     launch_peaks(d_cells, d_peaks, (int)n_tasks, e->ndop, e->dop_first, e->stream);
     HIPCHK(hipGetLastError());
     HIPCHK(hipEventRecord(e->ev[3], e->stream));
     e->timing_valid = true;
-    e->corr_launches = 1;
+    e->corr_launches = n_pass;
     e->cells_done = (int64_t)n_tasks * e->ndop;
     return GPSACQ_OK;
 }

@@ -44,7 +44,7 @@ extern "C" {
 #define GPSACQ_OK 0
 #define GPSACQ_ERR_ARG 1          /* bad argument */
 #define GPSACQ_ERR_DEVICE 2       /* no usable gfx950 device / HIP runtime error */
-#define GPSACQ_ERR_UNSUPPORTED 3  /* parameter outside what the kernels cover */
+#define GPSACQ_ERR_UNSUPPORTED 3  /* parameter outside what the kernels cover: max_fo >= fs/2, ref_quirks + non-coherent */
 #define GPSACQ_ERR_NOMEM 4
 
 typedef struct gpsacq_engine gpsacq_engine;

@@ -105,10 +105,10 @@ int emul_cell(const float* dspec, const float* cspec, int halo, int dop, int S, 
         int tmi;
         const cf* a = &acc[(size_t)tid * MC_MAX];
         switch (mc) {
-            case 12: corr_scan<12>(tid, S, a, tmx, tmi, tsum); break;
-            case 22: corr_scan<22>(tid, S, a, tmx, tmi, tsum); break;
-            case 33: corr_scan<33>(tid, S, a, tmx, tmi, tsum); break;
-            default: corr_scan<40>(tid, S, a, tmx, tmi, tsum); break;
+            case 12: corr_scan<12>(tid, S, 0, a, tmx, tmi, tsum); break;
+            case 22: corr_scan<22>(tid, S, 0, a, tmx, tmi, tsum); break;
+            case 33: corr_scan<33>(tid, S, 0, a, tmx, tmi, tsum); break;
+            default: corr_scan<40>(tid, S, 0, a, tmx, tmi, tsum); break;
         }
         peak_merge(mx, mi, tmx, tmi);
         sum += tsum;

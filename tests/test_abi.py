@@ -49,7 +49,7 @@ def test_argument_errors_before_device():
         gpsacq.Engine(1e6, 0.0)
     assert ei.value.code == 1
     with pytest.raises(gpsacq.GpsAcqError) as ei:
-        gpsacq.Engine(1e6, 20e6)  # 20000 lags > 10000 supported
+        gpsacq.Engine(1e6, 5e6, 3e6)  # Doppler range beyond half the sampling rate
     assert ei.value.code == 3
 
 

@@ -140,10 +140,11 @@ def test_config4_weak_signal_rtl_path(golden_dir):
 
 
 @pytest.mark.parametrize("fc,fs,max_fo", [(2.6e6, 10e6, 5000.0), (1.023e6, 4.092e6, 3000.0), (3.5e6, 9.9987e6, 5000.0),
-                                          (0.0, 1.1e6, 1000.0)])
+                                          (0.0, 1.1e6, 1000.0), (4.092e6, 16.368e6, 4000.0), (9.5e6, 38.192e6, 2000.0)])
 def test_other_sampling_rates(fc, fs, max_fo):
     """Every kernel instance (12/22/33/40 accumulator columns), lag counts that are not multiples of
-    250 or of 8, a zero IF: cells against the oracle on a seeded noise + signal capture."""
+    250 or of 8, a zero IF, and more than 10000 lags (fs > 10 MHz: 2 and 4 passes of 40 columns plus
+    the merge kernel): cells against the oracle on a seeded noise + signal capture."""
     import gpsacq
     from oracle_lib import Oracle
     rng = np.random.default_rng(int(fs) % 1000 + 17)
