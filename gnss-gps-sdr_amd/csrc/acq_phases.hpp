@@ -9,7 +9,6 @@
 //   code     "cpp"  [8][5000 + 2H]   FFT(code replica)[8 j + q] at [q][H + j], with a cyclic halo of
 //                                    H entries on both sides so that the whole-bin Doppler
 //                                    shift (:182) is a plain pointer offset
-//   scratch  "g"    [8][5000]        W_N^{q k1} F_q[k1], input of the radix-8 combine
 //
 // The vector-memory pipe, not the VALU, was the first limiter of the correlator (ablation in
 // DESIGN.md): every global access here is therefore a 16-byte access of two neighbouring

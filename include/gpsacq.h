@@ -47,6 +47,9 @@ extern "C" {
 #define GPSACQ_ERR_UNSUPPORTED 3  /* parameter outside what the kernels cover: max_fo >= fs/2, ref_quirks + non-coherent */
 #define GPSACQ_ERR_NOMEM 4
 
+/* One engine = one device + one HIP stream + its scratch.  An engine is NOT thread-safe (the
+ * reference's search stage is a single-instance, non-reentrant module as well, c/search_offline.cpp:55-64):
+ * use one engine per host thread / per GPU.  gpsacq_last_error() is per thread. */
 typedef struct gpsacq_engine gpsacq_engine;
 
 typedef struct {
