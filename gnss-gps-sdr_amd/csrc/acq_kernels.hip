@@ -32,12 +32,14 @@ hipError_t upload_wq(const cf* host) { return hipMemcpyToSymbol(HIP_SYMBOL(c_wq)
 template <bool BITS>
 __global__ __launch_bounds__(WG) void k_fwd(FwdArgs a) {
     __shared__ cf lds[M_SUB];
-    __shared__ uint8_t ibits[BITS ? USED_BYTES + 8 : 8], qbits[BITS ? USED_BYTES + 8 : 8];
+    __shared__ uint64_t ib[BITS ? USED_BYTES / NPOLY : 1], qb[BITS ? USED_BYTES / NPOLY : 1];
+    __shared__ cf lut[BITS ? 256 : 1];
     const int tid = threadIdx.x, kappa = blockIdx.x, item = blockIdx.y;
     if (BITS) {
-        fwd_stage_bits(tid, (const uint8_t*)a.src + (size_t)item * a.src_stride, a.cos_mask, a.sin_mask, ibits, qbits);
+        fwd_build_lut(tid, kappa, lut);
+        fwd_stage_bits(tid, (const uint8_t*)a.src + (size_t)item * a.src_stride, a.cos_t, a.sin_t, ib, qb);
         __syncthreads();
-        fwd_phase1(tid, kappa, BitsSrc{ibits, qbits}, a.tn, a.t1, lds);
+        fwd_phase1(tid, kappa, BitsSrc{reinterpret_cast<const uint8_t*>(ib), reinterpret_cast<const uint8_t*>(qb), lut}, a.tn, a.t1, lds);
     } else {
         fwd_phase1(tid, kappa, RealSrc{(const float*)a.src + (size_t)item * a.src_stride}, a.tn, a.t1, lds);
     }

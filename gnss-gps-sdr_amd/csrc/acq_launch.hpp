@@ -10,8 +10,8 @@ namespace acq {
 struct FwdArgs {
     const void* src;     // bits: packed capture bytes; real: float replicas
     size_t src_stride;   // per item: bytes (bits) or floats (real)
-    const uint8_t* cos_mask;
-    const uint8_t* sin_mask;
+    const uint64_t* cos_t;  // [625] bit-transposed LO masks (bits source only)
+    const uint64_t* sin_t;
     const cf* t1;
     const cf* t2;
     const cf* tn;

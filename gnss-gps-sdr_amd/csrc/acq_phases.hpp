@@ -160,31 +160,52 @@ ACQ_HD float pm1(unsigned bit) {  // 0 -> +1.0f, 1 -> -1.0f   (Bipolar(), :68-70
     v.u = 0x3f800000u | (bit << 31);
     return v.f;
 }
-struct BitsSrc {            // 1-bit unpack + XOR quadrature mix (:143-153)
-    const uint8_t* ibits;   // [5000] capture bytes ^ cos mask  (workgroup-local copy)
-    const uint8_t* qbits;   // [5000] capture bytes ^ sin mask
-    ACQ_HD void gather(int np, cf* x) const {  // x[nu] = sample n' + 5000 nu
-        const int byte = np >> 3, sh = np & 7;
-#pragma unroll
-        for (int nu = 0; nu < NPOLY; ++nu)
-            x[nu] = mk(pm1((ibits[byte + 625 * nu] >> sh) & 1u), pm1((qbits[byte + 625 * nu] >> sh) & 1u));
-    }
+// 8 x 8 bit-matrix transpose of a 64-bit word, LSB first: bit nu of output byte k = bit k of input byte nu
+ACQ_HD uint64_t transpose8x8(uint64_t x) {
+    uint64_t t;
+    t = (x ^ (x >> 7)) & 0x00AA00AA00AA00AAull;  x = x ^ t ^ (t << 7);
+    t = (x ^ (x >> 14)) & 0x0000CCCC0000CCCCull; x = x ^ t ^ (t << 14);
+    t = (x ^ (x >> 28)) & 0x00000000F0F0F0F0ull; x = x ^ t ^ (t << 28);
+    return x;
+}
+
+// 1-bit input (Sample(), :143-153).  Once per workgroup the block is bit-transposed so that byte n'
+// holds the eight samples n' + 5000 nu (nu = bit number), with the quadrature-LO masks XOR-ed in
+// (transposing commutes with XOR, so the masks are transposed once on the host), and a 256-entry
+// table lut[b] = sum_nu (+-1 by bit nu of b) W_8^{nu kappa} is built.  The radix-8 partial sum of a
+// term is then two table look-ups: lut[I byte] + i lut[Q byte].
+struct BitsSrc {
+    const uint8_t* ib;   // [5000] transposed (capture ^ cos mask)   (workgroup-local)
+    const uint8_t* qb;   // [5000] transposed (capture ^ sin mask)
+    const cf* lut;       // [256]
+    ACQ_HD cf partial(int np, cf, cf, cf) const { return add_i(lut[ib[np]], lut[qb[np]]); }
 };
-struct RealSrc {            // real code replica, imag = 0 (:101-102)
-    const float* x;         // [40000]
-    ACQ_HD void gather(int np, cf* v) const {
+// real code replica, imag = 0 (SearchInit(), :101-102): init-time only, plain pruned radix-8
+struct RealSrc {
+    const float* x;      // [40000]
+    ACQ_HD cf partial(int np, cf c4, cf c2, cf c1) const {
+        cf v[NPOLY];
 #pragma unroll
         for (int nu = 0; nu < NPOLY; ++nu) v[nu] = mk(x[np + M_SUB * nu], 0.f);
+        return dft8_one(v, c4, c2, c1);
     }
 };
 
-// workgroup-local copy of one block's bytes with the LO masks applied (thread tid's share)
-ACQ_HD void fwd_stage_bits(int tid, const uint8_t* __restrict__ bytes, const uint8_t* __restrict__ cos_mask,
-                           const uint8_t* __restrict__ sin_mask, uint8_t* ibits, uint8_t* qbits) {
-    for (int i = tid; i < USED_BYTES; i += WG) {
-        const uint8_t b = bytes[i];
-        ibits[i] = b ^ cos_mask[i];
-        qbits[i] = b ^ sin_mask[i];
+ACQ_HD void fwd_build_lut(int tid, int kappa, cf* lut) {  // thread tid computes entry tid (WG = 256)
+    cf s = mk(0.f, 0.f);
+#pragma unroll
+    for (int nu = 0; nu < NPOLY; ++nu) s = s + pm1(((unsigned)tid >> nu) & 1u) * w8(nu * kappa);
+    lut[tid] = s;
+}
+ACQ_HD void fwd_stage_bits(int tid, const uint8_t* __restrict__ bytes, const uint64_t* __restrict__ cos_t,
+                           const uint64_t* __restrict__ sin_t, uint64_t* ib, uint64_t* qb) {
+    for (int B = tid; B < USED_BYTES / NPOLY; B += WG) {
+        uint64_t x = 0;
+#pragma unroll
+        for (int nu = 0; nu < NPOLY; ++nu) x |= (uint64_t)bytes[B + (USED_BYTES / NPOLY) * nu] << (8 * nu);
+        x = transpose8x8(x);
+        ib[B] = x ^ cos_t[B];
+        qb[B] = x ^ sin_t[B];
     }
 }
 
@@ -198,12 +219,10 @@ ACQ_HD void fwd_phase1(int tid, int kappa, const Src& src, const cf* __restrict_
     cf x0[RA], x1[RA];
 #pragma unroll
     for (int a = 0; a < RA; ++a) {
-        cf g[NPOLY], tw0, tw1;
+        cf tw0, tw1;
         ld2(tk + NBF1 * a, tw0, tw1);
-        src.gather(2 * tid + NBF1 * a, g);
-        x0[a] = cmul(dft8_one(g, c4, c2, c1), tw0);
-        src.gather(2 * tid + 1 + NBF1 * a, g);
-        x1[a] = cmul(dft8_one(g, c4, c2, c1), tw1);
+        x0[a] = cmul(src.partial(2 * tid + NBF1 * a, c4, c2, c1), tw0);
+        x1[a] = cmul(src.partial(2 * tid + 1 + NBF1 * a, c4, c2, c1), tw1);
     }
     pass1_store<-1>(x0, 2 * tid, w[0], lds);
     pass1_store<-1>(x1, 2 * tid + 1, w[1], lds);

@@ -117,6 +117,20 @@ inline void lo_masks(double fc, double fs, int nbytes, uint8_t* cos_mask, uint8_
     }
 }
 
+// The same masks bit-transposed for the forward kernel: byte n' of word B = n' / 8 holds, at bit nu,
+// the mask bit of sample n' + 5000 nu (see acq_phases.hpp, fwd_stage_bits).
+inline void transpose_masks(const uint8_t* mask /* >= 5000 bytes */, uint64_t* out /* [625] */) {
+    for (int B = 0; B < 625; ++B) {
+        uint64_t x = 0;
+        for (int nu = 0; nu < 8; ++nu) x |= (uint64_t)mask[B + 625 * nu] << (8 * nu);
+        uint64_t t;
+        t = (x ^ (x >> 7)) & 0x00AA00AA00AA00AAull;  x = x ^ t ^ (t << 7);
+        t = (x ^ (x >> 14)) & 0x0000CCCC0000CCCCull; x = x ^ t ^ (t << 14);
+        t = (x ^ (x >> 28)) & 0x00000000F0F0F0F0ull; x = x ^ t ^ (t << 28);
+        out[B] = x;
+    }
+}
+
 // Search grid of Correlate(): Doppler half-range in bins (:176) and lags scanned (:190).
 inline int doppler_half_range(double fs, double max_fo) { return (int)(max_fo * (double)N_FFT / fs); }
 inline int num_lags(double fs) {

@@ -50,6 +50,7 @@ struct gpsacq_engine {
     // constants
     cf *d_t1 = nullptr, *d_t2 = nullptr, *d_bq = nullptr, *d_tn = nullptr;
     uint8_t *d_cos = nullptr, *d_sin = nullptr;
+    uint64_t *d_cos_t = nullptr, *d_sin_t = nullptr;  // bit-transposed masks for k_fwd
     cf* d_code = nullptr;  // [32 + patch_cap][8][crow]
     size_t patch_cap = 0;
     int32_t* d_patch_blocks = nullptr;
@@ -113,8 +114,8 @@ static int run_forward(gpsacq_engine* e, bool bits, const void* src, size_t src_
         FwdArgs fa{};
         fa.src = bits ? (const void*)((const uint8_t*)src + base * src_stride) : (const void*)((const float*)src + base * src_stride);
         fa.src_stride = src_stride;
-        fa.cos_mask = e->d_cos;
-        fa.sin_mask = e->d_sin;
+        fa.cos_t = e->d_cos_t;
+        fa.sin_t = e->d_sin_t;
         fa.t1 = e->d_t1;
         fa.t2 = e->d_t2;
         fa.tn = e->d_tn;
@@ -136,7 +137,7 @@ extern "C" void gpsacq_destroy(gpsacq_engine* e) {
     if (!e) return;
     (void)hipSetDevice(e->p.device);
     if (e->stream) (void)hipStreamSynchronize(e->stream);
-    void* bufs[] = {e->d_t1, e->d_t2, e->d_bq, e->d_tn, e->d_cos, e->d_sin, e->d_code, e->d_patch_blocks, e->d_bits, e->d_iq, e->d_iqbits, e->d_sums,
+    void* bufs[] = {e->d_t1, e->d_t2, e->d_bq, e->d_tn, e->d_cos, e->d_sin, e->d_cos_t, e->d_sin_t, e->d_code, e->d_patch_blocks, e->d_bits, e->d_iq, e->d_iqbits, e->d_sums,
                     e->d_dpp, e->d_parts, e->d_tasks, e->d_cells, e->d_peaks};
     for (void* b : bufs)
         if (b) (void)hipFree(b);
@@ -215,6 +216,13 @@ extern "C" int gpsacq_create(const gpsacq_params* params, gpsacq_engine** out) {
     HCK(hipMalloc((void**)&e->d_sin, BLOCK_BYTES));
     HCK(hipMemcpy(e->d_cos, cosm.data(), BLOCK_BYTES, hipMemcpyHostToDevice));
     HCK(hipMemcpy(e->d_sin, sinm.data(), BLOCK_BYTES, hipMemcpyHostToDevice));
+    std::vector<uint64_t> cos_t(625), sin_t(625);
+    transpose_masks(cosm.data(), cos_t.data());
+    transpose_masks(sinm.data(), sin_t.data());
+    HCK(hipMalloc((void**)&e->d_cos_t, 625 * sizeof(uint64_t)));
+    HCK(hipMalloc((void**)&e->d_sin_t, 625 * sizeof(uint64_t)));
+    HCK(hipMemcpy(e->d_cos_t, cos_t.data(), 625 * sizeof(uint64_t), hipMemcpyHostToDevice));
+    HCK(hipMemcpy(e->d_sin_t, sin_t.data(), 625 * sizeof(uint64_t), hipMemcpyHostToDevice));
 
     // SearchInit(): 32 resampled replicas (host, float-sequential NCO) -> code spectra (device)
     std::vector<float> rep((size_t)GPSACQ_NUM_SATS * N_FFT);

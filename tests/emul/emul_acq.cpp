@@ -47,11 +47,17 @@ extern "C" {
 
 // Sample(): spectrum of one 5120-byte block in natural order (un-conjugated).
 void emul_forward_bits(const uint8_t* bytes, const uint8_t* cosm, const uint8_t* sinm, float* out) {
-    std::vector<uint8_t> ib(USED_BYTES), qb(USED_BYTES);
-    for (int tid = 0; tid < WG; ++tid) fwd_stage_bits(tid, bytes, cosm, sinm, ib.data(), qb.data());
-    BitsSrc src{ib.data(), qb.data()};
+    std::vector<uint64_t> ib(625), qb(625), cos_t(625), sin_t(625);
+    transpose_masks(cosm, cos_t.data());
+    transpose_masks(sinm, sin_t.data());
+    for (int tid = 0; tid < WG; ++tid) fwd_stage_bits(tid, bytes, cos_t.data(), sin_t.data(), ib.data(), qb.data());
     std::vector<cf> pp((size_t)NPOLY * M_SUB);
-    emul_forward_pp(src, true, pp.data(), M_SUB, 0);
+    for (int kappa = 0; kappa < NPOLY; ++kappa) {  // the look-up table depends on the row
+        std::vector<cf> lut(256);
+        for (int tid = 0; tid < WG; ++tid) fwd_build_lut(tid, kappa, lut.data());
+        BitsSrc src{reinterpret_cast<const uint8_t*>(ib.data()), reinterpret_cast<const uint8_t*>(qb.data()), lut.data()};
+        emul_fwd_row(src, kappa, true, pp.data() + (size_t)kappa * M_SUB);
+    }
     pp_to_natural(pp.data(), M_SUB, 0, true, out);
 }
 // SearchInit(): spectrum of a real 40000-sample replica.
