@@ -180,11 +180,12 @@ def main():
         value = total_cells / elapsed
         kern_ms = float(np.mean(corr_ms))
         achieved = cells_per_step * ALG_BYTES_PER_CELL / (kern_ms * 1e-3) / 1e9
-        traffic, traffic_src = None, None
+        traffic, traffic_src, onchip = None, None, None
         try:  # HBM bytes per launch from the committed PMC passes (profiles/traffic.json), scaled by cells
             tj = json.load(open(os.path.join(ROOT, "profiles", "traffic.json")))
             traffic = (tj["hbm_read_bytes_per_cell"] + tj["hbm_write_bytes_per_cell"]) * cells_per_step
             traffic_src = f"profiles/{tj['tag']}_summary.md (rocprofv3 --pmc FETCH_SIZE, WRITE_SIZE; bytes per cell x cells per launch)"
+            onchip = tj.get("onchip_counters")
         except Exception:
             pass
         out = {
@@ -210,6 +211,9 @@ def main():
             "roofline": {"bound": "hbm", "kernel": f"k_corr<{eng.acc_columns}>", "achieved": achieved, "peak": HBM_PEAK_GBS,
                          "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_src,
                          "algorithmic_bytes_per_launch": cells_per_step * ALG_BYTES_PER_CELL,
+                         "note": "fused kernel: the algorithmic bytes never reach HBM (traffic << algorithmic), so frac > 1; "
+                                 "the real limiters are the fp32 VALU and LDS pipes (DESIGN.md section 4)",
+                         "onchip_counters": onchip,
                          "kernel_ms": kern_ms, "algorithmic_bytes_per_cell": ALG_BYTES_PER_CELL,
                          "cells_per_launch": cells_per_step},
             "stage_ms": {k: timing[k] for k in ("ms_total", "ms_sample", "ms_correlate", "ms_peaks")},

@@ -64,9 +64,23 @@ try:
     d = {c: sum(v) / len(v) for (kk, c), v in agg.items() if "k_corr" in kk}
     cells = d["_grid"] / 256.0 if "_grid" in d else None  # grid = workgroups*256 threads; one workgroup per cell (padded)
     if cells and "FETCH_SIZE" in d and "WRITE_SIZE" in d:
+        onchip = {}
+        for key, name in (("SQ_INSTS_VALU", "valu_wave_instr_per_cell"), ("SQ_INSTS_LDS", "lds_wave_instr_per_cell"),
+                          ("SQ_INSTS_VMEM_RD", "vmem_read_wave_instr_per_cell"), ("SQ_LDS_IDX_ACTIVE", "lds_active_cycles_per_cell"),
+                          ("SQ_LDS_BANK_CONFLICT", "lds_conflict_cycles_per_cell")):
+            if key in d:
+                onchip[name] = d[key] / cells
+        if "TCC_HIT_sum" in d:
+            onchip["l2_hit_rate"] = d["TCC_HIT_sum"] / (d["TCC_HIT_sum"] + d["TCC_MISS_sum"])
+        if "SQ_WAVE_CYCLES" in d:
+            for key, name in (("SQ_ACTIVE_INST_VALU", "valu_share_of_wave_cycles"), ("SQ_WAIT_INST_ANY", "issue_stall_share_of_wave_cycles"),
+                              ("SQ_WAIT_ANY", "waitcnt_barrier_share_of_wave_cycles")):
+                if key in d:
+                    onchip[name] = d[key] / d["SQ_WAVE_CYCLES"]
         json.dump({"tag": tag, "kernel": "k_corr", "cells_per_launch_profiled": cells,
                    "hbm_read_bytes_per_cell": d["FETCH_SIZE"] * 1024 * 2 / cells,
                    "hbm_write_bytes_per_cell": d["WRITE_SIZE"] * 1024 / cells,
+                   "onchip_counters": onchip,
                    "method": "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate passes; FETCH_SIZE KiB x 2 (gfx950 correction, "
                              "MI355X_MICROARCH.md section HBM); WRITE_SIZE uncalibrated"},
                   open(os.path.join(dst, "traffic.json"), "w"), indent=1)
