@@ -87,6 +87,9 @@ def main():
                          "grid (BASELINE configs[4]): --grid-blocks blocks x 32 PRN x +-100 kHz fine grid, Doppler slabs "
                          "sharded over ranks, per-(block, PRN) peak all-reduce, strong scaling")
     ap.add_argument("--grid-blocks", type=int, default=4)
+    ap.add_argument("--data", choices=["signals", "noise"], default="signals",
+                    help="signals (default): capture generated on the device, white noise + 8 PRNs at seeded Doppler / code "
+                         "phase (SURVEY section 8d throughput set); noise: host-generated random bits")
     args = ap.parse_args()
 
     import torch
@@ -119,7 +122,7 @@ def main():
     if grid:
         # every rank holds the same few blocks, searches all 32 PRNs over ITS slab of Doppler bins
         nblk = args.grid_blocks
-        host_bits = synth_bits(nblk, 77)
+        data_seed = 77
         first, nbins = gdist.shard_doppler(eng.dmax, rank, world)
         total_bins = 2 * eng.dmax + 1
         eng.set_doppler_window(first, nbins)
@@ -130,11 +133,21 @@ def main():
         job_cells_per_step = n_tasks * total_bins  # whole job, fixed as N grows
     else:
         nblk = args.blocks
-        host_bits = synth_bits(nblk, 1000 + rank)
+        data_seed = 1000 + rank
         d_tasks, n_tasks = None, nblk
         cells_per_step = nblk * eng.num_doppler
         job_cells_per_step = cells_per_step * world
-    d_bits = torch.from_numpy(host_bits).to(dev)
+    # synthetic input, resident in HBM before anything is timed
+    rs = np.random.default_rng(data_seed)
+    injected = sorted(rs.choice(np.arange(1, 33), size=8, replace=False).tolist())
+    sats = [(prn, 0.151, float(rs.uniform(-4500, 4500)), float(rs.uniform(0, 5456)), float(rs.random())) for prn in injected]
+    if args.data == "signals":
+        d_bits = torch.empty(nblk * 5120, dtype=torch.uint8, device=dev)
+        eng.generate_device(d_bits.data_ptr(), nblk * 5120, sats, noise_sigma=1.0, seed=data_seed)
+        host_bits = d_bits.cpu().numpy()
+    else:
+        host_bits = synth_bits(nblk, data_seed)
+        d_bits = torch.from_numpy(host_bits).to(dev)
     d_peaks = torch.zeros((n_tasks, 4), dtype=torch.int32, device=dev)
 
     def step():
@@ -201,6 +214,8 @@ def main():
             "vs_baseline": None,
             "dtype": "f32",
             "data": "synthetic",
+            "data_detail": ("device-generated 1-bit real-IF capture: white noise + PRNs %s at 45 dB-Hz, seeded Doppler/code phase" % injected)
+                           if args.data == "signals" else "uniform random bits (sign of white noise)",
             "config": {"workload": (f"BASELINE configs[4]: {args.grid_blocks} blocks x 32 PRN x {2 * eng.dmax + 1} Doppler bins (+-100 kHz, "
                                     "fs/N = 136.4 Hz), N=40000, 5456 lags") if grid else
                                    ("BASELINE configs[1]: 32 PRN x 73 Doppler bins (+-5 kHz, fs/N = 136.4 Hz), N=40000, "
@@ -219,6 +234,10 @@ def main():
             "stage_ms": {k: timing[k] for k in ("ms_total", "ms_sample", "ms_correlate", "ms_peaks")},
             "device": eng.device_name,
         }
+        if args.data == "signals" and not grid:  # the search must actually see what was injected (rank 0's capture)
+            snr, lo, ca = gdist.unpack_keys(best.cpu(), eng.dmax)
+            out["detected_prns"] = [int(p) + 1 for p in torch.nonzero(snr >= 25).flatten().tolist()]
+            out["injected_prns_rank0"] = injected
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(host_bits)
             try:

@@ -16,6 +16,7 @@
 #include "acq_launch.hpp"
 #include "acq_tables.hpp"
 #include "iq_launch.hpp"
+#include "gen_launch.hpp"
 
 using namespace acq;
 
@@ -70,6 +71,11 @@ struct gpsacq_engine {
     uint8_t* d_iqbits = nullptr;
     size_t iqbits_cap = 0;
     unsigned long long* d_sums = nullptr;
+    // capture generator scratch
+    GenSat* d_sats = nullptr;
+    size_t sats_cap = 0;
+    uint8_t* d_gen = nullptr;
+    size_t gen_cap = 0;
     // cached default schedule
     size_t sched_tasks = 0;
     bool sched_valid = false;
@@ -137,7 +143,7 @@ extern "C" void gpsacq_destroy(gpsacq_engine* e) {
     if (!e) return;
     (void)hipSetDevice(e->p.device);
     if (e->stream) (void)hipStreamSynchronize(e->stream);
-    void* bufs[] = {e->d_t1, e->d_t2, e->d_bq, e->d_tn, e->d_cos, e->d_sin, e->d_cos_t, e->d_sin_t, e->d_code, e->d_patch_blocks, e->d_bits, e->d_iq, e->d_iqbits, e->d_sums,
+    void* bufs[] = {e->d_t1, e->d_t2, e->d_bq, e->d_tn, e->d_cos, e->d_sin, e->d_cos_t, e->d_sin_t, e->d_code, e->d_patch_blocks, e->d_bits, e->d_iq, e->d_iqbits, e->d_sums, e->d_sats, e->d_gen,
                     e->d_dpp, e->d_parts, e->d_tasks, e->d_cells, e->d_peaks};
     for (void* b : bufs)
         if (b) (void)hipFree(b);
@@ -205,6 +211,17 @@ extern "C" int gpsacq_create(const gpsacq_params* params, gpsacq_engine** out) {
     HCK(hipMalloc((void**)&e->d_tn, T.tn.size() * sizeof(cf)));
     HCK(hipMemcpy(e->d_tn, T.tn.data(), T.tn.size() * sizeof(cf), hipMemcpyHostToDevice));
     HCK(upload_wq(T.wq.data()));
+    {   // C/A chips of all 32 PRNs for the capture generator
+        std::vector<uint32_t> chips(32 * 32, 0u);
+        for (int sv = 0; sv < GPSACQ_NUM_SATS; ++sv) {
+            CaCode ca(kTaps[sv][0], kTaps[sv][1]);
+            for (int i = 0; i < 1023; ++i) {
+                if (ca.chip()) chips[sv * 32 + (i >> 5)] |= 1u << (i & 31);
+                ca.clock();
+            }
+        }
+        HCK(upload_chips(chips.data()));
+    }
     HCK(hipMalloc((void**)&e->d_bq, T.bq.size() * sizeof(cf)));
     HCK(hipMemcpy(e->d_bq, T.bq.data(), T.bq.size() * sizeof(cf), hipMemcpyHostToDevice));
     HCK(hipMemcpy(e->d_t1, T.t1.data(), T.t1.size() * sizeof(cf), hipMemcpyHostToDevice));
@@ -457,6 +474,52 @@ extern "C" int gpsacq_last_timing(const gpsacq_engine* e, gpsacq_timing* t) {
     HIPCHK(hipEventElapsedTime(&t->ms_peaks, e->ev[2], e->ev[3]));
     t->correlate_launches = e->corr_launches;
     t->cells = e->cells_done;
+    return GPSACQ_OK;
+}
+
+// Synthetic capture on the device (gps_sig_gen.m's role; signal model of SURVEY.md section 8d)
+extern "C" int gpsacq_generate_device(gpsacq_engine* e, void* d_bits, size_t n_bytes, const gpsacq_sat* sats, int n_sats,
+                                      float noise_sigma, uint64_t seed, int sync) {
+    if (!e || !d_bits || n_bytes == 0 || n_sats < 0 || (n_sats > 0 && !sats)) return fail(GPSACQ_ERR_ARG, "gpsacq_generate_device: bad argument");
+    HIPCHK(hipSetDevice(e->p.device));
+    const double L1 = 1575.42e6, CPS = 1.023e6;
+    std::vector<GenSat> gs((size_t)n_sats);
+    for (int i = 0; i < n_sats; ++i) {
+        if (sats[i].prn < 1 || sats[i].prn > GPSACQ_NUM_SATS) return fail(GPSACQ_ERR_ARG, "satellite %d: PRN %d out of 1..32", i, sats[i].prn);
+        gs[i].sv = sats[i].prn - 1;
+        gs[i].amplitude = sats[i].amplitude;
+        gs[i].chips_per_sample = CPS * (1.0 + sats[i].doppler_hz / L1) / e->p.fs;
+        gs[i].code_phase = sats[i].code_phase_samples;
+        gs[i].cycles_per_sample = (e->p.fc + sats[i].doppler_hz) / e->p.fs;
+        gs[i].carrier_phase = sats[i].carrier_phase_cycles;
+    }
+    if (n_sats > 0) {
+        if (int rc = grow(e->d_sats, e->sats_cap, (size_t)n_sats)) return rc;
+        HIPCHK(hipMemcpyAsync(e->d_sats, gs.data(), gs.size() * sizeof(GenSat), hipMemcpyHostToDevice, e->stream));
+        HIPCHK(hipStreamSynchronize(e->stream));  // gs goes out of scope
+    }
+    GenArgs a{};
+    a.bits = (uint8_t*)d_bits;
+    a.n_bytes = n_bytes;
+    a.first_sample = 0;
+    a.seed = seed;
+    a.sats = e->d_sats;
+    a.n_sats = n_sats;
+    a.noise_sigma = noise_sigma;
+    launch_generate(a, e->stream);
+    HIPCHK(hipGetLastError());
+    if (sync) HIPCHK(hipStreamSynchronize(e->stream));
+    return GPSACQ_OK;
+}
+
+extern "C" int gpsacq_generate(gpsacq_engine* e, uint8_t* bits_out, size_t n_bytes, const gpsacq_sat* sats, int n_sats,
+                               float noise_sigma, uint64_t seed) {
+    if (!e || !bits_out || n_bytes == 0) return fail(GPSACQ_ERR_ARG, "gpsacq_generate: bad argument");
+    HIPCHK(hipSetDevice(e->p.device));
+    if (int rc = grow(e->d_gen, e->gen_cap, n_bytes)) return rc;
+    if (int rc = gpsacq_generate_device(e, e->d_gen, n_bytes, sats, n_sats, noise_sigma, seed, 0)) return rc;
+    HIPCHK(hipMemcpyAsync(bits_out, e->d_gen, n_bytes, hipMemcpyDeviceToHost, e->stream));
+    HIPCHK(hipStreamSynchronize(e->stream));
     return GPSACQ_OK;
 }
 

@@ -48,7 +48,12 @@ class Handoff(ctypes.Structure):
                 ("ca_rate", ctypes.c_uint32), ("ca_shift", ctypes.c_int32), ("ca_pause", ctypes.c_uint32)]
 
 
-EXPORTS = ["gpsacq_handoff", "gpsacq_iq8_to_bits", "gpsacq_iq8_to_bits_device", "gpsacq_create", "gpsacq_destroy", "gpsacq_last_error", "gpsacq_get_info", "gpsacq_search",
+class Sat(ctypes.Structure):
+    _fields_ = [("prn", ctypes.c_int32), ("amplitude", ctypes.c_float), ("doppler_hz", ctypes.c_double),
+                ("code_phase_samples", ctypes.c_double), ("carrier_phase_cycles", ctypes.c_double)]
+
+
+EXPORTS = ["gpsacq_generate", "gpsacq_generate_device", "gpsacq_handoff", "gpsacq_iq8_to_bits", "gpsacq_iq8_to_bits_device", "gpsacq_create", "gpsacq_destroy", "gpsacq_last_error", "gpsacq_get_info", "gpsacq_search",
            "gpsacq_search_device", "gpsacq_set_doppler_window", "gpsacq_set_noncoherent", "gpsacq_aligned_stride", "gpsacq_synchronize", "gpsacq_last_timing", "gpsacq_search_code",
            "gpsacq_sample_spectrum", "gpsacq_code_spectrum"]
 
@@ -92,6 +97,10 @@ def load_library(path=None):
     lib.gpsacq_iq8_to_bits.restype = ctypes.c_int
     lib.gpsacq_iq8_to_bits_device.argtypes = [vp, vp, sz, ctypes.c_int, ctypes.c_int, ctypes.c_double, ctypes.c_double, vp, ctypes.c_int]
     lib.gpsacq_iq8_to_bits_device.restype = ctypes.c_int
+    lib.gpsacq_generate.argtypes = [vp, vp, sz, ctypes.POINTER(Sat), ctypes.c_int, ctypes.c_float, ctypes.c_uint64]
+    lib.gpsacq_generate.restype = ctypes.c_int
+    lib.gpsacq_generate_device.argtypes = [vp, vp, sz, ctypes.POINTER(Sat), ctypes.c_int, ctypes.c_float, ctypes.c_uint64, ctypes.c_int]
+    lib.gpsacq_generate_device.restype = ctypes.c_int
     lib.gpsacq_handoff.argtypes = [vp, ctypes.c_double, ctypes.c_double, ctypes.c_double, ctypes.POINTER(Handoff)]
     lib.gpsacq_handoff.restype = ctypes.c_int
     lib.gpsacq_search_code.argtypes = [ctypes.c_int, ctypes.c_int]
@@ -219,6 +228,26 @@ class Engine:
         t = Timing()
         _check(self._lib, self._lib.gpsacq_last_timing(self._h, ctypes.byref(t)))
         return {k: getattr(t, k) for k, _ in Timing._fields_}
+
+    # ---- synthetic captures ---------------------------------------------------------------
+    @staticmethod
+    def _sats(sats):
+        arr = (Sat * max(1, len(sats)))()
+        for i, (prn, amp, dop, ca, ph) in enumerate(sats):
+            arr[i] = Sat(int(prn), float(amp), float(dop), float(ca), float(ph))
+        return arr
+
+    def generate(self, n_bytes, sats=(), noise_sigma=1.0, seed=1):
+        """Synthetic 1-bit real-IF capture made on the device: sats = [(prn, amplitude, doppler_hz,
+        code_phase_samples, carrier_phase_cycles), ...] on top of white noise (gps_sig_gen.m's role)."""
+        out = np.zeros(int(n_bytes), dtype=np.uint8)
+        _check(self._lib, self._lib.gpsacq_generate(self._h, out.ctypes.data_as(ctypes.c_void_p), int(n_bytes), self._sats(sats),
+                                                    len(sats), float(noise_sigma), int(seed)))
+        return out
+
+    def generate_device(self, d_bits_ptr, n_bytes, sats=(), noise_sigma=1.0, seed=1, sync=True):
+        _check(self._lib, self._lib.gpsacq_generate_device(self._h, d_bits_ptr, int(n_bytes), self._sats(sats), len(sats),
+                                                           float(noise_sigma), int(seed), 1 if sync else 0))
 
     # ---- 8-bit IQ ingestion --------------------------------------------------------------
     def iq8_to_bits(self, iq, signed=False, remove_dc=True, mix_hz=0.0, fs=0.0):

@@ -18,6 +18,7 @@
  *   gpsacq_search_code       SearchCode()            c/search_offline.cpp:205-209
  *   gpsacq_iq8_to_bits       the MATLAB pre-processing that produces gps_test's input from an 8-bit IQ
  *                            capture: proc_rtl_bin_for_gps.m:12-26,31-47, proc_hackrf_bin_for_gps.m:7-19
+ *   gpsacq_generate          gps_sig_gen.m:8-41 (synthetic 1-bit capture; here noise + any PRN set)
  *   gpsacq_handoff           CHANNEL::Start()'s NCO set-up from a search hit, c/channel.cpp:134-163
  *                            (the first consumer of the search result in the online receiver)
  *   gpsacq_sample_spectrum   Sample()'s fwd_buf      c/search_offline.cpp:161 (parity probe)
@@ -170,6 +171,27 @@ int gpsacq_iq8_to_bits(gpsacq_engine* e, const void* iq, size_t n_samples, int f
                        double mix_hz, double fs, uint8_t* bits_out);
 int gpsacq_iq8_to_bits_device(gpsacq_engine* e, const void* d_iq, size_t n_samples, int format, int remove_dc,
                               double mix_hz, double fs, void* d_bits_out, int sync);
+
+/*
+ * Synthetic 1-bit real-IF capture generated on the device (the reference's gps_sig_gen.m writes one
+ * noise-free PRN; this is the signal model of SURVEY.md section 8d): white Gaussian noise of standard
+ * deviation noise_sigma plus, per satellite, amplitude * C/A chip * cos(2 pi ((fc + doppler)/fs m +
+ * carrier_phase)), chips advancing at 1.023e6 (1 + doppler/L1) per second from code_phase_samples;
+ * bit = (sum < 0), sample m in bit m % 8 of byte m / 8.  Uses the engine's fc and fs.  Deterministic
+ * in (seed, arguments).  A search of the result reports lo_shift = round(doppler * 40000 / fs) and
+ * ca_shift = (code_phase + 8 * stride * block) mod (fs / 1000) for block-sized strides.
+ */
+typedef struct {
+    int32_t prn;                 /* 1..32 */
+    float amplitude;             /* relative to noise_sigma = 1: 0.151 ~ 45 dB-Hz */
+    double doppler_hz;
+    double code_phase_samples;
+    double carrier_phase_cycles;
+} gpsacq_sat;
+int gpsacq_generate(gpsacq_engine* e, uint8_t* bits_out, size_t n_bytes, const gpsacq_sat* sats, int n_sats,
+                    float noise_sigma, uint64_t seed);
+int gpsacq_generate_device(gpsacq_engine* e, void* d_bits_out, size_t n_bytes, const gpsacq_sat* sats, int n_sats,
+                           float noise_sigma, uint64_t seed, int sync);
 
 /*
  * Acquisition hand-off record: what the tracking channel derives from a search hit

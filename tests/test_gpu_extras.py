@@ -180,3 +180,35 @@ def test_cli_multi_engine_threads(golden_dir):
     bad = subprocess.run([GPS_TEST, path, "2.046e6", "8.184e6", "5000"], capture_output=True, text=True,
                          env=dict(base, GPSACQ_DEVICES="0,99"), timeout=300)
     assert bad.returncode == 1 and "SearchInit() returned 1" in bad.stdout
+
+
+def test_device_generated_capture_is_found():
+    """Synthetic capture made on the device (gps_sig_gen.m's role): the injected PRNs
+    must come back from the search with the Doppler bin and code phase they were generated with."""
+    import gpsacq
+    fs, fc = 5.456e6, 4.092e6
+    sats = [(1, 0.151, 6 * fs / 40000, 1465.0, 0.1), (21, 0.151, 8 * fs / 40000, 686.0, 0.7),
+            (29, 0.2, -9 * fs / 40000, 3868.0, 0.3), (5, 0.12, 2501.0, 12.25, 0.0)]
+    with gpsacq.Engine(fc, fs, 5000.0) as eng:
+        bits = eng.generate(4 * 5120, sats, noise_sigma=1.0, seed=42)
+        again = eng.generate(4 * 5120, sats, noise_sigma=1.0, seed=42)
+        other = eng.generate(4 * 5120, sats, noise_sigma=1.0, seed=43)
+        assert np.array_equal(bits, again) and not np.array_equal(bits, other)
+        ones = np.unpackbits(bits).mean()
+        assert 0.48 < ones < 0.52
+        tasks = [(b, sv) for b in range(4) for sv in range(32)]
+        _, peaks = eng.search(bits, tasks=tasks)
+        peaks = peaks.reshape(4, 32)
+        for prn, amp, dop, ca, ph in sats:
+            for b in range(4):
+                pk = peaks[b, prn - 1]
+                assert pk["snr"] > 30, (prn, b, pk)
+                assert abs(int(pk["lo_shift"]) - round(dop * 40000 / fs)) <= 1
+                expect = (ca + 40960 * b * (1 + dop / 1575.42e6)) % 5456
+                d = abs(int(pk["ca_shift"]) - expect)
+                assert min(d, 5456 - d) <= 1.5, (prn, b, pk, expect)
+        absent = [sv for sv in range(32) if sv + 1 not in (1, 21, 29, 5)]
+        assert peaks[:, absent]["snr"].max() < 25
+        noise_only = eng.generate(5120, (), seed=7)
+        _, p0 = eng.search(noise_only, tasks=[(0, sv) for sv in range(32)])
+        assert p0["snr"].max() < 25
