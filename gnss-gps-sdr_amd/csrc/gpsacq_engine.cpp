@@ -185,14 +185,6 @@ extern "C" int gpsacq_create(const gpsacq_params* params, gpsacq_engine** out) {
     e->crow = M_SUB + 2 * e->halo;
     e->cus = prop.multiProcessorCount;
     snprintf(e->name, sizeof e->name, "%s", prop.name);
-#define CK(expr)                               \
-    do {                                       \
-        int rc_ = (expr);                      \
-        if (rc_ != GPSACQ_OK) {                \
-            gpsacq_destroy(e);                 \
-            return rc_;                        \
-        }                                      \
-    } while (0)
 #define HCK(expr)                                                                     \
     do {                                                                              \
         hipError_t e_ = (expr);                                                       \
@@ -262,7 +254,6 @@ extern "C" int gpsacq_create(const gpsacq_params* params, gpsacq_engine** out) {
     HCK(hipGetLastError());
     HCK(hipStreamSynchronize(e->stream));
     HCK(hipFree(d_rep));
-#undef CK
 #undef HCK
     *out = e;
     return GPSACQ_OK;
