@@ -105,6 +105,18 @@ __global__ __launch_bounds__(WG, WPS) void k_corr(CorrArgs a) {
     const int task = grp * 8 + xcd;
     if (task >= a.n_tasks) return;
     const Task tk = a.tasks[task];
+    // task lists handed over in device memory are not seen by the host: bound them here (uniform branch)
+    if (tk.spec < 0 || (long)tk.spec + (long)(a.n_acc - 1) * a.acc_step >= a.n_spec || tk.code < 0 || tk.code >= a.n_code) {
+        if (tid == 0) {
+            Cell c;
+            c.max_pwr = 0.f;
+            c.max_i = -1;
+            c.tot_pwr = 0.f;
+            c.snr = 0.f;
+            a.cells[(size_t)task * a.ndop + di] = c;
+        }
+        return;
+    }
     const int dop = di + a.dop_first;
     const cf* dpp = a.dpp + (size_t)tk.spec * NPOLY * M_SUB;
     const cf* cpp = a.cpp + (size_t)tk.code * NPOLY * a.crow;

@@ -105,6 +105,7 @@ static int ensure_code_slots(gpsacq_engine* e, size_t n_patch) {
     HIPCHK(hipStreamSynchronize(e->stream));
     HIPCHK(hipFree(e->d_code));
     e->d_code = nd;
+    e->patch_cap = 0;
     if (e->d_patch_blocks) HIPCHK(hipFree(e->d_patch_blocks));
     e->d_patch_blocks = nullptr;
     HIPCHK(hipMalloc((void**)&e->d_patch_blocks, n_patch * sizeof(int32_t)));
@@ -280,7 +281,7 @@ static int prepare_tasks(gpsacq_engine* e, const gpsacq_task* h_tasks, const voi
                          size_t n_tasks, const uint8_t* d_bits, size_t stride) {
     const bool quirks = e->p.ref_quirks != 0;
     if (!h_tasks && !d_user_tasks) {
-        if (e->sched_valid && e->sched_tasks == n_tasks && !quirks && e->n_acc == 1) return GPSACQ_OK;  // cached
+        if (e->sched_valid && n_tasks <= e->sched_tasks && !quirks && e->n_acc == 1) return GPSACQ_OK;  // cached (a prefix is the same schedule)
     }
     if (int rc = grow(e->d_tasks, e->task_cap, n_tasks)) return rc;
     e->sched_valid = false;
@@ -340,6 +341,7 @@ static int search_core(gpsacq_engine* e, const uint8_t* d_bits, size_t n_blocks,
     if (n_blocks == 0 || n_tasks == 0) return fail(GPSACQ_ERR_ARG, "empty batch");
     if (stride < (size_t)BLOCK_BYTES && e->p.ref_quirks) return fail(GPSACQ_ERR_ARG, "ref_quirks needs all 5120 bytes of a block (stride >= 5120)");
     if (stride < (size_t)USED_BYTES) return fail(GPSACQ_ERR_ARG, "stride %zu < 5000 bytes", stride);
+    if (n_blocks > 0x7fffffffu) return fail(GPSACQ_ERR_ARG, "batch too large: %zu blocks", n_blocks);
     if (n_tasks * (size_t)e->ndop > 0x7fffff00u) return fail(GPSACQ_ERR_ARG, "batch too large: %zu tasks x %d bins", n_tasks, e->ndop);
     if (int rc = grow(e->d_dpp, e->dpp_cap, n_blocks, (size_t)NPOLY * M_SUB * sizeof(cf))) return rc;
     if (!d_cells) {
@@ -367,6 +369,8 @@ static int search_core(gpsacq_engine* e, const uint8_t* d_bits, size_t n_blocks,
     ca.halo = e->halo;
     ca.n_acc = e->n_acc;
     ca.acc_step = e->acc_step;
+    ca.n_spec = (int)n_blocks;
+    ca.n_code = GPSACQ_NUM_SATS + (int)e->patch_cap;
     const int n_cols = (e->nlags + NBF3 - 1) / NBF3;
     const int n_pass = (n_cols + MC_MAX - 1) / MC_MAX;  // 1 up to 10000 lags (fs <= 10 MHz)
     if (n_pass == 1) {

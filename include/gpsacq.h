@@ -130,7 +130,9 @@ int gpsacq_search(gpsacq_engine* e, const uint8_t* bits, size_t n_blocks, size_t
 /*
  * Same with every buffer already in this device's memory (bits, tasks, cells, peaks are
  * device pointers; tasks may be NULL as above; cells may be NULL).  Work is enqueued on the
- * engine's stream; `sync` != 0 waits for completion.
+ * engine's stream; `sync` != 0 waits for completion.  A device task list is not read by the host:
+ * a task whose block or prn is out of range is skipped by the kernel and reported as cells with
+ * max_i = -1, snr = 0 (peak: snr = 0) instead of GPSACQ_ERR_ARG.
  */
 int gpsacq_search_device(gpsacq_engine* e, const void* d_bits, size_t n_blocks, size_t stride,
                          const void* d_tasks, size_t n_tasks, void* d_cells, void* d_peaks, int sync);

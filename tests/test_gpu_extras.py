@@ -212,3 +212,34 @@ def test_device_generated_capture_is_found():
         noise_only = eng.generate(5120, (), seed=7)
         _, p0 = eng.search(noise_only, tasks=[(0, sv) for sv in range(32)])
         assert p0["snr"].max() < 25
+
+
+def test_device_entry_point_and_task_bounds():
+    """gpsacq_search_device (buffers already in HBM, engine stream): same answers as the host-pointer
+    entry point; a device task list is bounded by the kernel -- out-of-range tasks come back as empty
+    cells (max_i = -1, snr = 0) and the valid ones are untouched."""
+    import torch
+    import gpsacq
+    fs, fc = 5.456e6, 4.092e6
+    with gpsacq.Engine(fc, fs, 5000.0) as eng:
+        bits = eng.generate(3 * 5120, [(9, 0.2, 1000.0, 777.0, 0.0)], seed=5)
+        tasks = np.array([(0, 8), (2, 8), (3, 8), (1, 32), (-1, 0), (1, 8), (0, -5)], dtype=gpsacq.TASK_DTYPE)
+        valid = [0, 1, 5]
+        cells_h, peaks_h = eng.search(bits, tasks=[tuple(t) for t in tasks[valid]], want_cells=True)
+        d_bits = torch.from_numpy(bits).cuda()
+        d_tasks = torch.from_numpy(tasks.view(np.int32).reshape(-1, 2)).cuda()
+        d_cells = torch.zeros(len(tasks) * eng.num_doppler * 4, dtype=torch.int32, device="cuda")
+        d_peaks = torch.zeros(len(tasks) * 4, dtype=torch.int32, device="cuda")
+        eng.search_device(d_bits.data_ptr(), 3, d_peaks.data_ptr(), d_tasks_ptr=d_tasks.data_ptr(), n_tasks=len(tasks),
+                          d_cells_ptr=d_cells.data_ptr(), sync=True)
+        cells_d = d_cells.cpu().numpy().view(gpsacq.CELL_DTYPE).reshape(len(tasks), eng.num_doppler)
+        peaks_d = d_peaks.cpu().numpy().view(gpsacq.PEAK_DTYPE)
+        assert np.array_equal(cells_d[valid], cells_h)
+        assert np.array_equal(peaks_d[valid], peaks_h)
+        assert peaks_h["snr"].min() > 30
+        for t in (2, 3, 4, 6):
+            assert (cells_d[t]["max_i"] == -1).all() and (cells_d[t]["snr"] == 0).all()
+            assert peaks_d[t]["snr"] == 0
+        # host task lists are still rejected up front
+        with pytest.raises(gpsacq.GpsAcqError):
+            eng.search(bits, tasks=[(3, 8)])
