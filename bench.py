@@ -38,6 +38,13 @@ def synth_bits(n_blocks, seed):
     return rng.integers(0, 256, size=n_blocks * 5120, dtype=np.uint8)
 
 
+def synth_sats(seed):
+    """The 8 satellites injected into the capture generated from `seed`: (sorted PRNs, generator tuples)."""
+    rs = np.random.default_rng(seed)
+    prns = sorted(rs.choice(np.arange(1, 33), size=8, replace=False).tolist())
+    return prns, [(prn, 0.151, float(rs.uniform(-4500, 4500)), float(rs.uniform(0, 5456)), float(rs.random())) for prn in prns]
+
+
 def cpu_baseline(bits, target_s=12.0):
     """The oracle's float build (own mixed-radix FFT; `port`) timed single-threaded on a
     bounded sample of the same workload."""
@@ -138,9 +145,7 @@ def main():
         cells_per_step = nblk * eng.num_doppler
         job_cells_per_step = cells_per_step * world
     # synthetic input, resident in HBM before anything is timed
-    rs = np.random.default_rng(data_seed)
-    injected = sorted(rs.choice(np.arange(1, 33), size=8, replace=False).tolist())
-    sats = [(prn, 0.151, float(rs.uniform(-4500, 4500)), float(rs.uniform(0, 5456)), float(rs.random())) for prn in injected]
+    injected, sats = synth_sats(data_seed)
     if args.data == "signals":
         d_bits = torch.empty(nblk * 5120, dtype=torch.uint8, device=dev)
         eng.generate_device(d_bits.data_ptr(), nblk * 5120, sats, noise_sigma=1.0, seed=data_seed)
@@ -238,6 +243,8 @@ def main():
             snr, lo, ca = gdist.unpack_keys(best.cpu(), eng.dmax)
             out["detected_prns"] = [int(p) + 1 for p in torch.nonzero(snr >= 25).flatten().tolist()]
             out["injected_prns_rank0"] = injected
+            # after the all-reduce the per-PRN best covers every rank's capture (rank r: seed 1000 + r)
+            out["injected_prns_all_ranks"] = sorted(set().union(*[synth_sats(1000 + r)[0] for r in range(world)]))
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(host_bits)
             try:
