@@ -153,14 +153,28 @@ def main():
     else:
         host_bits = synth_bits(nblk, data_seed)
         d_bits = torch.from_numpy(host_bits).to(dev)
-    d_peaks = torch.zeros((n_tasks, 4), dtype=torch.int32, device=dev)
+    # The search runs on the engine's own HIP stream; the peak reduction and the collective run on
+    # torch's stream, ordered after it by an event, so step i's reduction / all-reduce overlaps step
+    # i+1's search (two peak buffers; the engine stream waits for a buffer's previous reader).
+    d_peaks = [torch.zeros((n_tasks, 4), dtype=torch.int32, device=dev) for _ in range(2)]
+    eng_stream = torch.cuda.ExternalStream(eng.stream_ptr, device=dev)
+    reader_done = [None, None]
+    step_no = [0]
 
     def step():
-        eng.search_device(d_bits.data_ptr(), nblk, d_peaks.data_ptr(), d_tasks_ptr=d_tasks.data_ptr() if grid else None,
-                          n_tasks=n_tasks, sync=True)
+        slot = step_no[0] & 1
+        step_no[0] += 1
+        buf = d_peaks[slot]
+        if reader_done[slot] is not None:
+            eng_stream.wait_event(reader_done[slot])
+        eng.search_device(d_bits.data_ptr(), nblk, buf.data_ptr(), d_tasks_ptr=d_tasks.data_ptr() if grid else None,
+                          n_tasks=n_tasks, sync=False)
+        searched = torch.cuda.Event()
+        searched.record(eng_stream)
+        torch.cuda.current_stream().wait_event(searched)
         # best peak per PRN (blocks mode) / per (block, PRN) (grid mode), packed so that integer MAX
         # reproduces the reference's ordering (higher SNR; ties -> lower Doppler bin, :198)
-        key = gdist.pack_keys(d_peaks, eng.dmax)
+        key = gdist.pack_keys(buf, eng.dmax)
         best = key if grid else gdist.per_prn_best(key)
         if dist is not None:
             if backend == "nccl":
@@ -169,9 +183,12 @@ def main():
                 b = best.cpu()
                 dist.all_reduce(b, op=dist.ReduceOp.MAX)
                 best = b.to(dev)
+        reader_done[slot] = torch.cuda.Event()
+        reader_done[slot].record(torch.cuda.current_stream())
         return best
 
     def fence():
+        eng.synchronize()
         torch.cuda.synchronize()
         if dist is not None:
             dist.barrier()
@@ -182,9 +199,11 @@ def main():
     fence()
     corr_ms = []
     t0 = time.perf_counter()
-    for _ in range(args.steps):
+    for i in range(args.steps):
         best = step()
-        corr_ms.append(eng.last_timing()["ms_correlate"])
+        if i > 0:  # the previous search's times: waits for that search only, this one is already queued
+            corr_ms.append(eng.last_timing(1)["ms_correlate"])
+    corr_ms.append(eng.last_timing(0)["ms_correlate"])
     fence()
     elapsed = time.perf_counter() - t0
     t = torch.tensor([elapsed], dtype=torch.float64, device=dev if backend == "nccl" else "cpu")

@@ -47,7 +47,13 @@ struct gpsacq_engine {
     int cus = 0;
     char name[64] = {0};
     hipStream_t stream = nullptr;
-    hipEvent_t ev[4] = {nullptr, nullptr, nullptr, nullptr};
+    // stage events of the last kTimingRing searches (asynchronous callers read a finished search's
+    // times while the next one runs)
+    static const int kTimingRing = 8;
+    hipEvent_t ev[kTimingRing][4] = {};
+    int ring_launches[kTimingRing] = {};
+    int64_t ring_cells[kTimingRing] = {};
+    long searches = 0;  // searches enqueued so far; search k uses ring slot k % kTimingRing
     // constants
     cf *d_t1 = nullptr, *d_t2 = nullptr, *d_bq = nullptr, *d_tn = nullptr;
     uint8_t *d_cos = nullptr, *d_sin = nullptr;
@@ -79,9 +85,6 @@ struct gpsacq_engine {
     // cached default schedule
     size_t sched_tasks = 0;
     bool sched_valid = false;
-    bool timing_valid = false;
-    int corr_launches = 0;
-    int64_t cells_done = 0;
 };
 
 static const size_t kFwdChunk = 32768;  // blocks per forward-transform launch (grid.y bound)
@@ -148,8 +151,9 @@ extern "C" void gpsacq_destroy(gpsacq_engine* e) {
                     e->d_dpp, e->d_parts, e->d_tasks, e->d_cells, e->d_peaks};
     for (void* b : bufs)
         if (b) (void)hipFree(b);
-    for (auto& ev : e->ev)
-        if (ev) (void)hipEventDestroy(ev);
+    for (auto& set : e->ev)
+        for (auto& ev : set)
+            if (ev) (void)hipEventDestroy(ev);
     if (e->stream) (void)hipStreamDestroy(e->stream);
     delete e;
 }
@@ -196,7 +200,8 @@ extern "C" int gpsacq_create(const gpsacq_params* params, gpsacq_engine** out) {
         }                                                                             \
     } while (0)
     HCK(hipStreamCreateWithFlags(&e->stream, hipStreamNonBlocking));
-    for (auto& ev : e->ev) HCK(hipEventCreate(&ev));
+    for (auto& set : e->ev)
+        for (auto& ev : set) HCK(hipEventCreate(&ev));
 
     Tables T;
     HCK(hipMalloc((void**)&e->d_t1, T.t1.size() * sizeof(cf)));
@@ -350,9 +355,10 @@ static int search_core(gpsacq_engine* e, const uint8_t* d_bits, size_t n_blocks,
     }
     if (int rc = prepare_tasks(e, h_tasks, d_user_tasks, n_blocks, n_tasks, d_bits, stride)) return rc;
 
-    HIPCHK(hipEventRecord(e->ev[0], e->stream));
+    hipEvent_t* ev = e->ev[e->searches % gpsacq_engine::kTimingRing];
+    HIPCHK(hipEventRecord(ev[0], e->stream));
     if (int rc = run_forward(e, true, d_bits, stride, n_blocks, e->d_dpp, (size_t)NPOLY * M_SUB, M_SUB, 0, true)) return rc;
-    HIPCHK(hipEventRecord(e->ev[1], e->stream));
+    HIPCHK(hipEventRecord(ev[1], e->stream));
     CorrArgs ca{};
     ca.dpp = e->d_dpp;
     ca.cpp = e->d_code;
@@ -387,13 +393,13 @@ static int search_core(gpsacq_engine* e, const uint8_t* d_bits, size_t n_blocks,
         launch_merge_cells(e->d_parts, d_cells, n_cells, n_pass, e->nlags, e->stream);
     }
     HIPCHK(hipGetLastError());
-    HIPCHK(hipEventRecord(e->ev[2], e->stream));
+    HIPCHK(hipEventRecord(ev[2], e->stream));
     launch_peaks(d_cells, d_peaks, (int)n_tasks, e->ndop, e->dop_first, e->stream);
     HIPCHK(hipGetLastError());
-    HIPCHK(hipEventRecord(e->ev[3], e->stream));
-    e->timing_valid = true;
-    e->corr_launches = n_pass;
-    e->cells_done = (int64_t)n_tasks * e->ndop;
+    HIPCHK(hipEventRecord(ev[3], e->stream));
+    e->ring_launches[e->searches % gpsacq_engine::kTimingRing] = n_pass;
+    e->ring_cells[e->searches % gpsacq_engine::kTimingRing] = (int64_t)n_tasks * e->ndop;
+    e->searches++;
     return GPSACQ_OK;
 }
 
@@ -458,19 +464,26 @@ extern "C" int gpsacq_synchronize(gpsacq_engine* e) {
     return GPSACQ_OK;
 }
 
-extern "C" int gpsacq_last_timing(const gpsacq_engine* e, gpsacq_timing* t) {
-    if (!e || !t) return fail(GPSACQ_ERR_ARG, "gpsacq_last_timing: null argument");
-    if (!e->timing_valid) return fail(GPSACQ_ERR_ARG, "no search has run yet");
-    HIPCHK(hipEventSynchronize(e->ev[3]));
+extern "C" int gpsacq_timing_ago(const gpsacq_engine* e, int n_back, gpsacq_timing* t) {
+    if (!e || !t) return fail(GPSACQ_ERR_ARG, "gpsacq_timing_ago: null argument");
+    if (n_back < 0 || n_back >= gpsacq_engine::kTimingRing || (long)n_back >= e->searches)
+        return fail(GPSACQ_ERR_ARG, "no timing %d searches back (%ld searches so far, %d kept)", n_back, e->searches, gpsacq_engine::kTimingRing);
+    const int slot = (int)((e->searches - 1 - n_back) % gpsacq_engine::kTimingRing);
+    const hipEvent_t* ev = e->ev[slot];
+    HIPCHK(hipEventSynchronize(ev[3]));
     memset(t, 0, sizeof *t);
-    HIPCHK(hipEventElapsedTime(&t->ms_total, e->ev[0], e->ev[3]));
-    HIPCHK(hipEventElapsedTime(&t->ms_sample, e->ev[0], e->ev[1]));
-    HIPCHK(hipEventElapsedTime(&t->ms_correlate, e->ev[1], e->ev[2]));
-    HIPCHK(hipEventElapsedTime(&t->ms_peaks, e->ev[2], e->ev[3]));
-    t->correlate_launches = e->corr_launches;
-    t->cells = e->cells_done;
+    HIPCHK(hipEventElapsedTime(&t->ms_total, ev[0], ev[3]));
+    HIPCHK(hipEventElapsedTime(&t->ms_sample, ev[0], ev[1]));
+    HIPCHK(hipEventElapsedTime(&t->ms_correlate, ev[1], ev[2]));
+    HIPCHK(hipEventElapsedTime(&t->ms_peaks, ev[2], ev[3]));
+    t->correlate_launches = e->ring_launches[slot];
+    t->cells = e->ring_cells[slot];
     return GPSACQ_OK;
 }
+
+extern "C" int gpsacq_last_timing(const gpsacq_engine* e, gpsacq_timing* t) { return gpsacq_timing_ago(e, 0, t); }
+
+extern "C" void* gpsacq_stream(gpsacq_engine* e) { return e ? (void*)e->stream : nullptr; }
 
 // Synthetic capture on the device (gps_sig_gen.m's role; signal model of SURVEY.md section 8d)
 extern "C" int gpsacq_generate_device(gpsacq_engine* e, void* d_bits, size_t n_bytes, const gpsacq_sat* sats, int n_sats,

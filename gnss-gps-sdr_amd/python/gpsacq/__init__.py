@@ -54,7 +54,7 @@ class Sat(ctypes.Structure):
 
 
 EXPORTS = ["gpsacq_generate", "gpsacq_generate_device", "gpsacq_handoff", "gpsacq_iq8_to_bits", "gpsacq_iq8_to_bits_device", "gpsacq_create", "gpsacq_destroy", "gpsacq_last_error", "gpsacq_get_info", "gpsacq_search",
-           "gpsacq_search_device", "gpsacq_set_doppler_window", "gpsacq_set_noncoherent", "gpsacq_aligned_stride", "gpsacq_synchronize", "gpsacq_last_timing", "gpsacq_search_code",
+           "gpsacq_search_device", "gpsacq_set_doppler_window", "gpsacq_set_noncoherent", "gpsacq_aligned_stride", "gpsacq_synchronize", "gpsacq_last_timing", "gpsacq_timing_ago", "gpsacq_stream", "gpsacq_search_code",
            "gpsacq_sample_spectrum", "gpsacq_code_spectrum"]
 
 _lib = None
@@ -93,6 +93,10 @@ def load_library(path=None):
     lib.gpsacq_synchronize.restype = ctypes.c_int
     lib.gpsacq_last_timing.argtypes = [vp, ctypes.POINTER(Timing)]
     lib.gpsacq_last_timing.restype = ctypes.c_int
+    lib.gpsacq_timing_ago.argtypes = [vp, ctypes.c_int, ctypes.POINTER(Timing)]
+    lib.gpsacq_timing_ago.restype = ctypes.c_int
+    lib.gpsacq_stream.argtypes = [vp]
+    lib.gpsacq_stream.restype = ctypes.c_void_p
     lib.gpsacq_iq8_to_bits.argtypes = [vp, vp, sz, ctypes.c_int, ctypes.c_int, ctypes.c_double, ctypes.c_double, vp]
     lib.gpsacq_iq8_to_bits.restype = ctypes.c_int
     lib.gpsacq_iq8_to_bits_device.argtypes = [vp, vp, sz, ctypes.c_int, ctypes.c_int, ctypes.c_double, ctypes.c_double, vp, ctypes.c_int]
@@ -224,10 +228,16 @@ class Engine:
     def synchronize(self):
         _check(self._lib, self._lib.gpsacq_synchronize(self._h))
 
-    def last_timing(self):
+    def last_timing(self, n_back=0):
+        """Stage times (ms) of the search n_back calls ago (0 = the last one); waits for that search only."""
         t = Timing()
-        _check(self._lib, self._lib.gpsacq_last_timing(self._h, ctypes.byref(t)))
+        _check(self._lib, self._lib.gpsacq_timing_ago(self._h, int(n_back), ctypes.byref(t)))
         return {k: getattr(t, k) for k, _ in Timing._fields_}
+
+    @property
+    def stream_ptr(self):
+        """The engine's hipStream_t as an integer (e.g. for torch.cuda.ExternalStream)."""
+        return int(self._lib.gpsacq_stream(self._h) or 0)
 
     # ---- synthetic captures ---------------------------------------------------------------
     @staticmethod

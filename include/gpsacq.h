@@ -156,7 +156,14 @@ int gpsacq_set_doppler_window(gpsacq_engine* e, int first_bin, int n_bins);
 int gpsacq_set_noncoherent(gpsacq_engine* e, int n_acc, int block_step);
 int gpsacq_aligned_stride(const gpsacq_engine* e);
 int gpsacq_synchronize(gpsacq_engine* e);
+/* stage times of the most recent search (waits for it to finish) ... */
 int gpsacq_last_timing(const gpsacq_engine* e, gpsacq_timing* t);
+/* ... and of the search n_back calls earlier (0 = last; the 8 most recent are kept): lets a caller
+ * that enqueues searches with sync = 0 read a finished search's times while the next one runs */
+int gpsacq_timing_ago(const gpsacq_engine* e, int n_back, gpsacq_timing* t);
+/* the engine's HIP stream (a hipStream_t) for callers that order their own device work after an
+ * asynchronous gpsacq_*_device call with an event instead of a host wait; NULL for a NULL engine */
+void* gpsacq_stream(gpsacq_engine* e);
 
 /*
  * 8-bit IQ capture -> the 1-bit real-IF stream gpsacq_search() takes.  format GPSACQ_IQ_U8: rtl-sdr

@@ -243,3 +243,41 @@ def test_device_entry_point_and_task_bounds():
         # host task lists are still rejected up front
         with pytest.raises(gpsacq.GpsAcqError):
             eng.search(bits, tasks=[(3, 8)])
+
+
+def test_async_searches_timing_ring_and_stream():
+    """Searches enqueued with sync=0 on the engine's stream: results read on another stream after an
+    event wait equal the synchronous ones; gpsacq_timing_ago() keeps the last 8 searches apart."""
+    import torch
+    import gpsacq
+    with gpsacq.Engine(4.092e6, 5.456e6, 5000.0) as eng:
+        with pytest.raises(gpsacq.GpsAcqError):
+            eng.last_timing()  # nothing has run yet
+        n = 64
+        bits = eng.generate(n * 5120, [(3, 0.2, -1500.0, 100.0, 0.0)], seed=11)
+        _, want = eng.search(bits, want_cells=False)
+        assert eng.last_timing()["cells"] == n * eng.num_doppler
+        d_bits = torch.from_numpy(bits).cuda()
+        stream = torch.cuda.ExternalStream(eng.stream_ptr)
+        assert eng.stream_ptr != 0
+        bufs = [torch.zeros(n * 4, dtype=torch.int32, device="cuda") for _ in range(3)]
+        half = torch.zeros((n // 2) * 4, dtype=torch.int32, device="cuda")
+        copies = []
+        for b in bufs:
+            eng.search_device(d_bits.data_ptr(), n, b.data_ptr(), sync=False)
+            ev = torch.cuda.Event()
+            ev.record(stream)
+            torch.cuda.current_stream().wait_event(ev)
+            copies.append(b.clone())
+        eng.search_device(d_bits.data_ptr(), n // 2, half.data_ptr(), sync=False)
+        t0, t1 = eng.last_timing(0), eng.last_timing(1)
+        assert t0["cells"] == (n // 2) * eng.num_doppler and t1["cells"] == n * eng.num_doppler
+        assert 0 < t0["ms_correlate"] < t1["ms_correlate"] * 1.5 and t1["ms_total"] >= t1["ms_correlate"]
+        with pytest.raises(gpsacq.GpsAcqError):
+            eng.last_timing(8)
+        with pytest.raises(gpsacq.GpsAcqError):
+            eng.last_timing(5)  # only 5 searches so far (indices 0..4)
+        torch.cuda.synchronize()
+        for c in copies:
+            assert np.array_equal(c.cpu().numpy().view(gpsacq.PEAK_DTYPE), want)
+        assert np.array_equal(half.cpu().numpy().view(gpsacq.PEAK_DTYPE), want[:n // 2])
