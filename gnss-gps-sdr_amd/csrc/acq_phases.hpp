@@ -66,17 +66,34 @@ ACQ_HD void corr_phase1(int tid, int q, int dop, const cf* __restrict__ dpp, con
     if (tid >= NBF3) return;
     int qp, c;
     shift_split(q, dop, qp, c);
-    const cf* drow = dpp + q * M_SUB + 2 * tid;
-    const cf* crw = cpp + (long)qp * crow + halo + c + 2 * tid;
     cf x0[RA], x1[RA];
     constexpr int PER = RA / NB;
+#if defined(__HIP_DEVICE_COMPILE__)
+    // Buffer loads: address = descriptor base + SGPR offset (row of this q / shift, scalar adds) +
+    // one 32-bit lane offset, so the 20 loads need no 64-bit vector address arithmetic
+    // (global_load's 13-bit immediate cannot span the 8000-byte row stride: 32 v_add_co/v_addc per
+    // sub-transform otherwise).  Descriptors cover one block spectrum / one PRN's code rows.
+    const __amdgpu_buffer_rsrc_t rd = __builtin_amdgcn_make_buffer_rsrc((void*)dpp, 0, NPOLY * M_SUB * (int)sizeof(cf), 0x00020000);
+    const __amdgpu_buffer_rsrc_t rc = __builtin_amdgcn_make_buffer_rsrc((void*)cpp, 0, NPOLY * crow * (int)sizeof(cf), 0x00020000);
+    const int sd = q * M_SUB * (int)sizeof(cf), sc = (qp * crow + halo + c) * (int)sizeof(cf);
+    const int lane = 2 * tid * (int)sizeof(cf);
+#else
+    const cf* drow = dpp + q * M_SUB + 2 * tid;
+    const cf* crw = cpp + (long)qp * crow + halo + c + 2 * tid;
+#endif
 #pragma unroll
     for (int b = 0; b < NB; ++b) {
         cf2 d[PER], cc[PER];
 #pragma unroll
         for (int i = 0; i < PER; ++i) {
+#if defined(__HIP_DEVICE_COMPILE__)
+            constexpr int ROW = NBF1 * (int)sizeof(cf);
+            d[i] = __builtin_bit_cast(cf2, __builtin_amdgcn_raw_buffer_load_b128(rd, lane, sd + ROW * (b * PER + i), 0));
+            cc[i] = __builtin_bit_cast(cf2, __builtin_amdgcn_raw_buffer_load_b128(rc, lane, sc + ROW * (b * PER + i), 0));
+#else
             d[i] = *reinterpret_cast<const cf2*>(drow + NBF1 * (b * PER + i));
             cc[i] = *reinterpret_cast<const cf2_a8*>(crw + NBF1 * (b * PER + i));  // arbitrary shift: 8-byte aligned only
+#endif
         }
         ACQ_SCHED_FENCE();
 #pragma unroll

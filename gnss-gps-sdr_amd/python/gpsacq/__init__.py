@@ -60,6 +60,23 @@ EXPORTS = ["gpsacq_generate", "gpsacq_generate_device", "gpsacq_handoff", "gpsac
 _lib = None
 
 
+def _preload_torch():
+    """PyTorch-ROCm wheels bundle their own HIP and HSA runtimes.  If libgpsacq (linked against
+    /opt/rocm) is the first to load an HSA runtime, a later torch.cuda initialisation in the same
+    process finds no GPU; with torch's libraries loaded first both HIP runtimes share one HSA
+    runtime and coexist (measured on the MI355X box, both orders).  So: if torch is installed and
+    not yet imported, import it before the dlopen.  GPSACQ_NO_TORCH_PRELOAD=1 skips this."""
+    import importlib.util
+    import sys
+    if "torch" in sys.modules or os.environ.get("GPSACQ_NO_TORCH_PRELOAD"):
+        return
+    try:
+        if importlib.util.find_spec("torch") is not None:
+            import torch  # noqa: F401
+    except Exception:
+        pass
+
+
 def load_library(path=None):
     """dlopen libgpsacq.so and declare the prototypes.  Raises OSError if it is not built."""
     global _lib
@@ -69,6 +86,7 @@ def load_library(path=None):
     if not os.path.exists(p):
         raise OSError(f"{p} not found: build it with `make lib` (hipcc --offload-arch=gfx950); "
                       "gpsacq has no CPU fallback")
+    _preload_torch()
     lib = ctypes.CDLL(p)
     vp, sz = ctypes.c_void_p, ctypes.c_size_t
     lib.gpsacq_create.argtypes = [ctypes.POINTER(Params), ctypes.POINTER(vp)]
