@@ -45,6 +45,31 @@ def synth_sats(seed):
     return prns, [(prn, 0.151, float(rs.uniform(-4500, 4500)), float(rs.uniform(0, 5456)), float(rs.random())) for prn in prns]
 
 
+def cpu_model():
+    try:
+        for line in open("/proc/cpuinfo"):
+            if line.startswith("model name"):
+                return line.split(":", 1)[1].strip()
+    except OSError:
+        pass
+    return "unknown CPU"
+
+
+def hbm_copy_gbs(torch, dev, nbytes=1 << 30, reps=5):
+    """Device-to-device copy rate (read + write bytes per second) as the measured counterpart of the
+    8 TB/s vendor peak (SURVEY.md section 8d asks for both)."""
+    a = torch.empty(nbytes, dtype=torch.uint8, device=dev)
+    b = torch.empty_like(a)
+    b.copy_(a)
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(reps):
+        b.copy_(a)
+    e1.record()
+    e1.synchronize()
+    return 2.0 * nbytes * reps / (e0.elapsed_time(e1) * 1e-3) / 1e9
+
+
 def cpu_baseline(bits, target_s=12.0):
     """The oracle's float build (own mixed-radix FFT; `port`) timed single-threaded on a
     bounded sample of the same workload."""
@@ -59,7 +84,7 @@ def cpu_baseline(bits, target_s=12.0):
     dt = time.perf_counter() - t0
     return {"value": cells / dt, "unit": "cells/s", "cores": 1, "kind": "port",
             "sample": f"{nblk} blocks x 73 bins = {cells} cells of the same capture, oracle f32 build (own FFT, -O3), "
-                      f"{dt:.1f} s on {os.cpu_count()} core host, 1 thread"}
+                      f"{dt:.1f} s on {os.cpu_count()} core host ({cpu_model()}), 1 thread"}
 
 
 def cpu_baseline_all_cores(bits, single_rate, target_s=8.0):
@@ -265,6 +290,7 @@ def main():
             # after the all-reduce the per-PRN best covers every rank's capture (rank r: seed 1000 + r)
             out["injected_prns_all_ranks"] = sorted(set().union(*[synth_sats(1000 + r)[0] for r in range(world)]))
         if world == 1 and not args.no_cpu_baseline:
+            out["roofline"]["hbm_copy_measured_GBs"] = hbm_copy_gbs(torch, dev)
             out["cpu_baseline"] = cpu_baseline(host_bits)
             try:
                 out["cpu_baseline_all_cores"] = cpu_baseline_all_cores(host_bits, out["cpu_baseline"]["value"])
