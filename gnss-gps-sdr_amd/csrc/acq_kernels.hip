@@ -94,11 +94,15 @@ __global__ __launch_bounds__(WG) void k_quirk_patch(QuirkArgs a) {
 // One workgroup per (task, Doppler bin).  blockIdx -> cell map keeps the 2*dmax+1 cells of a
 // task on one XCD (block b runs on XCD b % 8) so both spectra are read from that XCD's L2.
 // NC = true: non-coherent mode (no reference equivalent): the powers |y[n]|^2
+// are summed in an LDS array indexed by lag, so that block k's lags can be re-aligned by the whole
+// samples the code has crept since block 0 at this cell's Doppler (a.creep samples per block per bin;
+// 0 = plain sum): power of lag n goes to lag (n - round(k * creep * dop)) mod S.
 // of a.n_acc consecutive block spectra (a.acc_step apart) are summed per lag before the peak scan.
 template <int MC, int WPS, int NB, bool NC>
 __global__ __launch_bounds__(WG, WPS) void k_corr(CorrArgs a) {
     __shared__ cf lds[M_SUB];  // transform buffer
     __shared__ cf t2s[NT2];    // the 500 pass-2 twiddles
+    __shared__ float pws[NC ? MC * NBF3 : 1];  // non-coherent power per lag of this pass
     const int tid = threadIdx.x;
     const int g = blockIdx.x, xcd = g & 7, slot = g >> 3;
     const int grp = slot / a.ndop, di = slot - grp * a.ndop;
@@ -130,10 +134,9 @@ __global__ __launch_bounds__(WG, WPS) void k_corr(CorrArgs a) {
 #pragma unroll
     for (int m = 0; m < MC; ++m) acc[m] = mk(0.f, 0.f);
 
-    float pw[NC ? MC : 1];
-    if (NC) {
+    if (NC && tid < NBF3) {
 #pragma unroll
-        for (int m = 0; m < MC; ++m) pw[m] = 0.f;
+        for (int m = 0; m < MC; ++m) pws[NBF3 * m + tid] = 0.f;  // first read-modify-write is >= 3 barriers away
     }
     const int t3 = tid < NBF3 ? tid : 0;
     const int n_acc = NC ? a.n_acc : 1;
@@ -152,17 +155,18 @@ __global__ __launch_bounds__(WG, WPS) void k_corr(CorrArgs a) {
             __syncthreads();
         }
         if (NC) {
-#pragma unroll
-            for (int m = 0; m < MC; ++m) {
-                pw[m] += acc[m].x * acc[m].x + acc[m].y * acc[m].y;
-                acc[m] = mk(0.f, 0.f);
-            }
+            // every lag has one owner per block, so the scatter needs no atomics; successive blocks'
+            // updates are separated by the barriers of the next 8 sub-transforms
+            corr_accumulate_power<MC>(tid, a.nlags, a.m0, __float2int_rn((float)k * a.creep * (float)dop), acc, pws);
         }
     }
 
     float mx, sum;
     int mi;
-    if (NC) corr_scan_power<MC>(tid, a.nlags, a.m0, pw, mx, mi, sum);
+    if (NC) {
+        __syncthreads();  // the last block's scatter
+        corr_scan_power<MC>(tid, a.nlags, a.m0, pws, mx, mi, sum);
+    }
     else corr_scan<MC>(tid, a.nlags, a.m0, acc, mx, mi, sum);
     // wave reduction (64 lanes), then across the 4 waves through LDS
 #pragma unroll
@@ -275,7 +279,7 @@ int launch_corr(const CorrArgs& a, int mc, hipStream_t s) {
             else hipLaunchKernelGGL((k_corr<33, 2, 2, false>), grid, block, 0, s, a);
             break;
         case 40:
-            if (a.n_acc > 1) hipLaunchKernelGGL((k_corr<40, 2, 2, true>), grid, block, 0, s, a);
+            if (a.n_acc > 1) hipLaunchKernelGGL((k_corr<40, 1, 2, true>), grid, block, 0, s, a);  // 84 KB of LDS: one workgroup per CU
             else hipLaunchKernelGGL((k_corr<40, 2, 2, false>), grid, block, 0, s, a);
             break;
         default: return -1;

@@ -42,6 +42,7 @@ struct CorrArgs {
     int n_tasks, ndop, dop_first, nlags, crow, halo;  // bins dop_first .. dop_first+ndop-1
     int m0;               // first accumulator column of this pass (multiple of 40; 0 unless fs > 10 MHz)
     int n_acc, acc_step;  // non-coherent mode: spectra tk.spec + k*acc_step, k < n_acc (n_acc = 1: coherent)
+    float creep;          // non-coherent mode: code creep in samples per accumulated block per Doppler bin (0 = off)
     int n_spec, n_code;   // rows of dpp / cpp: tasks pointing outside get an empty cell (max_i = -1)
 };
 

@@ -142,9 +142,29 @@ ACQ_HD void corr_scan(int tid, int S, int m0, const cf* acc, float& mx, int& mi,
         sum += p;
     }
 }
-// same scan over summed powers (non-coherent mode)
+// non-coherent mode: add this block's powers into the per-lag array pws (lag n of this pass at
+// pws[n - 250 m0]), moved down by `shift` whole samples modulo the S lags (shift = 0 when the search
+// takes several passes, m0 > 0), and clear the accumulators for the next block
 template <int MC>
-ACQ_HD void corr_scan_power(int tid, int S, int m0, const float* pw, float& mx, int& mi, float& sum) {
+ACQ_HD void corr_accumulate_power(int tid, int S, int m0, int shift, cf* acc, float* pws) {
+    if (tid >= NBF3) return;
+    const int rho = pass3_rho(tid);
+    int sh = shift % S;
+    if (sh < 0) sh += S;
+#pragma unroll
+    for (int m = 0; m < MC; ++m) {
+        const int n = NBF3 * (m0 + m) + rho;
+        if (n < S) {
+            int j = n - sh;
+            if (j < 0) j += S;
+            pws[j - NBF3 * m0] += acc[m].x * acc[m].x + acc[m].y * acc[m].y;
+        }
+        acc[m] = mk(0.f, 0.f);
+    }
+}
+// same scan as corr_scan over the summed powers
+template <int MC>
+ACQ_HD void corr_scan_power(int tid, int S, int m0, const float* pws, float& mx, int& mi, float& sum) {
     mx = 0.f;
     mi = 0;
     sum = 0.f;
@@ -153,7 +173,7 @@ ACQ_HD void corr_scan_power(int tid, int S, int m0, const float* pw, float& mx, 
 #pragma unroll
     for (int m = 0; m < MC; ++m) {
         const int n = NBF3 * (m0 + m) + rho;
-        const float p = (n < S) ? pw[m] : 0.f;
+        const float p = (n < S) ? pws[n - NBF3 * m0] : 0.f;
         const bool up = p > mx;
         mx = up ? p : mx;
         mi = up ? n : mi;

@@ -44,6 +44,7 @@ struct gpsacq_engine {
     gpsacq_params p{};
     int dmax = 0, ndop = 0, dop_first = 0, nlags = 0, mc = 0, halo = 0, crow = 0;  // searched bins: dop_first .. +ndop-1
     int n_acc = 1, acc_step = 0;  // non-coherent accumulation (gpsacq_set_noncoherent)
+    bool creep_comp = false;      // re-align accumulated blocks by the code creep of each Doppler bin
     int cus = 0;
     char name[64] = {0};
     hipStream_t stream = nullptr;
@@ -376,11 +377,15 @@ static int search_core(gpsacq_engine* e, const uint8_t* d_bits, size_t n_blocks,
     ca.n_acc = e->n_acc;
     ca.acc_step = e->acc_step;
     ca.n_spec = (int)n_blocks;
+    ca.creep = 0.f;
     ca.n_code = GPSACQ_NUM_SATS + (int)e->patch_cap;
     const int n_cols = (e->nlags + NBF3 - 1) / NBF3;
     const int n_pass = (n_cols + MC_MAX - 1) / MC_MAX;  // 1 up to 10000 lags (fs <= 10 MHz)
     if (n_pass == 1) {
         ca.m0 = 0;
+        // samples the code advances per accumulated block per Doppler bin: elapsed samples x (bin Hz / L1)
+        if (e->creep_comp && e->n_acc > 1)
+            ca.creep = (float)((double)e->acc_step * (double)stride * 8.0 * (e->p.fs / N_FFT) / 1575.42e6);
         if (launch_corr(ca, e->mc, e->stream) != 0) return fail(GPSACQ_ERR_UNSUPPORTED, "no correlate kernel for %d columns", e->mc);
     } else {
         const size_t n_cells = n_tasks * (size_t)e->ndop;
@@ -438,6 +443,12 @@ extern "C" int gpsacq_set_noncoherent(gpsacq_engine* e, int n_acc, int block_ste
     e->n_acc = n_acc;
     e->acc_step = n_acc > 1 ? block_step : 0;
     e->sched_valid = false;
+    return GPSACQ_OK;
+}
+
+extern "C" int gpsacq_set_creep_compensation(gpsacq_engine* e, int on) {
+    if (!e) return fail(GPSACQ_ERR_ARG, "gpsacq_set_creep_compensation: null engine");
+    e->creep_comp = on != 0;
     return GPSACQ_OK;
 }
 

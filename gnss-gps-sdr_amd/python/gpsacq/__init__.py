@@ -54,7 +54,7 @@ class Sat(ctypes.Structure):
 
 
 EXPORTS = ["gpsacq_generate", "gpsacq_generate_device", "gpsacq_handoff", "gpsacq_iq8_to_bits", "gpsacq_iq8_to_bits_device", "gpsacq_create", "gpsacq_destroy", "gpsacq_last_error", "gpsacq_get_info", "gpsacq_search",
-           "gpsacq_search_device", "gpsacq_set_doppler_window", "gpsacq_set_noncoherent", "gpsacq_aligned_stride", "gpsacq_synchronize", "gpsacq_last_timing", "gpsacq_timing_ago", "gpsacq_stream", "gpsacq_search_code",
+           "gpsacq_search_device", "gpsacq_set_doppler_window", "gpsacq_set_noncoherent", "gpsacq_set_creep_compensation", "gpsacq_aligned_stride", "gpsacq_synchronize", "gpsacq_last_timing", "gpsacq_timing_ago", "gpsacq_stream", "gpsacq_search_code",
            "gpsacq_sample_spectrum", "gpsacq_code_spectrum"]
 
 _lib = None
@@ -111,6 +111,8 @@ def load_library(path=None):
     lib.gpsacq_synchronize.restype = ctypes.c_int
     lib.gpsacq_last_timing.argtypes = [vp, ctypes.POINTER(Timing)]
     lib.gpsacq_last_timing.restype = ctypes.c_int
+    lib.gpsacq_set_creep_compensation.argtypes = [vp, ctypes.c_int]
+    lib.gpsacq_set_creep_compensation.restype = ctypes.c_int
     lib.gpsacq_timing_ago.argtypes = [vp, ctypes.c_int, ctypes.POINTER(Timing)]
     lib.gpsacq_timing_ago.restype = ctypes.c_int
     lib.gpsacq_stream.argtypes = [vp]
@@ -193,6 +195,10 @@ class Engine:
     def set_noncoherent(self, n_acc, block_step=1):
         """Sum |IFFT|^2 over n_acc blocks (block_step apart) per cell before the peak scan; 1 = reference."""
         _check(self._lib, self._lib.gpsacq_set_noncoherent(self._h, int(n_acc), int(block_step)))
+
+    def set_creep_compensation(self, on=True):
+        """Non-coherent mode: re-align each accumulated block by the code creep of the cell's Doppler bin."""
+        _check(self._lib, self._lib.gpsacq_set_creep_compensation(self._h, 1 if on else 0))
 
     def aligned_stride(self):
         """Bytes between block starts that keep lags aligned for non-coherent sums (whole C/A periods)."""

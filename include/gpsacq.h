@@ -154,6 +154,18 @@ int gpsacq_set_doppler_window(gpsacq_engine* e, int first_bin, int n_bins);
  * t < n_tasks <= n_blocks - (n_acc-1)*block_step.
  */
 int gpsacq_set_noncoherent(gpsacq_engine* e, int n_acc, int block_step);
+/*
+ * Code-creep compensation for the non-coherent mode (off by default).  A carrier offset f -- true
+ * Doppler, or the crystal error of a single-oscillator front end such as the rtl-sdr, which is what
+ * the +-100 kHz search range is for -- comes with a code-rate offset f/L1, so the correlation peak of
+ * accumulated block k sits k * T * f / L1 samples later than block 0's (T = samples between
+ * accumulated blocks = block_step * stride * 8): 1.07 samples per block at 40 kHz and fs = 2.8 MHz.
+ * With compensation on, block k's powers are moved back by round(k * c * bin) whole samples (modulo
+ * the fs/1000 lags) before they are summed, c = T * (fs/40000) / 1575.42e6 in float, bin = the cell's
+ * Doppler bin; ca_shift then refers to block 0.  Ignored (plain sum) when fs > 10 MHz (more than
+ * 10000 lags are searched in several passes).
+ */
+int gpsacq_set_creep_compensation(gpsacq_engine* e, int on);
 int gpsacq_aligned_stride(const gpsacq_engine* e);
 int gpsacq_synchronize(gpsacq_engine* e);
 /* stage times of the most recent search (waits for it to finish) ... */

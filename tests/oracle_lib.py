@@ -51,6 +51,7 @@ def _p(a):
 class Oracle:
     def __init__(self, fc, fs, max_fo=5000.0, ref_quirks=False, kind="f64"):
         self.L = lib(kind)
+        self.fs = float(fs)
         self.h = self.L.oracle_create(fc, fs, max_fo, 1 if ref_quirks else 0)
         self.dmax = self.L.oracle_get_dmax(self.h)
         self.num_doppler = 2 * self.dmax + 1
@@ -96,9 +97,11 @@ class Oracle:
             peaks[t] = p
         return cells, peaks
 
-    def search_noncoherent(self, bits, stride, first_block, sv, n_acc, block_step, first_bin=None, n_bins=None):
+    def search_noncoherent(self, bits, stride, first_block, sv, n_acc, block_step, first_bin=None, n_bins=None, creep=False):
         """Restatement of the non-coherent extension: per Doppler bin, sum |IFFT|^2 per lag over
-        n_acc blocks, then the reference's scan (:190-196) over the sum."""
+        n_acc blocks, then the reference's scan (:190-196) over the sum.  creep: block k's powers are
+        first moved back by round(k * c * bin) samples modulo the S lags, c = float32(samples between
+        accumulated blocks * (fs / 40000) / L1) -- the product's code-creep compensation."""
         buf = np.frombuffer(bits, dtype=np.uint8)
         S = self.num_lags
         first_bin = -self.dmax if first_bin is None else first_bin
@@ -111,9 +114,11 @@ class Oracle:
             if blk.size < 5120:
                 blk = np.concatenate([blk, np.zeros(5120 - blk.size, np.uint8)])
             self.L.oracle_sample(self.h, _p(blk))
+            c = np.float32(float(block_step) * float(stride) * 8.0 * (self.fs / 40000.0) / 1575.42e6)
             for d in range(first_bin, first_bin + n_bins):
                 self.L.oracle_cell_power(self.h, sv, d, _p(tmp))
-                power[d - first_bin] += tmp
+                shift = int(np.rint(np.float32(k) * c * np.float32(d))) if creep else 0
+                power[d - first_bin] += np.roll(tmp, -shift)  # lag n -> (n - shift) mod S
         cells = np.zeros(n_bins, CELL_DTYPE)
         cells["max_pwr"] = power.max(axis=1)
         cells["max_i"] = power.argmax(axis=1)
