@@ -216,25 +216,46 @@ __global__ void k_merge_cells(const Cell* parts, Cell* cells, size_t n_cells, in
     cells[i] = c;
 }
 
-// Best SNR over the Doppler bins of each task, ascending dop, strict '>' (:196-198).
-__global__ void k_peaks(const Cell* cells, Peak* peaks, int n_tasks, int ndop, int dop_first) {
-    const int task = blockIdx.x * blockDim.x + threadIdx.x;
+// Best SNR over the Doppler bins of each task: the reference scans dop ascending with a strict '>'
+// (:196-198), i.e. the largest SNR wins and ties go to the lowest bin.  One wavefront per task: lane l
+// scans bins l, l + 64, ... (ascending, strict '>'), then the lanes merge with the same rule.
+__global__ __launch_bounds__(WG) void k_peaks(const Cell* cells, Peak* peaks, int n_tasks, int ndop, int dop_first) {
+    const int lane = threadIdx.x & 63;
+    const int task = blockIdx.x * (WG / 64) + (threadIdx.x >> 6);
     if (task >= n_tasks) return;
     const Cell* c = cells + (size_t)task * ndop;
-    Peak p;
-    p.snr = 0.f;
-    p.lo_shift = 0;
-    p.ca_shift = 0;
-    p.max_pwr = 0.f;
-    for (int di = 0; di < ndop; ++di) {
-        if (c[di].snr > p.snr) {
-            p.snr = c[di].snr;
-            p.lo_shift = di + dop_first;
-            p.ca_shift = c[di].max_i;
-            p.max_pwr = c[di].max_pwr;
+    float snr = 0.f;
+    int best = -1;  // -1: no bin with snr > 0 (the reference would leave its outputs untouched)
+    for (int di = lane; di < ndop; di += 64) {
+        const float s = c[di].snr;
+        if (s > snr) {
+            snr = s;
+            best = di;
         }
     }
-    peaks[task] = p;
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) {
+        const float os = __shfl_down(snr, off, 64);
+        const int ob = __shfl_down(best, off, 64);
+        if (ob >= 0 && (os > snr || (os == snr && (best < 0 || ob < best)))) {
+            snr = os;
+            best = ob;
+        }
+    }
+    if (lane == 0) {
+        Peak p;
+        p.snr = 0.f;
+        p.lo_shift = 0;
+        p.ca_shift = 0;
+        p.max_pwr = 0.f;
+        if (best >= 0) {
+            p.snr = snr;
+            p.lo_shift = best + dop_first;
+            p.ca_shift = c[best].max_i;
+            p.max_pwr = c[best].max_pwr;
+        }
+        peaks[task] = p;
+    }
 }
 
 // ---------------------------------------------------------------------------------------
@@ -290,7 +311,8 @@ void launch_merge_cells(const Cell* parts, Cell* cells, size_t n_cells, int n_pa
     hipLaunchKernelGGL(k_merge_cells, dim3((unsigned)((n_cells + 255) / 256)), dim3(256), 0, s, parts, cells, n_cells, n_parts, nlags);
 }
 void launch_peaks(const Cell* cells, Peak* peaks, int n_tasks, int ndop, int dop_first, hipStream_t s) {
-    hipLaunchKernelGGL(k_peaks, dim3((n_tasks + 255) / 256), dim3(256), 0, s, cells, peaks, n_tasks, ndop, dop_first);
+    const int per_wg = WG / 64;
+    hipLaunchKernelGGL(k_peaks, dim3((n_tasks + per_wg - 1) / per_wg), dim3(WG), 0, s, cells, peaks, n_tasks, ndop, dop_first);
 }
 
 }  // namespace acq
