@@ -61,11 +61,13 @@ _lib = None
 
 
 def _preload_torch():
-    """PyTorch-ROCm wheels bundle their own HIP and HSA runtimes.  If libgpsacq (linked against
-    /opt/rocm) is the first to load an HSA runtime, a later torch.cuda initialisation in the same
-    process finds no GPU; with torch's libraries loaded first both HIP runtimes share one HSA
-    runtime and coexist (measured on the MI355X box, both orders).  So: if torch is installed and
-    not yet imported, import it before the dlopen.  GPSACQ_NO_TORCH_PRELOAD=1 skips this."""
+    """PyTorch-ROCm wheels bundle their own libamdhip64.so (SONAME libamdhip64.so.7, the same as
+    /opt/rocm's).  Loaded first, torch's copy satisfies libgpsacq's NEEDED libamdhip64.so.7 by SONAME
+    and the process has ONE HIP runtime (streams and events are then interchangeable, which
+    bench.py relies on).  Loaded second, torch asks for the file name `libamdhip64.so`, gets its own
+    second copy next to /opt/rocm's, and its CUDA initialisation finds no GPU (measured on the
+    MI355X box, both orders).  So: if torch is installed and not yet imported, import it before the
+    dlopen.  GPSACQ_NO_TORCH_PRELOAD=1 skips this."""
     import importlib.util
     import sys
     if "torch" in sys.modules or os.environ.get("GPSACQ_NO_TORCH_PRELOAD"):
