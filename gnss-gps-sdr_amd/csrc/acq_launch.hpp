@@ -14,7 +14,9 @@ struct FwdArgs {
     const uint64_t* sin_t;
     const cf* t1;
     const cf* t2;
-    const cf* tn;
+    const cf* tn;        // [sub][8][5000] W_N^{n' (kappa + r/sub)}
+    const cf* rot8;      // [sub][8][8]    exp(-2 pi i nu (kappa + r/sub) / 8)   (bits source only)
+    int sub;             // spectra per source item (sub-bin Doppler offsets r/sub, r < sub); item i -> (source i / sub, r = i % sub)
     cf* out;             // [n_items][item_stride], polyphase rows
     size_t item_stride;  // complex elements per item in out
     long row;            // elements per polyphase row in out
@@ -37,6 +39,7 @@ struct CorrArgs {
     const Task* tasks; // [n_tasks]
     const cf* t1;
     const cf* t2;
+    const cf* t2u;     // pass-2 twiddles in order of use (k_corr2)
     const cf* bq;
     Cell* cells;       // [n_tasks][ndop]
     int n_tasks, ndop, dop_first, nlags, crow, halo;  // bins dop_first .. dop_first+ndop-1
@@ -44,6 +47,9 @@ struct CorrArgs {
     int n_acc, acc_step;  // non-coherent mode: spectra tk.spec + k*acc_step, k < n_acc (n_acc = 1: coherent)
     float creep;          // non-coherent mode: code creep in samples per accumulated block per Doppler bin (0 = off)
     int n_spec, n_code;   // rows of dpp / cpp: tasks pointing outside get an empty cell (max_i = -1)
+    int sub, dstride;     // Doppler grid (acq_phases.hpp grid_point): dop_first/ndop count grid points; spectrum of (block, r) at row block*sub + r
+    int nchunk;           // k_corr2: workgroups per task; each takes a contiguous share of the ndop bins
+    unsigned long long* prof;  // k_corr2<PROF>: [16] accumulated s_memtime deltas (experiments only), else NULL
 };
 
 void launch_fwd_bits(const FwdArgs& a, int n_items, hipStream_t s);

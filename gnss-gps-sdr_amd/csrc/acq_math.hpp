@@ -38,6 +38,16 @@
 #define ACQ_PK_ASM 0
 #endif
 
+// Timing-only ablation builds (tools/ablate.sh; WRONG results, never shipped): ACQ_ABL = 6 drops pass 1's LDS stores,
+// 7 pass 2's stores, 8 pass 3's LDS reads, 9 pass 2's reads (data + twiddles); the arithmetic is kept alive by empty asm sinks.
+#ifndef ACQ_ABL
+#define ACQ_ABL 0
+#endif
+#if ACQ_ABL && defined(__HIP_DEVICE_COMPILE__)
+#define ACQ_SINK(v) asm volatile("" ::"v"(v))
+#define ACQ_JUNK(v) asm volatile("" : "=v"(v))
+#endif
+
 namespace acq {
 
 constexpr int N_FFT = 40000;  // FFT_LEN, c/gps_offline.h:15
@@ -319,9 +329,16 @@ template <int DIR> ACQ_HD void pass1_store(const cf* x, int jp, const cf* w, cf*
     radix10<DIR>(x, y);
     const int b = jp / RC, jpp = jp - b * RC;
     cf* dst = lds + RB * jpp + b;
+#if ACQ_ABL == 6 && defined(__HIP_DEVICE_COMPILE__)
+    ACQ_SINK(y[0]);
+#pragma unroll
+    for (int al = 1; al < RA; ++al) { cf v = tw<DIR>(y[al], w[al - 1]); ACQ_SINK(v); }
+    (void)dst;
+#else
     dst[0] = y[0];
 #pragma unroll
     for (int al = 1; al < RA; ++al) dst[NBF1 * al] = tw<DIR>(y[al], w[al - 1]);
+#endif
 }
 
 // pass 2 for butterfly e (0..199), in place; t2 may live in LDS (its own allocation, so the
@@ -343,8 +360,14 @@ template <int DIR> ACQ_HD void pass3_load(int t3, const cf* lds, cf* y) {
     const int al = t3 / RB, be = t3 - al * RB;
     const cf* p = lds + NBF1 * al + be;
     cf x[RC];
+#if ACQ_ABL == 8 && defined(__HIP_DEVICE_COMPILE__)
+    (void)p;
+#pragma unroll
+    for (int jpp = 0; jpp < RC; ++jpp) ACQ_JUNK(x[jpp]);
+#else
 #pragma unroll
     for (int jpp = 0; jpp < RC; ++jpp) x[jpp] = p[RB * jpp];
+#endif
     radix20<DIR>(x, y);
 }
 ACQ_HD int pass3_rho(int t3) {

@@ -8,7 +8,7 @@
 #include <cstring>
 #include <vector>
 
-#include "acq_math.hpp"
+#include "acq_phases.hpp"
 
 namespace acq {
 
@@ -23,22 +23,40 @@ inline cf unit_fwd(long long num, long long den) {  // exp(-2 pi i num/den)
 struct Tables {
     std::vector<cf> t1;  // [10][500]   W_5000^{j' alpha}
     std::vector<cf> t2;  // [25][20]    W_500^{j'' beta}
+    std::vector<cf> t2u; // [20][26]    the same values per j'' in pass2_pipe's order of use (acq_phases.hpp)
     std::vector<cf> bq;  // [8][250]    W_40000^{q rho(t3)}, rho = 10 (t3 % 25) + t3 / 25
     std::vector<cf> wq;  // [8][40]     W_160^{q m}
     std::vector<cf> tn;  // [8][5000]   W_40000^{n' kappa}: forward transform's decimation-in-frequency twiddle
-    Tables() : t1(RA * NBF1), t2((size_t)NT2), bq((size_t)NPOLY * NBF3), wq(NPOLY * WQ_STRIDE), tn((size_t)NPOLY * M_SUB) {
+    Tables() : t1(RA * NBF1), t2((size_t)NT2), t2u((size_t)NT2U, mk(1.f, 0.f)), bq((size_t)NPOLY * NBF3), wq(NPOLY * WQ_STRIDE), tn((size_t)NPOLY * M_SUB) {
         for (int ka = 0; ka < NPOLY; ++ka)
             for (int n = 0; n < M_SUB; ++n) tn[(size_t)ka * M_SUB + n] = unit_fwd((long long)n * ka, N_FFT);
         for (int al = 0; al < RA; ++al)
             for (int jp = 0; jp < NBF1; ++jp) t1[al * NBF1 + jp] = unit_fwd((long long)jp * al, M_SUB);
         for (int be = 0; be < RB; ++be)
             for (int jpp = 0; jpp < RC; ++jpp) t2[(size_t)be * RC + jpp] = unit_fwd((long long)jpp * be, NBF1);
+        for (int jpp = 0; jpp < RC; ++jpp)
+            for (int i = 0; i < 24; ++i) t2u[(size_t)jpp * T2U_ROW + i] = t2[(size_t)t2u_beta(i) * RC + jpp];
         for (int q = 0; q < NPOLY; ++q)
             for (int t3 = 0; t3 < NBF3; ++t3) bq[(size_t)q * NBF3 + t3] = unit_fwd((long long)q * pass3_rho(t3), N_FFT);
         for (int q = 0; q < NPOLY; ++q)
             for (int m = 0; m < WQ_STRIDE; ++m) wq[q * WQ_STRIDE + m] = unit_fwd((long long)q * m, NW160);
     }
 };
+
+// Forward-transform tables for `sub` sub-bin Doppler offsets r/sub (r < sub) of a bin (extension; the reference's grid is
+// sub = 1): spectrum r of a block is the transform of x[n] exp(-2 pi i (r/sub) n / N), i.e. the block's spectrum
+// evaluated r/sub of a bin higher, which the decimation-in-frequency split absorbs exactly into its twiddles:
+//   tn [r][kappa][n'] = exp(-2 pi i n' (kappa + r/sub) / N),   rot8[r][kappa][nu] = exp(-2 pi i nu (kappa + r/sub) / 8)
+inline void forward_tables(int sub, std::vector<cf>& tn, std::vector<cf>& rot8) {
+    tn.resize((size_t)sub * NPOLY * M_SUB);
+    rot8.resize((size_t)sub * NPOLY * NPOLY);
+    for (int r = 0; r < sub; ++r)
+        for (int ka = 0; ka < NPOLY; ++ka) {
+            const long long m = (long long)ka * sub + r;  // (kappa + r/sub) * sub
+            for (int n = 0; n < M_SUB; ++n) tn[((size_t)r * NPOLY + ka) * M_SUB + n] = unit_fwd((long long)n * m, (long long)N_FFT * sub);
+            for (int nu = 0; nu < NPOLY; ++nu) rot8[((size_t)r * NPOLY + ka) * NPOLY + nu] = unit_fwd((long long)nu * m, (long long)NPOLY * sub);
+        }
+}
 
 // ---- C/A code ------------------------------------------------------------------------
 // PRN -> G2 tap pair, c/search_offline.cpp:20-53 (the navstar column is unused there).

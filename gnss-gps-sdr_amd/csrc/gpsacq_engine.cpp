@@ -8,6 +8,7 @@
 #include <cmath>
 #include <cstdarg>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <string>
 #include <vector>
@@ -44,6 +45,9 @@ struct gpsacq_engine {
     gpsacq_params p{};
     int dmax = 0, ndop = 0, dop_first = 0, nlags = 0, mc = 0, halo = 0, crow = 0;  // searched bins: dop_first .. +ndop-1
     int n_acc = 1, acc_step = 0;  // non-coherent accumulation (gpsacq_set_noncoherent)
+    // Doppler grid (gpsacq_set_doppler_step): step = bin * dstride / sub, points -kmax..+kmax; sub = dstride = 1 is the reference's
+    int sub = 1, dstride = 1, kmax = 0;
+    cf* d_rot8 = nullptr;
     bool creep_comp = false;      // re-align accumulated blocks by the code creep of each Doppler bin
     int cus = 0;
     char name[64] = {0};
@@ -56,7 +60,7 @@ struct gpsacq_engine {
     int64_t ring_cells[kTimingRing] = {};
     long searches = 0;  // searches enqueued so far; search k uses ring slot k % kTimingRing
     // constants
-    cf *d_t1 = nullptr, *d_t2 = nullptr, *d_bq = nullptr, *d_tn = nullptr;
+    cf *d_t1 = nullptr, *d_t2 = nullptr, *d_t2u = nullptr, *d_bq = nullptr, *d_tn = nullptr;
     uint8_t *d_cos = nullptr, *d_sin = nullptr;
     uint64_t *d_cos_t = nullptr, *d_sin_t = nullptr;  // bit-transposed masks for k_fwd
     cf* d_code = nullptr;  // [32 + patch_cap][8][crow]
@@ -83,6 +87,7 @@ struct gpsacq_engine {
     size_t sats_cap = 0;
     uint8_t* d_gen = nullptr;
     size_t gen_cap = 0;
+    unsigned long long* d_prof = nullptr;  // GPSACQ_PROF=1: s_memtime phase profile of k_corr2<PROF> (kernel experiments)
     // cached default schedule
     size_t sched_tasks = 0;
     bool sched_valid = false;
@@ -118,19 +123,24 @@ static int ensure_code_slots(gpsacq_engine* e, size_t n_patch) {
 }
 
 // forward transforms of n items into out (polyphase layout)
-static int run_forward(gpsacq_engine* e, bool bits, const void* src, size_t src_stride, size_t n, cf* out,
+// (sub spectra per source item when bits: item i of the grid -> source i / sub, sub-bin offset i % sub)
+static int run_forward(gpsacq_engine* e, bool bits, const void* src, size_t src_stride, size_t n_src, cf* out,
                        size_t item_stride, long row, int off, bool conj_out) {
-    for (size_t base = 0; base < n; base += kFwdChunk) {  // grid.y bound
-        const size_t cnt = std::min(kFwdChunk, n - base);
+    const int sub = bits ? e->sub : 1;
+    const size_t chunk = kFwdChunk / (size_t)sub;  // sources per launch
+    for (size_t base = 0; base < n_src; base += chunk) {  // grid.y bound
+        const size_t cnt = std::min(chunk, n_src - base) * (size_t)sub;
         FwdArgs fa{};
         fa.src = bits ? (const void*)((const uint8_t*)src + base * src_stride) : (const void*)((const float*)src + base * src_stride);
         fa.src_stride = src_stride;
+        fa.sub = sub;
+        fa.rot8 = e->d_rot8;
         fa.cos_t = e->d_cos_t;
         fa.sin_t = e->d_sin_t;
         fa.t1 = e->d_t1;
         fa.t2 = e->d_t2;
         fa.tn = e->d_tn;
-        fa.out = out + base * item_stride;
+        fa.out = out + base * (size_t)sub * item_stride;
         fa.item_stride = item_stride;
         fa.row = row;
         fa.off = off;
@@ -148,7 +158,7 @@ extern "C" void gpsacq_destroy(gpsacq_engine* e) {
     if (!e) return;
     (void)hipSetDevice(e->p.device);
     if (e->stream) (void)hipStreamSynchronize(e->stream);
-    void* bufs[] = {e->d_t1, e->d_t2, e->d_bq, e->d_tn, e->d_cos, e->d_sin, e->d_cos_t, e->d_sin_t, e->d_code, e->d_patch_blocks, e->d_bits, e->d_iq, e->d_iqbits, e->d_sums, e->d_sats, e->d_gen,
+    void* bufs[] = {e->d_t1, e->d_t2, e->d_t2u, e->d_bq, e->d_tn, e->d_cos, e->d_sin, e->d_cos_t, e->d_sin_t, e->d_code, e->d_patch_blocks, e->d_bits, e->d_iq, e->d_iqbits, e->d_sums, e->d_sats, e->d_gen, e->d_prof, e->d_rot8,
                     e->d_dpp, e->d_parts, e->d_tasks, e->d_cells, e->d_peaks};
     for (void* b : bufs)
         if (b) (void)hipFree(b);
@@ -164,6 +174,9 @@ extern "C" int gpsacq_create(const gpsacq_params* params, gpsacq_engine** out) {
     *out = nullptr;
     if (!(params->fs > 0) || !(params->fc >= 0) || !(params->max_fo >= 0))
         return fail(GPSACQ_ERR_ARG, "gpsacq_create: need fs > 0, fc >= 0, max_fo >= 0");
+    // the quadrature LO steps 4 fc / fs quadrants per sample and wraps with ONE subtraction (:155-156): at fc >= fs the
+    // quadrant index leaves the 4-entry tables (undefined behaviour in the reference; rejected here)
+    if (!(params->fc < params->fs)) return fail(GPSACQ_ERR_ARG, "gpsacq_create: need fc < fs (fc = %g, fs = %g)", params->fc, params->fs);
     const int dmax = doppler_half_range(params->fs, params->max_fo);
     const int nlags = num_lags(params->fs);
     const int mc = corr_columns(nlags);
@@ -187,7 +200,8 @@ extern "C" int gpsacq_create(const gpsacq_params* params, gpsacq_engine** out) {
     e->dop_first = -dmax;
     e->nlags = nlags;
     e->mc = mc;
-    e->halo = ((dmax + 7) / 8 + 2 + 7) & ~7;  // |floor((q - dop)/8)| <= dmax/8 + 1
+    e->kmax = dmax;
+    e->halo = ((dmax + 1 + 7) / 8 + 2 + 7) & ~7;  // |floor((q - dop)/8)| <= (dmax + 1)/8 + 1 (a sub-bin grid reaches bin -(dmax + 1))
     e->crow = M_SUB + 2 * e->halo;
     e->cus = prop.multiProcessorCount;
     snprintf(e->name, sizeof e->name, "%s", prop.name);
@@ -207,8 +221,14 @@ extern "C" int gpsacq_create(const gpsacq_params* params, gpsacq_engine** out) {
     Tables T;
     HCK(hipMalloc((void**)&e->d_t1, T.t1.size() * sizeof(cf)));
     HCK(hipMalloc((void**)&e->d_t2, T.t2.size() * sizeof(cf)));
-    HCK(hipMalloc((void**)&e->d_tn, T.tn.size() * sizeof(cf)));
-    HCK(hipMemcpy(e->d_tn, T.tn.data(), T.tn.size() * sizeof(cf), hipMemcpyHostToDevice));
+    {
+        std::vector<cf> tn, rot8;
+        forward_tables(1, tn, rot8);
+        HCK(hipMalloc((void**)&e->d_tn, tn.size() * sizeof(cf)));
+        HCK(hipMemcpy(e->d_tn, tn.data(), tn.size() * sizeof(cf), hipMemcpyHostToDevice));
+        HCK(hipMalloc((void**)&e->d_rot8, rot8.size() * sizeof(cf)));
+        HCK(hipMemcpy(e->d_rot8, rot8.data(), rot8.size() * sizeof(cf), hipMemcpyHostToDevice));
+    }
     HCK(upload_wq(T.wq.data()));
     {   // C/A chips of all 32 PRNs for the capture generator
         std::vector<uint32_t> chips(32 * 32, 0u);
@@ -225,6 +245,8 @@ extern "C" int gpsacq_create(const gpsacq_params* params, gpsacq_engine** out) {
     HCK(hipMemcpy(e->d_bq, T.bq.data(), T.bq.size() * sizeof(cf), hipMemcpyHostToDevice));
     HCK(hipMemcpy(e->d_t1, T.t1.data(), T.t1.size() * sizeof(cf), hipMemcpyHostToDevice));
     HCK(hipMemcpy(e->d_t2, T.t2.data(), T.t2.size() * sizeof(cf), hipMemcpyHostToDevice));
+    HCK(hipMalloc((void**)&e->d_t2u, T.t2u.size() * sizeof(cf)));
+    HCK(hipMemcpy(e->d_t2u, T.t2u.data(), T.t2u.size() * sizeof(cf), hipMemcpyHostToDevice));
 
     std::vector<uint8_t> cosm(BLOCK_BYTES), sinm(BLOCK_BYTES);
     lo_masks(params->fc, params->fs, BLOCK_BYTES, cosm.data(), sinm.data());
@@ -278,6 +300,11 @@ extern "C" int gpsacq_get_info(const gpsacq_engine* e, gpsacq_info* info) {
     info->device = e->p.device;
     info->compute_units = e->cus;
     snprintf(info->device_name, sizeof info->device_name, "%s", e->name);
+    info->doppler_sub = e->sub;
+    info->doppler_stride = e->dstride;
+    info->num_doppler_total = 2 * e->kmax + 1;
+    info->first_doppler_total = -e->kmax;
+    info->doppler_step_hz = e->p.fs / N_FFT * e->dstride / e->sub;
     return GPSACQ_OK;
 }
 
@@ -349,7 +376,8 @@ static int search_core(gpsacq_engine* e, const uint8_t* d_bits, size_t n_blocks,
     if (stride < (size_t)USED_BYTES) return fail(GPSACQ_ERR_ARG, "stride %zu < 5000 bytes", stride);
     if (n_blocks > 0x7fffffffu) return fail(GPSACQ_ERR_ARG, "batch too large: %zu blocks", n_blocks);
     if (n_tasks * (size_t)e->ndop > 0x7fffff00u) return fail(GPSACQ_ERR_ARG, "batch too large: %zu tasks x %d bins", n_tasks, e->ndop);
-    if (int rc = grow(e->d_dpp, e->dpp_cap, n_blocks, (size_t)NPOLY * M_SUB * sizeof(cf))) return rc;
+    if (n_blocks * (size_t)e->sub > 0x7fffffffu) return fail(GPSACQ_ERR_ARG, "batch too large: %zu blocks x %d sub-bin spectra", n_blocks, e->sub);
+    if (int rc = grow(e->d_dpp, e->dpp_cap, n_blocks * (size_t)e->sub, (size_t)NPOLY * M_SUB * sizeof(cf))) return rc;
     if (!d_cells) {
         if (int rc = grow(e->d_cells, e->cell_cap, n_tasks * (size_t)e->ndop)) return rc;
         d_cells = e->d_cells;
@@ -366,6 +394,7 @@ static int search_core(gpsacq_engine* e, const uint8_t* d_bits, size_t n_blocks,
     ca.tasks = e->d_tasks;
     ca.t1 = e->d_t1;
     ca.t2 = e->d_t2;
+    ca.t2u = e->d_t2u;
     ca.bq = e->d_bq;
     ca.cells = d_cells;
     ca.n_tasks = (int)n_tasks;
@@ -379,13 +408,20 @@ static int search_core(gpsacq_engine* e, const uint8_t* d_bits, size_t n_blocks,
     ca.n_spec = (int)n_blocks;
     ca.creep = 0.f;
     ca.n_code = GPSACQ_NUM_SATS + (int)e->patch_cap;
+    ca.sub = e->sub;
+    ca.dstride = e->dstride;
+    if (getenv("GPSACQ_PROF")) {
+        if (!e->d_prof) HIPCHK(hipMalloc((void**)&e->d_prof, 16 * sizeof(unsigned long long)));
+        HIPCHK(hipMemsetAsync(e->d_prof, 0, 16 * sizeof(unsigned long long), e->stream));
+        ca.prof = e->d_prof;
+    }
     const int n_cols = (e->nlags + NBF3 - 1) / NBF3;
     const int n_pass = (n_cols + MC_MAX - 1) / MC_MAX;  // 1 up to 10000 lags (fs <= 10 MHz)
     if (n_pass == 1) {
         ca.m0 = 0;
         // samples the code advances per accumulated block per Doppler bin: elapsed samples x (bin Hz / L1)
         if (e->creep_comp && e->n_acc > 1)
-            ca.creep = (float)((double)e->acc_step * (double)stride * 8.0 * (e->p.fs / N_FFT) / 1575.42e6);
+            ca.creep = (float)((double)e->acc_step * (double)stride * 8.0 * (e->p.fs / N_FFT * e->dstride / e->sub) / 1575.42e6);
         if (launch_corr(ca, e->mc, e->stream) != 0) return fail(GPSACQ_ERR_UNSUPPORTED, "no correlate kernel for %d columns", e->mc);
     } else {
         const size_t n_cells = n_tasks * (size_t)e->ndop;
@@ -399,6 +435,19 @@ static int search_core(gpsacq_engine* e, const uint8_t* d_bits, size_t n_blocks,
     }
     HIPCHK(hipGetLastError());
     HIPCHK(hipEventRecord(ev[2], e->stream));
+    if (ca.prof) {  // wave-role 0 and role 3 (lane 0): cycles summed over all workgroups, per segment
+        unsigned long long h[16];
+        HIPCHK(hipMemcpyAsync(h, e->d_prof, sizeof h, hipMemcpyDeviceToHost, e->stream));
+        HIPCHK(hipStreamSynchronize(e->stream));
+        static const char* seg[8] = {"load+mul", "pass1", "barrier1", "pass2", "barrier2", "pass3(+prefetch)", "barrier3", "scan"};
+        const double cells = (double)n_tasks * e->ndop;
+        for (int r = 0; r < 2; ++r) {
+            fprintf(stderr, "k_corr2 profile, role %d, cycles per cell:", r ? 3 : 0);
+            double tot = 0;
+            for (int k = 0; k < 8; ++k) { fprintf(stderr, " %s %.0f", seg[k], h[8 * r + k] / cells); tot += h[8 * r + k] / cells; }
+            fprintf(stderr, " | total %.0f\n", tot);
+        }
+    }
     launch_peaks(d_cells, d_peaks, (int)n_tasks, e->ndop, e->dop_first, e->stream);
     HIPCHK(hipGetLastError());
     HIPCHK(hipEventRecord(ev[3], e->stream));
@@ -461,10 +510,44 @@ extern "C" int gpsacq_aligned_stride(const gpsacq_engine* e) {
 
 extern "C" int gpsacq_set_doppler_window(gpsacq_engine* e, int first_bin, int n_bins) {
     if (!e) return fail(GPSACQ_ERR_ARG, "gpsacq_set_doppler_window: null engine");
-    if (n_bins <= 0 || first_bin < -e->dmax || first_bin + n_bins - 1 > e->dmax)
-        return fail(GPSACQ_ERR_ARG, "Doppler window [%d, %d] outside [-%d, %d]", first_bin, first_bin + n_bins - 1, e->dmax, e->dmax);
+    if (n_bins <= 0 || first_bin < -e->kmax || first_bin + n_bins - 1 > e->kmax)
+        return fail(GPSACQ_ERR_ARG, "Doppler window [%d, %d] outside [-%d, %d]", first_bin, first_bin + n_bins - 1, e->kmax, e->kmax);
     e->dop_first = first_bin;
     e->ndop = n_bins;
+    return GPSACQ_OK;
+}
+
+extern "C" int gpsacq_set_doppler_step(gpsacq_engine* e, double step_hz) {
+    if (!e) return fail(GPSACQ_ERR_ARG, "gpsacq_set_doppler_step: null engine");
+    HIPCHK(hipSetDevice(e->p.device));
+    const double bin = e->p.fs / N_FFT;
+    int sub = 1, dstride = 1;
+    if (step_hz > 0 && step_hz < bin * (1 - 1e-9)) sub = (int)std::ceil(bin / step_hz - 1e-9);
+    else if (step_hz >= 2 * bin * (1 - 1e-9)) dstride = (int)std::floor(step_hz / bin + 1e-9);
+    if (sub > GPSACQ_MAX_DOPPLER_SUB) return fail(GPSACQ_ERR_UNSUPPORTED, "Doppler step %g Hz needs %d sub-bin spectra per block (limit %d)", step_hz, sub, GPSACQ_MAX_DOPPLER_SUB);
+    if (sub > 1 && e->p.ref_quirks) return fail(GPSACQ_ERR_UNSUPPORTED, "ref_quirks is defined for the reference's Doppler grid only");
+    const double step = bin * dstride / sub;
+    const int kmax = (int)(e->p.max_fo / step);  // same truncation as :176
+    if (2 * kmax + 1 > 0xFFFF) return fail(GPSACQ_ERR_UNSUPPORTED, "%d Doppler points exceed the 65535 the peak keys can carry", 2 * kmax + 1);
+    if (sub != e->sub) {  // forward-transform tables of the sub-bin offsets
+        HIPCHK(hipStreamSynchronize(e->stream));
+        std::vector<cf> tn, rot8;
+        forward_tables(sub, tn, rot8);
+        cf *ntn = nullptr, *nrot = nullptr;
+        HIPCHK(hipMalloc((void**)&ntn, tn.size() * sizeof(cf)));
+        HIPCHK(hipMalloc((void**)&nrot, rot8.size() * sizeof(cf)));
+        HIPCHK(hipMemcpy(ntn, tn.data(), tn.size() * sizeof(cf), hipMemcpyHostToDevice));
+        HIPCHK(hipMemcpy(nrot, rot8.data(), rot8.size() * sizeof(cf), hipMemcpyHostToDevice));
+        HIPCHK(hipFree(e->d_tn));
+        HIPCHK(hipFree(e->d_rot8));
+        e->d_tn = ntn;
+        e->d_rot8 = nrot;
+    }
+    e->sub = sub;
+    e->dstride = dstride;
+    e->kmax = kmax;
+    e->dop_first = -kmax;
+    e->ndop = 2 * kmax + 1;
     return GPSACQ_OK;
 }
 
@@ -594,6 +677,9 @@ extern "C" int gpsacq_handoff(const gpsacq_peak* peak, double fc, double fs, dou
     const double L1 = 1575.42e6, CPS = 1.023e6;  // c/gps_offline.h:22,30
     const double lo_dop = peak->lo_shift * fs / N_FFT;
     const double ca_dop = lo_dop / L1 * CPS;
+    // the NCO words are fractions of 2^32: frequencies outside [0, fs) do not fit (the reference would wrap silently)
+    if (!(fc + lo_dop >= 0 && fc + lo_dop < fs) || !(CPS + ca_dop >= 0 && CPS + ca_dop < fs))
+        return fail(GPSACQ_ERR_ARG, "gpsacq_handoff: carrier %g Hz or code rate %g Hz outside [0, fs = %g)", fc + lo_dop, CPS + ca_dop, fs);
     out->lo_dop_hz = lo_dop;
     out->ca_dop_hz = ca_dop;
     out->lo_rate = (uint32_t)((fc + lo_dop) / fs * 4294967296.0);

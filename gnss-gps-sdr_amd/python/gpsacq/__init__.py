@@ -20,7 +20,7 @@ BLOCK_BYTES = 5120
 THRESHOLD = 25.0  # c/search_offline.cpp:248
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.normpath(os.path.join(_HERE, "..", "..", "lib", "libgpsacq.so"))
+LIB_PATH = os.environ.get("GPSACQ_LIB") or os.path.normpath(os.path.join(_HERE, "..", "..", "lib", "libgpsacq.so"))
 
 CELL_DTYPE = np.dtype([("max_pwr", "<f4"), ("max_i", "<i4"), ("tot_pwr", "<f4"), ("snr", "<f4")])
 PEAK_DTYPE = np.dtype([("snr", "<f4"), ("lo_shift", "<i4"), ("ca_shift", "<i4"), ("max_pwr", "<f4")])
@@ -35,7 +35,9 @@ class Params(ctypes.Structure):
 class Info(ctypes.Structure):
     _fields_ = [("fft_len", ctypes.c_int32), ("dmax", ctypes.c_int32), ("num_doppler", ctypes.c_int32),
                 ("first_doppler", ctypes.c_int32), ("num_lags", ctypes.c_int32), ("acc_columns", ctypes.c_int32), ("device", ctypes.c_int32),
-                ("compute_units", ctypes.c_int32), ("device_name", ctypes.c_char * 64)]
+                ("compute_units", ctypes.c_int32), ("device_name", ctypes.c_char * 64),
+                ("doppler_sub", ctypes.c_int32), ("doppler_stride", ctypes.c_int32), ("num_doppler_total", ctypes.c_int32),
+                ("first_doppler_total", ctypes.c_int32), ("doppler_step_hz", ctypes.c_double)]
 
 
 class Timing(ctypes.Structure):
@@ -54,7 +56,7 @@ class Sat(ctypes.Structure):
 
 
 EXPORTS = ["gpsacq_generate", "gpsacq_generate_device", "gpsacq_handoff", "gpsacq_iq8_to_bits", "gpsacq_iq8_to_bits_device", "gpsacq_create", "gpsacq_destroy", "gpsacq_last_error", "gpsacq_get_info", "gpsacq_search",
-           "gpsacq_search_device", "gpsacq_set_doppler_window", "gpsacq_set_noncoherent", "gpsacq_set_creep_compensation", "gpsacq_aligned_stride", "gpsacq_synchronize", "gpsacq_last_timing", "gpsacq_timing_ago", "gpsacq_stream", "gpsacq_search_code",
+           "gpsacq_search_device", "gpsacq_set_doppler_window", "gpsacq_set_doppler_step", "gpsacq_set_noncoherent", "gpsacq_set_creep_compensation", "gpsacq_aligned_stride", "gpsacq_synchronize", "gpsacq_last_timing", "gpsacq_timing_ago", "gpsacq_stream", "gpsacq_search_code",
            "gpsacq_sample_spectrum", "gpsacq_code_spectrum"]
 
 _lib = None
@@ -105,6 +107,8 @@ def load_library(path=None):
     lib.gpsacq_search_device.restype = ctypes.c_int
     lib.gpsacq_set_doppler_window.argtypes = [vp, ctypes.c_int, ctypes.c_int]
     lib.gpsacq_set_doppler_window.restype = ctypes.c_int
+    lib.gpsacq_set_doppler_step.argtypes = [vp, ctypes.c_double]
+    lib.gpsacq_set_doppler_step.restype = ctypes.c_int
     lib.gpsacq_set_noncoherent.argtypes = [vp, ctypes.c_int, ctypes.c_int]
     lib.gpsacq_set_noncoherent.restype = ctypes.c_int
     lib.gpsacq_aligned_stride.argtypes = [vp]
@@ -188,10 +192,22 @@ class Engine:
         self.device = info.device
         self.compute_units = info.compute_units
         self.device_name = info.device_name.decode(errors="replace")
+        self.doppler_sub = info.doppler_sub
+        self.doppler_stride = info.doppler_stride
+        self.num_doppler_total = info.num_doppler_total
+        self.first_doppler_total = info.first_doppler_total
+        self.kmax = -info.first_doppler_total  # grid points run -kmax..+kmax (= dmax on the reference grid)
+        self.doppler_step_hz = info.doppler_step_hz
 
     def set_doppler_window(self, first_bin, n_bins):
         """Search only bins first_bin .. first_bin+n_bins-1 (multi-GPU Doppler-slab sharding)."""
         _check(self._lib, self._lib.gpsacq_set_doppler_window(self._h, int(first_bin), int(n_bins)))
+        self._refresh_info()
+
+    def set_doppler_step(self, step_hz):
+        """Doppler grid step in Hz: finer than fs/40000 through sub-bin spectra, coarser through a bin stride
+        (include/gpsacq.h).  lo_shift / windows / cells columns then count grid points of doppler_step_hz."""
+        _check(self._lib, self._lib.gpsacq_set_doppler_step(self._h, float(step_hz)))
         self._refresh_info()
 
     def set_noncoherent(self, n_acc, block_step=1):

@@ -35,6 +35,13 @@ def shard_doppler(dmax, rank, world):
     return first - dmax, n
 
 
+def shard_doppler_grid(n_points, first_point, rank, world):
+    """Contiguous split of a Doppler grid of n_points points starting at index first_point (Engine.num_doppler_total,
+    .first_doppler_total): returns (first, n); n may be 0 when there are more ranks than points."""
+    first, n = shard_runs(n_points, rank, world)
+    return first + first_point, n
+
+
 def pack_keys(peaks_i32, dmax):
     """peaks_i32: int32 tensor [n, 4] viewing gpsacq_peak records {snr f32 bits, lo, ca, max_pwr bits}."""
     snr_bits = peaks_i32[:, 0].to(torch.int64) & 0xFFFFFFFF

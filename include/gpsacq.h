@@ -15,6 +15,7 @@
  *                            for a batch of 5120-byte blocks (the body of the
  *                            SearchTask() loop, :239-246)
  *   gpsacq_search_device     same, capture already resident in HBM
+ *   gpsacq_set_doppler_step  the Doppler grid of Correlate()'s loop, :176,182 (finer or coarser than fs/40000)
  *   gpsacq_search_code       SearchCode()            c/search_offline.cpp:205-209
  *   gpsacq_iq8_to_bits       the MATLAB pre-processing that produces gps_test's input from an 8-bit IQ
  *                            capture: proc_rtl_bin_for_gps.m:12-26,31-47, proc_hackrf_bin_for_gps.m:7-19
@@ -95,6 +96,12 @@ typedef struct {
     int32_t device;
     int32_t compute_units;
     char device_name[64];
+    /* Doppler grid (gpsacq_set_doppler_step); reference grid: sub = stride = 1, step = fs/40000 */
+    int32_t doppler_sub;         /* sub-bin offsets per FFT bin (step = bin / sub) */
+    int32_t doppler_stride;      /* or whole bins per grid point (step = bin * stride) */
+    int32_t num_doppler_total;   /* grid points of the full +-max_fo range */
+    int32_t first_doppler_total; /* index of the lowest one (= -(num_doppler_total - 1) / 2) */
+    double doppler_step_hz;      /* lo_shift, first_doppler, Doppler windows are in units of this step */
 } gpsacq_info;
 
 /* per-stage device time of the last gpsacq_search* call, milliseconds (HIP events on the
@@ -143,6 +150,20 @@ int gpsacq_search_device(gpsacq_engine* e, const void* d_bits, size_t n_blocks, 
  * lo_shift stays an absolute bin number.
  */
 int gpsacq_set_doppler_window(gpsacq_engine* e, int first_bin, int n_bins);
+/*
+ * Doppler grid step (extension; the reference's grid is whole FFT bins of fs/40000 Hz, c/search_offline.cpp:176,182,
+ * and its front end ignores argv[4]).  step_hz <= 0 or within (bin, 2 bin): the reference grid.  step_hz < bin: the
+ * grid is refined to bin / R, R = ceil(bin / step_hz) (the finest grid not coarser than asked): each block is
+ * transformed R times, spectrum r being that of the block multiplied by exp(-2 pi i (r/R) n / 40000) -- a carrier
+ * offset of r/R of a bin, exact, folded into the forward transform's twiddles -- and grid point k = d R + r pairs
+ * spectrum r with the code spectrum shifted by d whole bins.  step_hz >= 2 bin: every S-th bin, S = floor(step_hz /
+ * bin).  The range is -K..+K with K = trunc(max_fo / step) like :176.  Afterwards num_doppler / first_doppler /
+ * lo_shift / Doppler windows count grid points (Hz = index * gpsacq_info.doppler_step_hz), cells rows hold one
+ * record per grid point in ascending frequency, and the Doppler window is reset to the full range.
+ * Costs R forward transforms and R x 320 KB of spectra per block; the correlate work per grid point is unchanged.
+ */
+#define GPSACQ_MAX_DOPPLER_SUB 16
+int gpsacq_set_doppler_step(gpsacq_engine* e, double step_hz);
 /*
  * Non-coherent accumulation (extension; the reference scans one coherent block per cell,
  * c/search_offline.cpp:176-199): every task then sums |IFFT|^2 per lag over n_acc block spectra

@@ -318,6 +318,25 @@ void oracle_sample(oracle_t *o, const unsigned char *bytes) {
 }
 void oracle_get_sample_spectrum(const oracle_t *o, float *out) { memcpy(out, o->fwd, sizeof(cf32) * FFT_LEN); }
 
+/* EXTENSION, no reference behaviour ("arbitrary Doppler step"): Sample() whose mixed
+ * samples are multiplied by exp(-2 pi i eps n / N) before the transform -- a carrier offset of eps FFT bins
+ * (0 <= eps < 1), so that Correlate's whole-bin shift d (:182) then tests the Doppler (d + eps) fs/N.  The ramp is
+ * formed in double and the product rounded to float (what a float sample buffer would hold); eps = 0 is
+ * oracle_sample().  Restates the product's sub-bin grid (gpsacq_set_doppler_step). */
+void oracle_sample_ramped(oracle_t *o, const unsigned char *bytes, double eps) {
+    oracle_mix_block(bytes, o->quad, o->fwd);
+    if (eps != 0.0) {
+        const double tp = 6.283185307179586476925286766559;
+        for (int n = 0; n < FFT_LEN; n++) {
+            const double th = tp * eps * (double)n / (double)FFT_LEN, c = cos(th), s = sin(th);
+            const double re = o->fwd[n].re, im = o->fwd[n].im;
+            o->fwd[n].re = (float)(re * c + im * s);
+            o->fwd[n].im = (float)(im * c - re * s);
+        }
+    }
+    fft_exec_cf32(o->plan, o->fwd, +1);
+}
+
 /* Correlate(): :169-201.  cells (may be NULL) receives one record per Doppler bin. */
 float oracle_correlate(oracle_t *o, int sv, int *max_snr_dop, int *max_snr_i, oracle_cell *cells) {
     const cf32 *data = o->fwd;
@@ -365,6 +384,29 @@ void oracle_cell_power(oracle_t *o, int sv, int dop, float *pwr /* nlags */) {
     }
     fft_exec_cf32(o->plan, prod, -1);
     for (int i = 0; i < o->nlags; i++) pwr[i] = prod[i].re * prod[i].re + prod[i].im * prod[i].im;
+}
+
+/* One cell of Correlate (:178-196) at whole-bin shift dop of the block last sampled. */
+void oracle_one_cell(oracle_t *o, int sv, int dop, oracle_cell *out) {
+    const cf32 *data = o->fwd;
+    const cf32 *code = o->code + (size_t)sv * FFT_LEN;
+    cf32 *prod = o->rev;
+    const int S = o->nlags;
+    for (int i = 0; i < FFT_LEN; i++) {
+        int j = ((i - dop) % FFT_LEN + FFT_LEN) % FFT_LEN;
+        prod[i].re = data[i].re * code[j].re + data[i].im * code[j].im;
+        prod[i].im = data[i].re * code[j].im - data[i].im * code[j].re;
+    }
+    fft_exec_cf32(o->plan, prod, -1);
+    float max_pwr = 0, tot_pwr = 0;
+    int max_pwr_i = 0, i;
+    for (i = 0; i < S; i++) {
+        float pwr = prod[i].re * prod[i].re + prod[i].im * prod[i].im;
+        if (pwr > max_pwr) max_pwr = pwr, max_pwr_i = i;
+        tot_pwr += pwr;
+    }
+    out->max_pwr = max_pwr; out->max_i = max_pwr_i; out->tot_pwr = tot_pwr;
+    out->snr = (tot_pwr > 0) ? max_pwr / (tot_pwr / i) : 0;
 }
 
 /* One (block, sv) search = Sample + Correlate */

@@ -19,11 +19,12 @@ static const Tables& tables() {
 
 // "kernel" k_fwd: one workgroup = one (item, kappa) -> row kappa of the polyphase spectrum
 template <class Src>
-static void emul_fwd_row(const Src& src, int kappa, bool conj_out, cf* row /*[5000]*/) {
+static void emul_fwd_row(const Src& src, int kappa, bool conj_out, cf* row /*[5000]*/, const cf* tn_row = nullptr) {
     const Tables& T = tables();
     std::vector<cf> lds(M_SUB);
     std::vector<cf> regs((size_t)WG * RC);
-    for (int tid = 0; tid < WG; ++tid) fwd_phase1(tid, kappa, src, T.tn.data(), T.t1.data(), lds.data());
+    if (!tn_row) tn_row = T.tn.data() + (size_t)kappa * M_SUB;
+    for (int tid = 0; tid < WG; ++tid) fwd_phase1(tid, kappa, src, tn_row, T.t1.data(), lds.data());
     for (int tid = 0; tid < WG; ++tid) fwd_phase2(tid, T.t2.data(), lds.data());
     for (int tid = 0; tid < WG; ++tid) fwd_phase3_load(tid, lds.data(), &regs[(size_t)tid * RC]);
     for (int tid = 0; tid < WG; ++tid) fwd_phase3_store(tid, conj_out, &regs[(size_t)tid * RC], lds.data());
@@ -45,20 +46,26 @@ static void pp_to_natural(const cf* pp, long row, int off, bool conj, float* out
 
 extern "C" {
 
-// Sample(): spectrum of one 5120-byte block in natural order (un-conjugated).
-void emul_forward_bits(const uint8_t* bytes, const uint8_t* cosm, const uint8_t* sinm, float* out) {
+// Sample(): spectrum of one 5120-byte block in natural order (un-conjugated); spectrum r of `sub` sub-bin Doppler
+// offsets (r = 0, sub = 1: the reference's Sample()).
+void emul_forward_bits_sub(const uint8_t* bytes, const uint8_t* cosm, const uint8_t* sinm, int sub, int r, float* out) {
     std::vector<uint64_t> ib(625), qb(625), cos_t(625), sin_t(625);
     transpose_masks(cosm, cos_t.data());
     transpose_masks(sinm, sin_t.data());
     for (int tid = 0; tid < WG; ++tid) fwd_stage_bits(tid, bytes, cos_t.data(), sin_t.data(), ib.data(), qb.data());
+    std::vector<cf> tn, rot8;
+    forward_tables(sub, tn, rot8);
     std::vector<cf> pp((size_t)NPOLY * M_SUB);
     for (int kappa = 0; kappa < NPOLY; ++kappa) {  // the look-up table depends on the row
         std::vector<cf> lut(256);
-        for (int tid = 0; tid < WG; ++tid) fwd_build_lut(tid, kappa, lut.data());
+        for (int tid = 0; tid < WG; ++tid) fwd_build_lut(tid, rot8.data() + ((size_t)r * NPOLY + kappa) * NPOLY, lut.data());
         BitsSrc src{reinterpret_cast<const uint8_t*>(ib.data()), reinterpret_cast<const uint8_t*>(qb.data()), lut.data()};
-        emul_fwd_row(src, kappa, true, pp.data() + (size_t)kappa * M_SUB);
+        emul_fwd_row(src, kappa, true, pp.data() + (size_t)kappa * M_SUB, tn.data() + ((size_t)r * NPOLY + kappa) * M_SUB);
     }
     pp_to_natural(pp.data(), M_SUB, 0, true, out);
+}
+void emul_forward_bits(const uint8_t* bytes, const uint8_t* cosm, const uint8_t* sinm, float* out) {
+    emul_forward_bits_sub(bytes, cosm, sinm, 1, 0, out);
 }
 // SearchInit(): spectrum of a real 40000-sample replica.
 void emul_forward_real(const float* x, float* out) {
@@ -116,6 +123,68 @@ int emul_cell(const float* dspec, const float* cspec, int halo, int dop, int S, 
             case 33: corr_scan<33>(tid, S, 0, a, tmx, tmi, tsum); break;
             default: corr_scan<40>(tid, S, 0, a, tmx, tmi, tsum); break;
         }
+        peak_merge(mx, mi, tmx, tmi);
+        sum += tsum;
+    }
+    *max_pwr = mx;
+    *max_i = mi;
+    *tot_pwr = sum;
+    return 0;
+}
+
+// Same cell through the phase functions of k_corr2: inputs requested in two calls (rows [0, pre) "before the
+// barrier", the rest after), pass 2 by wave role with the two-step tail for butterflies 192..199.
+int emul_cell2(const float* dspec, const float* cspec, int halo, int dop, int S, int pre, int roles, int pipe, float* max_pwr, int* max_i, float* tot_pwr) {
+    const Tables& T = tables();
+    const int crow = M_SUB + 2 * halo;
+    std::vector<cf> dpp((size_t)NPOLY * M_SUB), cpp((size_t)NPOLY * crow);
+    for (int k = 0; k < N_FFT; ++k) {
+        dpp[(size_t)(k & 7) * M_SUB + (k >> 3)] = mk(dspec[2 * k], -dspec[2 * k + 1]);
+        cpp[(size_t)(k & 7) * crow + halo + (k >> 3)] = mk(cspec[2 * k], cspec[2 * k + 1]);
+    }
+    for (int q = 0; q < NPOLY; ++q)
+        for (int h = 0; h < halo; ++h) {
+            cpp[(size_t)q * crow + h] = cpp[(size_t)q * crow + M_SUB + h];
+            cpp[(size_t)q * crow + halo + M_SUB + h] = cpp[(size_t)q * crow + halo + h];
+        }
+    std::vector<cf> lds(M_SUB);
+    constexpr int MC = 22;
+    std::vector<cf> acc((size_t)WG * MC, mk(0.f, 0.f));
+    for (int q = 0; q < NPOLY; ++q) {
+        for (int tid = 0; tid < NBF3; ++tid) {
+            cf w1[2][RA - 1];
+            load_tw1(tid, T.t1.data(), w1);
+            cf2 d[RA], c[RA];
+            cf x0[RA], x1[RA];
+            if (pre == 5) {
+                corr_issue<0, 5>(tid, q, dop, dpp.data(), cpp.data(), crow, halo, d, c);
+                corr_issue<5, RA>(tid, q, dop, dpp.data(), cpp.data(), crow, halo, d, c);
+            } else {
+                corr_issue<0, RA>(tid, q, dop, dpp.data(), cpp.data(), crow, halo, d, c);
+            }
+            corr_mul<0, 5>(d, c, x0, x1);
+            corr_mul<5, RA>(d, c, x0, x1);
+            corr_phase1_store(tid, x0, x1, w1, lds.data());
+        }
+        for (int vt = 0; vt < (roles ? TAIL_E0 : NBF2); ++vt) {
+            if (pipe) pass2_pipe<+1>(vt, T.t2u.data(), lds.data());
+            else pass2_inplace<+1>(vt, T.t2.data(), lds.data());
+        }
+        if (roles) {
+            for (int L = 0; L < TAIL_LANES; ++L) pass2_tail1<+1>(L, T.t2.data(), lds.data());
+            std::vector<cf> y((size_t)TAIL_LANES * 5);
+            for (int L = 0; L < TAIL_LANES; ++L) pass2_tail2_load<+1>(L, lds.data(), &y[(size_t)L * 5]);
+            for (int L = 0; L < TAIL_LANES; ++L) pass2_tail2_store<+1>(L, T.t2.data(), &y[(size_t)L * 5], lds.data());
+        }
+        for (int tid = 0; tid < WG; ++tid)
+            corr_phase3<MC>(tid, T.bq[(size_t)q * NBF3 + (tid < NBF3 ? tid : 0)], &T.wq[(size_t)q * WQ_STRIDE], lds.data(), &acc[(size_t)tid * MC]);
+    }
+    float mx = 0.f, sum = 0.f;
+    int mi = 0;
+    for (int tid = 0; tid < WG; ++tid) {
+        float tmx, tsum;
+        int tmi;
+        corr_scan<MC>(tid, S, 0, &acc[(size_t)tid * MC], tmx, tmi, tsum);
         peak_merge(mx, mi, tmx, tmi);
         sum += tsum;
     }

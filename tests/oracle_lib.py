@@ -29,6 +29,8 @@ def lib(kind="f64"):
     L.oracle_get_sample_spectrum.argtypes = [vp, vp]
     L.oracle_search_block.argtypes = [vp, vp, i, vp, vp]
     L.oracle_cell_power.argtypes = [vp, i, i, vp]
+    L.oracle_sample_ramped.argtypes = [vp, vp, d]
+    L.oracle_one_cell.argtypes = [vp, i, i, vp]
     L.oracle_search_file.argtypes = [vp, ctypes.c_char_p, i, ctypes.c_char_p, ctypes.c_size_t, vp, ctypes.c_size_t]
     L.oracle_bench_blocks.argtypes = [vp, vp, ctypes.c_long, ctypes.c_long, vp]
     L.oracle_bench_blocks.restype = ctypes.c_long
@@ -52,6 +54,7 @@ class Oracle:
     def __init__(self, fc, fs, max_fo=5000.0, ref_quirks=False, kind="f64"):
         self.L = lib(kind)
         self.fs = float(fs)
+        self.max_fo = float(max_fo)
         self.h = self.L.oracle_create(fc, fs, max_fo, 1 if ref_quirks else 0)
         self.dmax = self.L.oracle_get_dmax(self.h)
         self.num_doppler = 2 * self.dmax + 1
@@ -96,6 +99,27 @@ class Oracle:
             cells[t] = c
             peaks[t] = p
         return cells, peaks
+
+    def search_grid(self, block, sv, sub=1, dstride=1, max_fo=None, points=None):
+        """Restatement of the product's Doppler grid (gpsacq_set_doppler_step): step = bin * dstride / sub, points
+        k = -K..K, K = trunc(max_fo / step); point k pairs the block's spectrum at sub-bin offset r / sub with the code
+        spectrum shifted by d whole bins (k = d sub + r, or d = k dstride).  Returns (cells[points], ks)."""
+        b = np.ascontiguousarray(np.frombuffer(block, dtype=np.uint8)[:5120])
+        step = self.fs / 40000.0 * dstride / sub
+        K = int((max_fo if max_fo is not None else self.max_fo) / step)
+        ks = list(range(-K, K + 1)) if points is None else list(points)
+        cells = np.zeros(len(ks), CELL_DTYPE)
+        for r in range(sub):
+            sel = [(i, k) for i, k in enumerate(ks) if (k % sub if sub > 1 else 0) == r]
+            if not sel:
+                continue
+            self.L.oracle_sample_ramped(self.h, _p(b), float(r) / sub)
+            one = np.zeros(1, CELL_DTYPE)
+            for i, k in sel:
+                d = (k - r) // sub if sub > 1 else k * dstride
+                self.L.oracle_one_cell(self.h, sv, d, _p(one))
+                cells[i] = one[0]
+        return cells, ks
 
     def search_noncoherent(self, bits, stride, first_block, sv, n_acc, block_step, first_bin=None, n_bins=None, creep=False):
         """Restatement of the non-coherent extension: per Doppler bin, sum |IFFT|^2 per lag over

@@ -8,6 +8,7 @@ import subprocess
 import pytest
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+pytestmark = pytest.mark.usefixtures("hip_artifacts")  # built on first use (conftest.py); skipped where hipcc is missing
 
 
 def _header_symbols(path):
@@ -29,7 +30,7 @@ def test_exports_match_header():
 def test_struct_sizes_match_abi():
     import gpsacq
     assert gpsacq.CELL_DTYPE.itemsize == 16 and gpsacq.PEAK_DTYPE.itemsize == 16 and gpsacq.TASK_DTYPE.itemsize == 8
-    assert ctypes.sizeof(gpsacq.Params) == 32 and ctypes.sizeof(gpsacq.Info) == 96 and ctypes.sizeof(gpsacq.Timing) == 32
+    assert ctypes.sizeof(gpsacq.Params) == 32 and ctypes.sizeof(gpsacq.Info) == 120 and ctypes.sizeof(gpsacq.Timing) == 32
 
 
 def test_search_code_host_only():
@@ -51,6 +52,9 @@ def test_argument_errors_before_device():
     with pytest.raises(gpsacq.GpsAcqError) as ei:
         gpsacq.Engine(1e6, 5e6, 3e6)  # Doppler range beyond half the sampling rate
     assert ei.value.code == 3
+    with pytest.raises(gpsacq.GpsAcqError) as ei:
+        gpsacq.Engine(6e6, 5e6)  # fc >= fs: the quadrature LO's quadrant index would leave its table (UB in the reference)
+    assert ei.value.code == 1
 
 
 def test_fails_loudly_without_gpu():

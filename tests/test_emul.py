@@ -21,8 +21,10 @@ def emul():
     E = ctypes.CDLL(path)
     vp, d, i = ctypes.c_void_p, ctypes.c_double, ctypes.c_int
     E.emul_forward_bits.argtypes = [vp] * 4
+    E.emul_forward_bits_sub.argtypes = [vp, vp, vp, i, i, vp]
     E.emul_forward_real.argtypes = [vp] * 2
     E.emul_cell.argtypes = [vp, vp, i, i, i, i, vp, vp, vp]
+    E.emul_cell2.argtypes = [vp, vp, i, i, i, i, i, i, vp, vp, vp]
     E.emul_code_replica.argtypes = [d, i, vp]
     E.emul_lo_masks.argtypes = [d, d, vp, vp]
     E.emul_search_code.argtypes = [i, i]
@@ -80,3 +82,32 @@ def test_emulated_kernels_vs_oracle(emul, golden_dir, fc, fs, file, mc):
         ref = cells[dop + orc.dmax]
         assert abs(mp.value / ref["max_pwr"] - 1) < 2e-5 and abs(tp.value / ref["tot_pwr"] - 1) < 2e-5
         assert mi.value == ref["max_i"]
+        if mc == 22:  # k_corr2's phase functions (split input requests, pass 2 by wave role): same numbers as k_corr's
+            for pre, roles, pipe in ((5, 1, 0), (10, 0, 1), (5, 1, 1)):
+                mp2, mi2, tp2 = ctypes.c_float(), ctypes.c_int(), ctypes.c_float()
+                assert emul.emul_cell2(_p(d_in), _p(c_in), 24, dop, orc.num_lags, pre, roles, pipe, ctypes.byref(mp2), ctypes.byref(mi2), ctypes.byref(tp2)) == 0
+                assert abs(mp2.value / mp.value - 1) < 1e-6 and abs(tp2.value / tp.value - 1) < 1e-6 and mi2.value == mi.value
+
+
+def test_emulated_subbin_forward_vs_oracle(emul, golden_dir):
+    """Sub-bin Doppler offsets folded into the forward transform's twiddles (gpsacq_set_doppler_step) against the
+    oracle's restatement: Sample() of the block multiplied by exp(-2 pi i (r/R) n / N)."""
+    fc, fs = 4.092e6, 5.456e6
+    buf = open(os.path.join(golden_dir, "synth_nott_fs5456.bin"), "rb").read()
+    blk = np.frombuffer(buf[3 * 5120:4 * 5120], np.uint8).copy()
+    orc = Oracle(fc, fs, 5000.0)
+    cosm, sinm = np.zeros(5120, np.uint8), np.zeros(5120, np.uint8)
+    emul.emul_lo_masks(fc, fs, _p(cosm), _p(sinm))
+    for sub, r in ((3, 1), (3, 2), (4, 3)):
+        d_emul = np.zeros(80000, np.float32)
+        emul.emul_forward_bits_sub(_p(blk), _p(cosm), _p(sinm), sub, r, _p(d_emul))
+        orc.L.oracle_sample_ramped(orc.h, _p(blk), float(r) / sub)
+        d_orc = np.zeros(80000, np.float32)
+        orc.L.oracle_get_sample_spectrum(orc.h, _p(d_orc))
+        a, b = d_emul.view(np.complex64), d_orc.view(np.complex64)
+        assert np.abs(a - b).max() / np.abs(b).max() < 3e-6, (sub, r)
+    # r = 0 is the reference's Sample()
+    d0, d1 = np.zeros(80000, np.float32), np.zeros(80000, np.float32)
+    emul.emul_forward_bits_sub(_p(blk), _p(cosm), _p(sinm), 3, 0, _p(d0))
+    emul.emul_forward_bits(_p(blk), _p(cosm), _p(sinm), _p(d1))
+    assert np.array_equal(d0, d1)

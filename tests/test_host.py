@@ -3,6 +3,7 @@ import os
 import subprocess
 
 import numpy as np
+import pytest
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 GPS_TEST = os.path.join(ROOT, "gnss-gps-sdr_amd", "bin", "gps_test")
@@ -15,10 +16,10 @@ BANNER = ("GPS CA code offline search. Extract from http://www.aholme.co.uk/GPS/
 
 
 def _ensure_built():
-    if not os.path.exists(GPS_TEST):
-        subprocess.check_call(["make", "-C", ROOT, "lib", "host"], stdout=subprocess.DEVNULL)
+    pass  # the hip_artifacts fixture (conftest.py) built the front end
 
 
+@pytest.mark.usefixtures("hip_artifacts")
 def test_cli_banner_and_arg_count():
     """c/test_search_offline.cpp:24-38: six banner lines always; argc not in {1,5} -> message, exit 0."""
     _ensure_built()
@@ -27,6 +28,7 @@ def test_cli_banner_and_arg_count():
     assert r.stdout == BANNER + "Please run with 3 arguments or without argument!\n"
 
 
+@pytest.mark.usefixtures("hip_artifacts")
 def test_cli_without_gpu_reports_init_failure():
     import torch
     if torch.cuda.is_available():
