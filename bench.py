@@ -104,6 +104,33 @@ def cpu_baseline(cfg, bits, ndop, target_s=12.0):
                       f"{dt:.1f} s on {os.cpu_count()} core host ({cpu_model()}), 1 thread"}
 
 
+def cpu_baseline_reference(cfg, bits, ndop, target_s=15.0):
+    """The reference binary itself (oracle/_ref/gps_test_ref, built by `make -C oracle ref` where a real FFTW3 exists;
+    travels to the GPU box with the snapshot) timed on whole runs of the same capture.  None if it was never built."""
+    import subprocess
+    import tempfile
+    exe = os.path.join(ROOT, "oracle", "_ref", "gps_test_ref")
+    if not os.path.exists(exe):
+        return None
+    runs_avail = len(bits) // (32 * 5120)
+    if runs_avail < 1:
+        return None
+    def timed(n_runs):
+        with tempfile.NamedTemporaryFile(suffix=".bin") as f:
+            f.write(bytes(bits[:n_runs * 32 * 5120]))
+            f.flush()
+            t0 = time.perf_counter()
+            subprocess.run([exe, f.name, repr(cfg["fc"]), repr(cfg["fs"]), "5000"], stdout=subprocess.DEVNULL, check=True)
+            return time.perf_counter() - t0
+    dt1 = timed(1)
+    n = int(max(1, min(runs_avail, target_s / dt1)))
+    dt = timed(n) if n > 1 else dt1
+    cells = n * 32 * ndop
+    return {"value": cells / dt, "unit": "cells/s", "cores": 1, "kind": "reference",
+            "sample": f"oracle/_ref/gps_test_ref (the reference's sources + FFTW3f) on {n} runs x 32 PRN x {ndop} bins = {cells} cells of the "
+                      f"same capture, {dt:.1f} s incl. process start, on {os.cpu_count()} core host ({cpu_model()}), 1 thread"}
+
+
 def cpu_baseline_all_cores(cfg, bits, ndop, single_rate, target_s=8.0):
     """Same port, one oracle instance per host core (threads; ctypes releases the GIL)."""
     from concurrent.futures import ThreadPoolExecutor
@@ -397,7 +424,11 @@ def main():
             host_bits = d_bits[:64 * 5120 if not grid else d_bits.numel()].cpu().numpy()
             ndop = eng.num_doppler_total if grid else eng.num_doppler
             if args.config in (1, 2):
-                out["cpu_baseline"] = cpu_baseline(cfg, host_bits, ndop)
+                port = cpu_baseline(cfg, host_bits, ndop)
+                ref = cpu_baseline_reference(cfg, host_bits, ndop)
+                out["cpu_baseline"] = ref or port
+                if ref:
+                    out["cpu_baseline_port"] = port
                 try:
                     out["cpu_baseline_all_cores"] = cpu_baseline_all_cores(cfg, host_bits, ndop, out["cpu_baseline"]["value"])
                 except Exception as ex:  # the 1-thread figure is the contract; this one is informative

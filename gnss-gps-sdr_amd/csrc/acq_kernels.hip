@@ -17,6 +17,7 @@
 #include <hip/hip_runtime.h>
 
 #include <cstdlib>
+#include <type_traits>
 
 #include "acq_launch.hpp"
 #include "acq_phases.hpp"
@@ -210,17 +211,17 @@ __global__ __launch_bounds__(WG, WPS) void k_corr(CorrArgs a) {
 // not a pipe but the time a wave spends waiting (L2 latency after every third barrier, barrier skew):
 //   * PRE rows (of 10) of the next sub-transform's inputs are requested before the barrier that ends
 //     pass 3, the rest after it
-//   * ROLES: pass 2 by wave role (acq_phases.hpp), role = (wave + f(workgroup)) % 4 so that the light
-//     role lands on a different SIMD in co-resident workgroups
+//   * LAYB: LDS slot map with 16-byte pass-1 stores and pass-3 reads (acq_math.hpp)
 //   * one workgroup walks a contiguous chunk of a task's Doppler bins (a.nchunk workgroups per task):
 //     the q-independent twiddles are fetched once per chunk and the next cell's first loads are in
 //     flight during the peak scan
 // ABL != 0: timing-only ablations (WRONG results; GPSACQ_KVAR 30..): 1 no global loads in the loop, 2 no LDS stores in
 // pass 1, 3 pass 2 skipped, 4 no barriers, 5 no pass-3 arithmetic
-template <int MC, int WPS, int PRE, bool ROLES, bool PROF, bool PIPE2 = true, int ABL = 0>
+template <int MC, int WPS, int PRE, bool LAYB, bool PROF, bool PIPE2 = true, int ABL = 0>
 __global__ __launch_bounds__(WG, WPS) void k_corr2(CorrArgs a) {
     static_assert(PRE >= 0 && PRE <= RA, "prefetch rows");
-    __shared__ cf lds[M_SUB];
+    using L = typename std::conditional<LAYB, LayB, LayA>::type;
+    __shared__ __attribute__((aligned(16))) cf lds[L::SIZE];
     __shared__ __attribute__((aligned(16))) cf t2s[PIPE2 ? NT2U : NT2];  // pass-2 twiddles (order of use / [beta][j''])
     __shared__ float red[4 * (WG / 64)];
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
@@ -241,9 +242,7 @@ __global__ __launch_bounds__(WG, WPS) void k_corr2(CorrArgs a) {
         }
         return;
     }
-    // virtual thread index: wave role * 64 + lane
-    const int role = ROLES ? ((wave + ((slot * 0x9E3779B1u) >> 30)) & 3) : wave;
-    const int tid = role * 64 + lane;
+    const int tid = threadIdx.x;
     const cf* dpp0 = a.dpp + (size_t)tk.spec * a.sub * NPOLY * M_SUB;  // the block's first spectrum (sub-bin offset 0)
     const cf* cpp = a.cpp + (size_t)tk.code * NPOLY * a.crow;
 
@@ -304,15 +303,14 @@ __global__ __launch_bounds__(WG, WPS) void k_corr2(CorrArgs a) {
                     for (int i = 0; i < RA; ++i) sink = sink + x0[i] * w1[0][i % 9] + x1[i] * w1[1][i % 9];
                     if (sink.x == 12345.f) lds[tid] = sink;
                 } else
-                corr_phase1_store(tid, x0, x1, w1, lds);
+                corr_phase1_store<L>(tid, x0, x1, w1, lds);
             }
             ACQ_STAMP(1);  // pass 1 done
             if (ABL != 4) __syncthreads();
             ACQ_STAMP(2);  // barrier 1
             if (ABL == 3) {}
-            else if (ROLES) corr_phase2_roles<PIPE2>(tid, t2s, a.t2, lds);
-            else if (PIPE2) { if (tid < NBF2) pass2_pipe<+1>(tid, t2s, lds); }
-            else corr_phase2(tid, t2s, lds);
+            else if (PIPE2) { if (tid < NBF2) pass2_pipe<+1, L>(tid, t2s, lds); }
+            else if (tid < NBF2) pass2_inplace<+1, L>(tid, t2s, lds);
             ACQ_STAMP(3);  // pass 2 done
             if (ABL != 4) __syncthreads();
             ACQ_STAMP(4);  // barrier 2
@@ -322,7 +320,7 @@ __global__ __launch_bounds__(WG, WPS) void k_corr2(CorrArgs a) {
             // (requested unconditionally: after the chunk's last sub-transform the rows of bin di1 are fetched and dropped --
             // a conditional request would keep the old rows alive through passes 2 and 3 as the other arm of the merge)
             if (ABL == 5) { if (tid < NBF3) acc[q] = acc[q] + lds[tid] * b; }
-            else corr_phase3<MC>(tid, b, wqv, lds, acc);
+            else corr_phase3<MC, L>(tid, b, wqv, lds, acc);
             if (PRE > 0) {
                 ACQ_SCHED_FENCE();
                 corr_issue<0, PRE>(tid, nq, ndp, ndpp, cpp, a.crow, a.halo, pd, pc);
@@ -373,8 +371,8 @@ __global__ __launch_bounds__(WG, WPS) void k_corr2(CorrArgs a) {
         dpp = dpp_next;
     }
 #undef ACQ_STAMP
-    if (PROF && a.prof && lane == 0 && (role == 0 || role == 3)) {
-        for (int k = 0; k < 8; ++k) atomicAdd(a.prof + (role == 0 ? 0 : 8) + k, tprof[k]);
+    if (PROF && a.prof && lane == 0 && (wave == 0 || wave == 3)) {
+        for (int k = 0; k < 8; ++k) atomicAdd(a.prof + (wave == 0 ? 0 : 8) + k, tprof[k]);
     }
 }
 
@@ -436,6 +434,19 @@ __global__ __launch_bounds__(WG) void k_peaks(const Cell* cells, Peak* peaks, in
     }
 }
 
+// Multi-GPU merge key of a peak: integer MAX over
+//   key = snr bits << 32 | (0xFFFF - (lo_shift + kmax)) << 16 | ca_shift
+// picks the higher SNR and, on equal SNR, the LOWER Doppler grid point -- the reference's strict '>' scan over
+// ascending dop (:196-198).  Non-negative IEEE floats order like their bit patterns.
+__global__ void k_pack_keys(const Peak* peaks, unsigned long long* keys, int n, int kmax) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const Peak p = peaks[i];
+    const unsigned long long snr = (unsigned long long)__float_as_uint(p.snr > 0.f ? p.snr : 0.f);
+    const unsigned long long lo = (unsigned long long)(0xFFFF - (p.lo_shift + kmax)) & 0xFFFFull;
+    keys[i] = (snr << 32) | (lo << 16) | ((unsigned long long)p.ca_shift & 0xFFFFull);
+}
+
 // ---------------------------------------------------------------------------------------
 // launchers (host)
 void launch_fwd_bits(const FwdArgs& a, int n_items, hipStream_t s) {
@@ -484,22 +495,22 @@ int launch_corr(const CorrArgs& a0, int mc, hipStream_t s) {
     if (mc == 22 && a.n_acc == 1 && kv >= 1) {
         a.nchunk = corr_chunks(a.ndop);
         const dim3 grid2((unsigned)groups * 8u * (unsigned)a.nchunk);
-#define K2(PRE, ROLES, PROF, PIPE2) hipLaunchKernelGGL((k_corr2<22, 3, PRE, ROLES, PROF, PIPE2>), grid2, block, 0, s, a)
+#define K2(PRE, LAYB, PROF, PIPE2) hipLaunchKernelGGL((k_corr2<22, 3, PRE, LAYB, PROF, PIPE2>), grid2, block, 0, s, a)
 #define K2A(ABL) hipLaunchKernelGGL((k_corr2<22, 3, 0, false, false, true, ABL>), grid2, block, 0, s, a)
         switch (kv) {
             case 1: K2(0, false, false, false); break;  // k_corr's structure, chunked cells
             case 2: K2(0, false, false, true); break;   // + pipelined pass 2
             case 3: K2(5, false, false, true); break;   // + half the rows requested before the barrier
-            case 4: K2(7, false, false, true); break;
-            case 5: K2(0, true, false, true); break;    // wave roles
-            case 6: K2(7, true, false, true); break;
+            case 4: K2(0, true, false, true); break;    // layout B
+            case 5: K2(5, true, false, true); break;
+            case 6: K2(0, true, false, false); break;   // layout B, pass 2 as in k_corr
             case 31: K2A(1); break;  // ablations (wrong results, timing only)
             case 32: K2A(2); break;
             case 33: K2A(3); break;
             case 34: K2A(4); break;
             case 35: K2A(5); break;
             case 20: K2(0, false, true, true); break;   // s_memtime phase profiles
-            case 21: K2(7, true, true, true); break;
+            case 21: K2(0, true, true, true); break;
             default: return -1;
         }
 #undef K2
@@ -522,10 +533,12 @@ int launch_corr(const CorrArgs& a0, int mc, hipStream_t s) {
             break;
         case 33:
             if (a.n_acc > 1) hipLaunchKernelGGL((k_corr<33, 2, 2, true>), grid, block, 0, s, a);
+            else if (getenv("GPSACQ_WIDE3")) hipLaunchKernelGGL((k_corr<33, 3, 2, false>), grid, block, 0, s, a);
             else hipLaunchKernelGGL((k_corr<33, 2, 2, false>), grid, block, 0, s, a);
             break;
         case 40:
             if (a.n_acc > 1) hipLaunchKernelGGL((k_corr<40, 1, 2, true>), grid, block, 0, s, a);  // 84 KB of LDS: one workgroup per CU
+            else if (getenv("GPSACQ_WIDE3")) hipLaunchKernelGGL((k_corr<40, 3, 2, false>), grid, block, 0, s, a);
             else hipLaunchKernelGGL((k_corr<40, 2, 2, false>), grid, block, 0, s, a);
             break;
         default: return -1;
@@ -534,6 +547,9 @@ int launch_corr(const CorrArgs& a0, int mc, hipStream_t s) {
 }
 void launch_merge_cells(const Cell* parts, Cell* cells, size_t n_cells, int n_parts, int nlags, hipStream_t s) {
     hipLaunchKernelGGL(k_merge_cells, dim3((unsigned)((n_cells + 255) / 256)), dim3(256), 0, s, parts, cells, n_cells, n_parts, nlags);
+}
+void launch_pack_keys(const Peak* peaks, unsigned long long* keys, int n, int kmax, hipStream_t s) {
+    hipLaunchKernelGGL(k_pack_keys, dim3((n + 255) / 256), dim3(256), 0, s, peaks, keys, n, kmax);
 }
 void launch_peaks(const Cell* cells, Peak* peaks, int n_tasks, int ndop, int dop_first, hipStream_t s) {
     const int per_wg = WG / 64;

@@ -60,6 +60,7 @@ int corr_columns(int nlags);
 hipError_t upload_wq(const cf* host);  // fills the __constant__ copy of wq on the current device
 int launch_corr(const CorrArgs& a, int mc, hipStream_t s);
 void launch_merge_cells(const Cell* parts, Cell* cells, size_t n_cells, int n_parts, int nlags, hipStream_t s);
+void launch_pack_keys(const Peak* peaks, unsigned long long* keys, int n, int kmax, hipStream_t s);
 void launch_peaks(const Cell* cells, Peak* peaks, int n_tasks, int ndop, int dop_first, hipStream_t s);
 
 }  // namespace acq

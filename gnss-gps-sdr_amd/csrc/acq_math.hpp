@@ -323,12 +323,22 @@ ACQ_HD void ld2u(const cf* p, cf& a, cf& b) {
     b = v.zw;
 }
 
+// Where element (alpha, j'', b) of the in-place transform lives in the workgroup's LDS buffer (complex units):
+//   LayA (k_corr, k_fwd)   500 alpha + 25 j'' + b : a pass-2 butterfly's 25 elements are contiguous (paired 8-byte accesses),
+//                          pass-1 stores and pass-3 reads are strided and pay 2-way bank conflicts
+//   LayB (k_corr2)         564 alpha + 22 b + j'' : the two butterflies a pass-1 thread owns (j' = 2 tid, 2 tid + 1) are
+//                          neighbours, so their outputs leave as ONE 16-byte store per alpha, and a pass-3 thread's 20
+//                          elements are contiguous (ten 16-byte reads); 22 and 564 keep every access conflict-free
+//                          (176-byte lane stride for the 16-byte reads, 564 - 20 = 17 * 32 across the alpha boundary of pass 2)
+struct LayA { static constexpr int SA = NBF1, SJ = RB, SB = 1, SIZE = M_SUB; };
+struct LayB { static constexpr int SA = 564, SJ = 1, SB = 22, SIZE = 10 * 564; };
+
 // pass 1 for butterfly jp (0..499): x[a] = element jp + 500 a; w[al-1] = t1[al*500 + jp].
-template <int DIR> ACQ_HD void pass1_store(const cf* x, int jp, const cf* w, cf* lds) {
+template <int DIR, class L = LayA> ACQ_HD void pass1_store(const cf* x, int jp, const cf* w, cf* lds) {
     cf y[RA];
     radix10<DIR>(x, y);
     const int b = jp / RC, jpp = jp - b * RC;
-    cf* dst = lds + RB * jpp + b;
+    cf* dst = lds + L::SJ * jpp + L::SB * b;
 #if ACQ_ABL == 6 && defined(__HIP_DEVICE_COMPILE__)
     ACQ_SINK(y[0]);
 #pragma unroll
@@ -337,36 +347,61 @@ template <int DIR> ACQ_HD void pass1_store(const cf* x, int jp, const cf* w, cf*
 #else
     dst[0] = y[0];
 #pragma unroll
-    for (int al = 1; al < RA; ++al) dst[NBF1 * al] = tw<DIR>(y[al], w[al - 1]);
+    for (int al = 1; al < RA; ++al) dst[L::SA * al] = tw<DIR>(y[al], w[al - 1]);
 #endif
+}
+// LayB: butterflies jp = 2 t and 2 t + 1 together, one 16-byte store per alpha
+template <int DIR> ACQ_HD void pass1_store_pair(const cf* x0, const cf* x1, int t, const cf* w0, const cf* w1, cf* lds) {
+    cf y0[RA], y1[RA];
+    radix10<DIR>(x0, y0);
+    radix10<DIR>(x1, y1);
+    const int jp = 2 * t, b = jp / RC, jpp = jp - b * RC;  // jpp even: the pair never straddles a row of 20
+    cf* dst = lds + LayB::SB * b + jpp;
+#pragma unroll
+    for (int al = 0; al < RA; ++al) {
+        const cf a0 = al ? tw<DIR>(y0[al], w0[al - 1]) : y0[0], a1 = al ? tw<DIR>(y1[al], w1[al - 1]) : y1[0];
+        cf2 v;
+        v.xy = a0;
+        v.zw = a1;
+#if ACQ_ABL == 6 && defined(__HIP_DEVICE_COMPILE__)
+        ACQ_SINK(v);
+#else
+        *reinterpret_cast<cf2*>(dst + LayB::SA * al) = v;
+#endif
+    }
 }
 
 // pass 2 for butterfly e (0..199), in place; t2 may live in LDS (its own allocation, so the
 // compiler knows the in-place stores do not alias it) or in global memory.
-template <int DIR> ACQ_HD void pass2_inplace(int e, const cf* __restrict__ t2, cf* lds) {
+template <int DIR, class L = LayA> ACQ_HD void pass2_inplace(int e, const cf* __restrict__ t2, cf* lds) {
     const int al = e / RC, jpp = e - al * RC;
-    cf* p = lds + NBF1 * al + RB * jpp;
+    cf* p = lds + L::SA * al + L::SJ * jpp;
     cf x[RB], y[RB];
 #pragma unroll
-    for (int b = 0; b < RB; ++b) x[b] = p[b];
+    for (int b = 0; b < RB; ++b) x[b] = p[L::SB * b];
     radix25<DIR>(x, y);
     p[0] = y[0];
 #pragma unroll
-    for (int be = 1; be < RB; ++be) p[be] = tw<DIR>(y[be], t2[be * RC + jpp]);
+    for (int be = 1; be < RB; ++be) p[L::SB * be] = tw<DIR>(y[be], t2[be * RC + jpp]);
 }
 
 // pass 3 for butterfly t3 (0..249): y[n''] = F[250 n'' + rho(t3)].
-template <int DIR> ACQ_HD void pass3_load(int t3, const cf* lds, cf* y) {
+template <int DIR, class L = LayA> ACQ_HD void pass3_load(int t3, const cf* lds, cf* y) {
     const int al = t3 / RB, be = t3 - al * RB;
-    const cf* p = lds + NBF1 * al + be;
+    const cf* p = lds + L::SA * al + L::SB * be;
     cf x[RC];
 #if ACQ_ABL == 8 && defined(__HIP_DEVICE_COMPILE__)
     (void)p;
 #pragma unroll
     for (int jpp = 0; jpp < RC; ++jpp) ACQ_JUNK(x[jpp]);
 #else
+    if (L::SJ == 1) {  // contiguous: 16-byte reads (SA and SB keep p 16-byte aligned)
 #pragma unroll
-    for (int jpp = 0; jpp < RC; ++jpp) x[jpp] = p[RB * jpp];
+        for (int jpp = 0; jpp < RC; jpp += 2) ld2(p + jpp, x[jpp], x[jpp + 1]);
+    } else {
+#pragma unroll
+        for (int jpp = 0; jpp < RC; ++jpp) x[jpp] = p[L::SJ * jpp];
+    }
 #endif
     radix20<DIR>(x, y);
 }

@@ -113,11 +113,11 @@ ACQ_HD void corr_phase2(int tid, const cf* t2, cf* lds) {
 // acc[m] accumulates y[n] for n = 250 (m0 + m) + rho over the 8 polyphase components (m0, the first
 // column of this pass, is a multiple of 20 so that column m0 + m reads radix-20 output m % 20):
 // W_N^{-q n} = conj(b) (per thread, b = bq[q][tid]) * conj(wqv[m]) (wave-uniform, wqv[m] = W_160^{q m}).
-template <int MC>
+template <int MC, class L = LayA>
 ACQ_HD void corr_phase3(int tid, cf b, const cf* wqv, const cf* lds, cf* acc) {
     if (tid >= NBF3) return;
     cf y[RC];
-    pass3_load<+1>(tid, lds, y);
+    pass3_load<+1, L>(tid, lds, y);
 #pragma unroll
     for (int n = 0; n < RC; ++n) y[n] = cmulc(y[n], b);
 #pragma unroll
@@ -165,10 +165,15 @@ ACQ_HD void corr_mul(const cf2 (&d)[RA], const cf2 (&cc)[RA], cf (&x0)[RA], cf (
         x1[i] = cmul(d[i].zw, cc[i].zw);
     }
 }
+template <class L>
 ACQ_HD void corr_phase1_store(int tid, const cf (&x0)[RA], const cf (&x1)[RA], const cf (&w)[2][RA - 1], cf* lds) {
     if (tid >= NBF3) return;
-    pass1_store<+1>(x0, 2 * tid, w[0], lds);
-    pass1_store<+1>(x1, 2 * tid + 1, w[1], lds);
+    if (L::SJ == 1) {
+        pass1_store_pair<+1>(x0, x1, tid, w[0], w[1], lds);
+    } else {
+        pass1_store<+1, L>(x0, 2 * tid, w[0], lds);
+        pass1_store<+1, L>(x1, 2 * tid + 1, w[1], lds);
+    }
 }
 
 // Pass 2 with its LDS traffic software-pipelined.  The s_memtime profile of round 2 (profiles/r02a) showed
@@ -185,11 +190,11 @@ ACQ_HD int t2u_beta(int i) { return i < 4 ? 5 * (i + 1) : ((i - 4) / 5 + 1) + 5 
 #if ACQ_ABL == 7 && defined(__HIP_DEVICE_COMPILE__)
 #define ACQ_ST(n, expr) do { cf v_ = (expr); ACQ_SINK(v_); } while (0)
 #else
-#define ACQ_ST(n, expr) p[n] = (expr)
+#define ACQ_ST(n, expr) p[L::SB * (n)] = (expr)
 #endif
-template <int DIR> ACQ_HD void pass2_pipe(int e, const cf* __restrict__ t2u, cf* lds) {
+template <int DIR, class L = LayA> ACQ_HD void pass2_pipe(int e, const cf* __restrict__ t2u, cf* lds) {
     const int al = e / RC, jpp = e - al * RC;
-    cf* p = lds + NBF1 * al + RB * jpp;
+    cf* p = lds + L::SA * al + L::SJ * jpp;
     const cf2* twp = reinterpret_cast<const cf2*>(t2u + T2U_ROW * jpp);
     cf x[RB];
     cf2 c[12];
@@ -201,7 +206,7 @@ template <int DIR> ACQ_HD void pass2_pipe(int e, const cf* __restrict__ t2u, cf*
 #define ACQ_TWLD(i) ((void)0)
 #else
 #pragma unroll
-    for (int b = 0; b < RB; ++b) x[b] = p[b];
+    for (int b = 0; b < RB; ++b) x[b] = p[L::SB * b];
 #define ACQ_TWLD(i) c[i] = twp[i]
 #endif
     ACQ_TWLD(0);
@@ -272,71 +277,6 @@ template <int DIR> ACQ_HD void pass2_pipe(int e, const cf* __restrict__ t2u, cf*
 }
 #undef ACQ_ST
 #undef ACQ_TWLD
-
-// Pass 2 by wave role.  200 radix-25 butterflies on four 64-lane waves leave the fourth wave with 8
-// active lanes for the longest instruction stream of the kernel.  Roles 0..2 take butterflies 0..191
-// (all lanes busy); role 3 does the remaining 8 as a two-step 5 x 5 on 40 lanes: step 1 = dft5 over
-// n1 of x[5 n1 + n2] (+ W_25^{n2 k1}), step 2 = dft5 over n2 (+ the pass-2 twiddle), exchanged through
-// the butterfly's own 25 LDS slots.  A wave's LDS operations execute in order, so inside one wave no
-// barrier is needed between the steps.  W_25^{n2 k1} = W_500^{20 n2 k1} = t2[(5 k1) * 20 + 4 n2].
-constexpr int TAIL_E0 = 3 * 64;             // first butterfly of the tail
-constexpr int TAIL_LANES = 5 * (NBF2 - TAIL_E0);  // 40
-template <int DIR> ACQ_HD void pass2_tail1(int L, const cf* __restrict__ t2, cf* lds) {
-    const int i = L / 5, n2 = L - 5 * i, e = TAIL_E0 + i;
-    const int al = e / RC, jpp = e - al * RC;
-    cf* p = lds + NBF1 * al + RB * jpp + n2;
-    cf a = p[0], b = p[5], c = p[10], d = p[15], f = p[20];
-    dft5<DIR>(a, b, c, d, f);
-    const cf* w = t2 + 4 * n2;  // n2 = 0: all ones
-    p[0] = a;
-    p[5] = tw<DIR>(b, w[5 * RC]);
-    p[10] = tw<DIR>(c, w[10 * RC]);
-    p[15] = tw<DIR>(d, w[15 * RC]);
-    p[20] = tw<DIR>(f, w[20 * RC]);  // (t2 is the [beta][j''] table in global memory: 40 lanes, once per sub-transform)
-}
-template <int DIR> ACQ_HD void pass2_tail2_load(int L, const cf* lds, cf* y) {
-    const int i = L / 5, k1 = L - 5 * i, e = TAIL_E0 + i;
-    const int al = e / RC, jpp = e - al * RC;
-    const cf* p = lds + NBF1 * al + RB * jpp + 5 * k1;
-    y[0] = p[0]; y[1] = p[1]; y[2] = p[2]; y[3] = p[3]; y[4] = p[4];
-    dft5<DIR>(y[0], y[1], y[2], y[3], y[4]);
-}
-template <int DIR> ACQ_HD void pass2_tail2_store(int L, const cf* __restrict__ t2, const cf* y, cf* lds) {
-    const int i = L / 5, k1 = L - 5 * i, e = TAIL_E0 + i;
-    const int al = e / RC, jpp = e - al * RC;
-    cf* p = lds + NBF1 * al + RB * jpp + k1;
-    const cf* w = t2 + k1 * RC + jpp;  // t2[(k1 + 5 k2) * 20 + jpp]
-#pragma unroll
-    for (int k2 = 0; k2 < 5; ++k2) p[5 * k2] = tw<DIR>(y[k2], w[5 * k2 * RC]);  // (k1, k2) = (0, 0): t2 = 1
-}
-#if defined(__HIP_DEVICE_COMPILE__)
-#define ACQ_WAVE_FENCE()                                       \
-    do {                                                       \
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); \
-        __builtin_amdgcn_wave_barrier();                       \
-        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront"); \
-    } while (0)
-#else
-#define ACQ_WAVE_FENCE() ((void)0)
-#endif
-// device form: vt = 64 role + lane.  t2s: the workgroup's LDS copy of the pass-2 twiddles (order of use if PIPE,
-// else [beta][j'']); t2g: the [beta][j''] table in global memory for the 40 tail lanes when PIPE.
-template <bool PIPE>
-ACQ_HD void corr_phase2_roles(int vt, const cf* t2s, const cf* __restrict__ t2g, cf* lds) {
-    if (vt < TAIL_E0) {
-        if (PIPE) pass2_pipe<+1>(vt, t2s, lds);
-        else pass2_inplace<+1>(vt, t2s, lds);
-    } else if (vt - TAIL_E0 < TAIL_LANES) {
-        const int L = vt - TAIL_E0;
-        const cf* t2 = PIPE ? t2g : t2s;
-        pass2_tail1<+1>(L, t2, lds);
-        ACQ_WAVE_FENCE();
-        cf y[5];
-        pass2_tail2_load<+1>(L, lds, y);
-        ACQ_WAVE_FENCE();
-        pass2_tail2_store<+1>(L, t2, y, lds);
-    }
-}
 
 // Doppler grid point k (in units of the grid step) -> whole-bin shift `dop` of the code spectrum (:182) and the
 // index r of the sub-bin-offset spectrum of the block.  sub > 1: step = bin / sub, k = dop * sub + r with

@@ -34,6 +34,10 @@ static int fail(int code, const char* fmt, ...) {
     g_err = buf;
     return code;
 }
+extern "C" int gpsacq_set_error_(int code, const char* msg) {  // for the other translation units of the library
+    g_err = msg ? msg : "";
+    return code;
+}
 #define HIPCHK(expr)                                                                                  \
     do {                                                                                              \
         hipError_t e_ = (expr);                                                                       \

@@ -1,0 +1,226 @@
+// gpsacq_multi.cpp -- single-process multi-GPU search of one capture's PRN x Doppler grid (include/gpsacq.h,
+// gpsacq_multi_*): one engine per device, the Doppler grid cut into one contiguous slab per device, and ONE
+// ncclAllReduce(MAX) of the packed per-task peak keys over RCCL (xGMI on an 8 x MI355X node) -- the only exchange
+// step of the path (BASELINE.json north_star: "RCCL all-reduce of the per-PRN peak only").  The reference has no
+// parallelism at all (c/search_offline.cpp is one thread); every (block, PRN, Doppler) cell is independent.
+//
+// RCCL is loaded with dlopen at the first gpsacq_multi_create so that libgpsacq.so carries no link dependency on it
+// (a process that already holds an RCCL -- PyTorch bundles one under the same SONAME -- keeps using that copy).
+#include <dlfcn.h>
+#include <hip/hip_runtime.h>
+#include <rccl/rccl.h>
+
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "../../include/gpsacq.h"
+#include "acq_launch.hpp"
+
+using namespace acq;
+
+extern "C" int gpsacq_set_error_(int code, const char* msg);  // gpsacq_engine.cpp: sets gpsacq_last_error() of this thread
+
+namespace {
+struct Rccl {
+    void* so = nullptr;
+    ncclResult_t (*CommInitAll)(ncclComm_t*, int, const int*) = nullptr;
+    ncclResult_t (*CommDestroy)(ncclComm_t) = nullptr;
+    ncclResult_t (*AllReduce)(const void*, void*, size_t, ncclDataType_t, ncclRedOp_t, ncclComm_t, hipStream_t) = nullptr;
+    ncclResult_t (*GroupStart)() = nullptr;
+    ncclResult_t (*GroupEnd)() = nullptr;
+    const char* (*GetErrorString)(ncclResult_t) = nullptr;
+};
+Rccl g_rccl;
+const char* load_rccl() {
+    if (g_rccl.so) return nullptr;
+    for (const char* name : {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"}) {
+        g_rccl.so = dlopen(name, RTLD_NOW | RTLD_GLOBAL);
+        if (g_rccl.so) break;
+    }
+    if (!g_rccl.so) return "librccl.so.1 not found (dlopen)";
+#define SYM(field, name)                                                       \
+    g_rccl.field = reinterpret_cast<decltype(g_rccl.field)>(dlsym(g_rccl.so, name)); \
+    if (!g_rccl.field) return "RCCL symbol " name " missing";
+    SYM(CommInitAll, "ncclCommInitAll")
+    SYM(CommDestroy, "ncclCommDestroy")
+    SYM(AllReduce, "ncclAllReduce")
+    SYM(GroupStart, "ncclGroupStart")
+    SYM(GroupEnd, "ncclGroupEnd")
+    SYM(GetErrorString, "ncclGetErrorString")
+#undef SYM
+    return nullptr;
+}
+int failf(int code, const char* fmt, ...) {
+    char buf[512];
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(buf, sizeof buf, fmt, ap);
+    va_end(ap);
+    return gpsacq_set_error_(code, buf);
+}
+}  // namespace
+
+struct gpsacq_multi {
+    std::vector<gpsacq_engine*> eng;
+    std::vector<int> dev;
+    std::vector<ncclComm_t> comm;
+    std::vector<uint8_t*> d_bits;
+    std::vector<size_t> bits_cap;
+    std::vector<Task*> d_tasks;
+    std::vector<Peak*> d_peaks;
+    std::vector<unsigned long long*> d_keys;
+    std::vector<size_t> task_cap;
+    gpsacq_info info{};
+};
+
+#define HIPM(expr)                                                                                        \
+    do {                                                                                                  \
+        hipError_t e_ = (expr);                                                                           \
+        if (e_ != hipSuccess) return failf(e_ == hipErrorOutOfMemory ? GPSACQ_ERR_NOMEM : GPSACQ_ERR_DEVICE, "%s: %s", #expr, hipGetErrorString(e_)); \
+    } while (0)
+#define NCCLM(expr)                                                                                \
+    do {                                                                                           \
+        ncclResult_t r_ = (expr);                                                                  \
+        if (r_ != ncclSuccess) return failf(GPSACQ_ERR_DEVICE, "%s: %s", #expr, g_rccl.GetErrorString(r_)); \
+    } while (0)
+
+extern "C" void gpsacq_multi_destroy(gpsacq_multi* m) {
+    if (!m) return;
+    for (size_t i = 0; i < m->eng.size(); ++i) {
+        (void)hipSetDevice(m->dev[i]);
+        if (m->eng[i]) (void)gpsacq_synchronize(m->eng[i]);
+        if (i < m->comm.size() && m->comm[i]) (void)g_rccl.CommDestroy(m->comm[i]);
+        for (void* p : {(void*)m->d_bits[i], (void*)m->d_tasks[i], (void*)m->d_peaks[i], (void*)m->d_keys[i]})
+            if (p) (void)hipFree(p);
+        gpsacq_destroy(m->eng[i]);
+    }
+    delete m;
+}
+
+extern "C" int gpsacq_multi_create(const gpsacq_params* params, const int32_t* devices, int n_devices, gpsacq_multi** out) {
+    if (!params || !out || n_devices < 1 || n_devices > 64) return failf(GPSACQ_ERR_ARG, "gpsacq_multi_create: bad argument");
+    *out = nullptr;
+    if (params->ref_quirks) return failf(GPSACQ_ERR_UNSUPPORTED, "ref_quirks belongs to the reference's one-block-per-PRN schedule, not to the grid search");
+    if (const char* why = load_rccl()) return failf(GPSACQ_ERR_DEVICE, "RCCL unavailable: %s", why);
+    gpsacq_multi* m = new gpsacq_multi();
+    const size_t n = (size_t)n_devices;
+    m->eng.assign(n, nullptr);
+    m->dev.resize(n);
+    m->d_bits.assign(n, nullptr);
+    m->bits_cap.assign(n, 0);
+    m->d_tasks.assign(n, nullptr);
+    m->d_peaks.assign(n, nullptr);
+    m->d_keys.assign(n, nullptr);
+    m->task_cap.assign(n, 0);
+    for (size_t i = 0; i < n; ++i) {
+        m->dev[i] = devices ? devices[i] : (int)i;
+        gpsacq_params p = *params;
+        p.device = m->dev[i];
+        if (int rc = gpsacq_create(&p, &m->eng[i])) {
+            gpsacq_multi_destroy(m);
+            return rc;
+        }
+    }
+    m->comm.assign(n, nullptr);
+    ncclResult_t r = g_rccl.CommInitAll(m->comm.data(), n_devices, m->dev.data());
+    if (r != ncclSuccess) {
+        int rc = failf(GPSACQ_ERR_DEVICE, "ncclCommInitAll over %d device(s): %s", n_devices, g_rccl.GetErrorString(r));
+        for (auto& c : m->comm) c = nullptr;
+        gpsacq_multi_destroy(m);
+        return rc;
+    }
+    (void)gpsacq_get_info(m->eng[0], &m->info);
+    *out = m;
+    return GPSACQ_OK;
+}
+
+extern "C" int gpsacq_multi_set_doppler_step(gpsacq_multi* m, double step_hz) {
+    if (!m) return failf(GPSACQ_ERR_ARG, "gpsacq_multi_set_doppler_step: null handle");
+    for (gpsacq_engine* e : m->eng)
+        if (int rc = gpsacq_set_doppler_step(e, step_hz)) return rc;
+    (void)gpsacq_get_info(m->eng[0], &m->info);
+    return GPSACQ_OK;
+}
+
+extern "C" int gpsacq_multi_get_info(const gpsacq_multi* m, gpsacq_info* info, int32_t* n_devices) {
+    if (!m || !info) return failf(GPSACQ_ERR_ARG, "gpsacq_multi_get_info: null argument");
+    *info = m->info;
+    if (n_devices) *n_devices = (int32_t)m->eng.size();
+    return GPSACQ_OK;
+}
+
+extern "C" int gpsacq_multi_search_grid(gpsacq_multi* m, const uint8_t* bits, size_t n_blocks, size_t stride, const gpsacq_task* tasks,
+                                        size_t n_tasks, gpsacq_peak* peaks) {
+    if (!m || !bits || !tasks || !peaks || n_blocks == 0 || n_tasks == 0 || stride < 5000) return failf(GPSACQ_ERR_ARG, "gpsacq_multi_search_grid: bad argument");
+    for (size_t t = 0; t < n_tasks; ++t)
+        if (tasks[t].block < 0 || (size_t)tasks[t].block >= n_blocks || tasks[t].prn < 0 || tasks[t].prn >= GPSACQ_NUM_SATS)
+            return failf(GPSACQ_ERR_ARG, "task %zu = (block %d, prn %d) out of range", t, tasks[t].block, tasks[t].prn);
+    const size_t n = m->eng.size();
+    const size_t nbytes = (n_blocks - 1) * stride + (stride < (size_t)GPSACQ_BLOCK_BYTES ? stride : (size_t)GPSACQ_BLOCK_BYTES);
+    const int total = m->info.num_doppler_total, first = m->info.first_doppler_total, kmax = -first;
+    std::vector<int> active;
+    for (size_t i = 0; i < n; ++i) {
+        // contiguous, balanced slab of the grid for device i (possibly empty when there are more devices than points)
+        const int base = total / (int)n, rem = total % (int)n;
+        const int cnt = base + ((int)i < rem ? 1 : 0), off = (int)i * base + ((int)i < rem ? (int)i : rem);
+        HIPM(hipSetDevice(m->dev[i]));
+        hipStream_t st = (hipStream_t)gpsacq_stream(m->eng[i]);
+        if (nbytes > m->bits_cap[i]) {
+            if (m->d_bits[i]) HIPM(hipFree(m->d_bits[i]));
+            m->d_bits[i] = nullptr;
+            HIPM(hipMalloc((void**)&m->d_bits[i], nbytes));
+            m->bits_cap[i] = nbytes;
+        }
+        if (n_tasks > m->task_cap[i]) {
+            for (void** p : {(void**)&m->d_tasks[i], (void**)&m->d_peaks[i], (void**)&m->d_keys[i]}) {
+                if (*p) HIPM(hipFree(*p));
+                *p = nullptr;
+            }
+            HIPM(hipMalloc((void**)&m->d_tasks[i], n_tasks * sizeof(Task)));
+            HIPM(hipMalloc((void**)&m->d_peaks[i], n_tasks * sizeof(Peak)));
+            HIPM(hipMalloc((void**)&m->d_keys[i], n_tasks * sizeof(unsigned long long)));
+            m->task_cap[i] = n_tasks;
+        }
+        if (cnt > 0) {
+            HIPM(hipMemcpyAsync(m->d_bits[i], bits, nbytes, hipMemcpyHostToDevice, st));
+            HIPM(hipMemcpyAsync(m->d_tasks[i], tasks, n_tasks * sizeof(Task), hipMemcpyHostToDevice, st));
+            if (int rc = gpsacq_set_doppler_window(m->eng[i], first + off, cnt)) return rc;
+            if (int rc = gpsacq_search_device(m->eng[i], m->d_bits[i], n_blocks, stride, m->d_tasks[i], n_tasks, nullptr, m->d_peaks[i], 0)) return rc;
+            launch_pack_keys(m->d_peaks[i], m->d_keys[i], (int)n_tasks, kmax, st);
+            HIPM(hipGetLastError());
+        } else {
+            HIPM(hipMemsetAsync(m->d_keys[i], 0, n_tasks * sizeof(unsigned long long), st));  // key 0 = "nothing found": neutral for MAX
+        }
+    }
+    // the path's one collective: all-reduce(MAX) of n_tasks 64-bit keys across the devices' communicators
+    NCCLM(g_rccl.GroupStart());
+    for (size_t i = 0; i < n; ++i) {
+        ncclResult_t r = g_rccl.AllReduce(m->d_keys[i], m->d_keys[i], n_tasks, ncclUint64, ncclMax, m->comm[i], (hipStream_t)gpsacq_stream(m->eng[i]));
+        if (r != ncclSuccess) {
+            (void)g_rccl.GroupEnd();
+            return failf(GPSACQ_ERR_DEVICE, "ncclAllReduce on device %d: %s", m->dev[i], g_rccl.GetErrorString(r));
+        }
+    }
+    NCCLM(g_rccl.GroupEnd());
+    std::vector<unsigned long long> keys(n_tasks);
+    HIPM(hipSetDevice(m->dev[0]));
+    HIPM(hipMemcpyAsync(keys.data(), m->d_keys[0], n_tasks * sizeof(unsigned long long), hipMemcpyDeviceToHost, (hipStream_t)gpsacq_stream(m->eng[0])));
+    for (size_t i = 0; i < n; ++i) {
+        HIPM(hipSetDevice(m->dev[i]));
+        HIPM(hipStreamSynchronize((hipStream_t)gpsacq_stream(m->eng[i])));
+    }
+    for (size_t t = 0; t < n_tasks; ++t) {
+        const unsigned long long k = keys[t];
+        const uint32_t sb = (uint32_t)(k >> 32);
+        float snr;
+        memcpy(&snr, &sb, sizeof snr);
+        peaks[t].snr = snr;
+        peaks[t].lo_shift = k ? (int32_t)(0xFFFF - ((k >> 16) & 0xFFFF)) - kmax : 0;
+        peaks[t].ca_shift = (int32_t)(k & 0xFFFF);
+        peaks[t].max_pwr = 0.f;  // not carried by the key
+    }
+    return GPSACQ_OK;
+}

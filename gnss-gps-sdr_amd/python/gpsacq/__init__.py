@@ -57,7 +57,8 @@ class Sat(ctypes.Structure):
 
 EXPORTS = ["gpsacq_generate", "gpsacq_generate_device", "gpsacq_handoff", "gpsacq_iq8_to_bits", "gpsacq_iq8_to_bits_device", "gpsacq_create", "gpsacq_destroy", "gpsacq_last_error", "gpsacq_get_info", "gpsacq_search",
            "gpsacq_search_device", "gpsacq_set_doppler_window", "gpsacq_set_doppler_step", "gpsacq_set_noncoherent", "gpsacq_set_creep_compensation", "gpsacq_aligned_stride", "gpsacq_synchronize", "gpsacq_last_timing", "gpsacq_timing_ago", "gpsacq_stream", "gpsacq_search_code",
-           "gpsacq_sample_spectrum", "gpsacq_code_spectrum"]
+           "gpsacq_sample_spectrum", "gpsacq_code_spectrum", "gpsacq_multi_create", "gpsacq_multi_destroy",
+           "gpsacq_multi_set_doppler_step", "gpsacq_multi_get_info", "gpsacq_multi_search_grid"]
 
 _lib = None
 
@@ -139,6 +140,16 @@ def load_library(path=None):
     lib.gpsacq_sample_spectrum.restype = ctypes.c_int
     lib.gpsacq_code_spectrum.argtypes = [vp, ctypes.c_int, vp]
     lib.gpsacq_code_spectrum.restype = ctypes.c_int
+    lib.gpsacq_multi_create.argtypes = [ctypes.POINTER(Params), vp, ctypes.c_int, ctypes.POINTER(vp)]
+    lib.gpsacq_multi_create.restype = ctypes.c_int
+    lib.gpsacq_multi_destroy.argtypes = [vp]
+    lib.gpsacq_multi_destroy.restype = None
+    lib.gpsacq_multi_set_doppler_step.argtypes = [vp, ctypes.c_double]
+    lib.gpsacq_multi_set_doppler_step.restype = ctypes.c_int
+    lib.gpsacq_multi_get_info.argtypes = [vp, ctypes.POINTER(Info), ctypes.POINTER(ctypes.c_int32)]
+    lib.gpsacq_multi_get_info.restype = ctypes.c_int
+    lib.gpsacq_multi_search_grid.argtypes = [vp, vp, sz, sz, vp, sz, vp]
+    lib.gpsacq_multi_search_grid.restype = ctypes.c_int
     if path is None:
         _lib = lib
     return lib
@@ -326,6 +337,57 @@ class Engine:
         out = np.zeros(2 * FFT_LEN, dtype=np.float32)
         _check(self._lib, self._lib.gpsacq_code_spectrum(self._h, int(sv), out.ctypes.data_as(ctypes.c_void_p)))
         return out.view(np.complex64)
+
+
+class MultiEngine:
+    """gpsacq_multi_*: one capture's PRN x Doppler grid cut into Doppler slabs over several GPUs of this process, the
+    per-task peaks merged by one RCCL all-reduce(MAX) of packed keys (include/gpsacq.h)."""
+
+    def __init__(self, fc, fs, max_fo, devices=(0,)):
+        self._lib = load_library()
+        self._h = ctypes.c_void_p()
+        prm = Params(float(fc), float(fs), float(max_fo), 0, 0)
+        dev = (ctypes.c_int32 * len(devices))(*[int(d) for d in devices])
+        _check(self._lib, self._lib.gpsacq_multi_create(ctypes.byref(prm), dev, len(devices), ctypes.byref(self._h)))
+        self._refresh()
+
+    def _refresh(self):
+        info, n = Info(), ctypes.c_int32()
+        _check(self._lib, self._lib.gpsacq_multi_get_info(self._h, ctypes.byref(info), ctypes.byref(n)))
+        self.n_devices = n.value
+        self.num_doppler_total = info.num_doppler_total
+        self.kmax = -info.first_doppler_total
+        self.doppler_step_hz = info.doppler_step_hz
+
+    def set_doppler_step(self, step_hz):
+        _check(self._lib, self._lib.gpsacq_multi_set_doppler_step(self._h, float(step_hz)))
+        self._refresh()
+
+    def search_grid(self, bits, tasks, stride=BLOCK_BYTES):
+        buf = np.ascontiguousarray(np.frombuffer(bits, dtype=np.uint8) if not isinstance(bits, np.ndarray) else bits.view(np.uint8))
+        n_blocks = (buf.size - min(stride, BLOCK_BYTES)) // stride + 1
+        t = np.ascontiguousarray(np.asarray(tasks, dtype=np.int32).reshape(-1, 2))
+        peaks = np.zeros(t.shape[0], dtype=PEAK_DTYPE)
+        _check(self._lib, self._lib.gpsacq_multi_search_grid(self._h, buf.ctypes.data_as(ctypes.c_void_p), n_blocks, stride,
+                                                             t.ctypes.data_as(ctypes.c_void_p), t.shape[0], peaks.ctypes.data_as(ctypes.c_void_p)))
+        return peaks
+
+    def close(self):
+        if self._h:
+            self._lib.gpsacq_multi_destroy(self._h)
+            self._h = ctypes.c_void_p()
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *a):
+        self.close()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
 
 
 def format_report(peaks, first_run=0):

@@ -16,6 +16,7 @@
  *                            SearchTask() loop, :239-246)
  *   gpsacq_search_device     same, capture already resident in HBM
  *   gpsacq_set_doppler_step  the Doppler grid of Correlate()'s loop, :176,182 (finer or coarser than fs/40000)
+ *   gpsacq_multi_search_grid the same Correlate() grid cut over several GPUs, peaks merged by one RCCL all-reduce
  *   gpsacq_search_code       SearchCode()            c/search_offline.cpp:205-209
  *   gpsacq_iq8_to_bits       the MATLAB pre-processing that produces gps_test's input from an 8-bit IQ
  *                            capture: proc_rtl_bin_for_gps.m:12-26,31-47, proc_hackrf_bin_for_gps.m:7-19
@@ -249,6 +250,24 @@ typedef struct {
                            per millisecond (the reference hard-codes 20000 / 10000 for its 10 MHz FPGA, :163) */
 } gpsacq_handoff_t;
 int gpsacq_handoff(const gpsacq_peak* peak, double fc, double fs, double secs_since_sample, gpsacq_handoff_t* out);
+
+/*
+ * Single-process multi-GPU search of ONE capture's PRN x Doppler grid (BASELINE.json configs[4]; the reference is
+ * single-threaded, c/search_offline.cpp has no counterpart).  One engine per listed device; the Doppler grid -K..+K is
+ * cut into one contiguous slab per device, every device searches all tasks over its slab, packs each task's best peak
+ * into a 64-bit key (snr bits << 32 | (0xFFFF - grid index) << 16 | ca_shift: integer MAX = higher SNR, ties to the
+ * LOWER Doppler point like the strict '>' of :196-198) and ONE ncclAllReduce(MAX, uint64) over RCCL (xGMI) merges them.
+ * devices == NULL: ordinals 0..n_devices-1.  n_devices == 1 is the degenerate case (same result as gpsacq_search's
+ * peaks).  peaks[n_tasks]: snr / lo_shift / ca_shift of the merged best; max_pwr is not carried by the key and reads 0.
+ * RCCL is dlopen'ed on first use (librccl.so.1); GPSACQ_ERR_DEVICE if it is missing.
+ */
+typedef struct gpsacq_multi gpsacq_multi;
+int gpsacq_multi_create(const gpsacq_params* params, const int32_t* devices, int n_devices, gpsacq_multi** out);
+void gpsacq_multi_destroy(gpsacq_multi* m);
+int gpsacq_multi_set_doppler_step(gpsacq_multi* m, double step_hz);
+int gpsacq_multi_get_info(const gpsacq_multi* m, gpsacq_info* info, int32_t* n_devices);
+int gpsacq_multi_search_grid(gpsacq_multi* m, const uint8_t* bits, size_t n_blocks, size_t stride,
+                             const gpsacq_task* tasks, size_t n_tasks, gpsacq_peak* peaks);
 
 /* SearchCode(): chips to clock PRN sv's generator until its G1 register reads g1 (-1 if never) */
 int gpsacq_search_code(int sv, int g1);

@@ -133,8 +133,10 @@ int emul_cell(const float* dspec, const float* cspec, int halo, int dop, int S, 
 }
 
 // Same cell through the phase functions of k_corr2: inputs requested in two calls (rows [0, pre) "before the
-// barrier", the rest after), pass 2 by wave role with the two-step tail for butterflies 192..199.
-int emul_cell2(const float* dspec, const float* cspec, int halo, int dop, int S, int pre, int roles, int pipe, float* max_pwr, int* max_i, float* tot_pwr) {
+// barrier", the rest after), pipelined pass 2, LDS slot map LayA / LayB.
+extern "C++" {
+template <class L>
+static int emul_cell2_t(const float* dspec, const float* cspec, int halo, int dop, int S, int pre, int pipe, float* max_pwr, int* max_i, float* tot_pwr) {
     const Tables& T = tables();
     const int crow = M_SUB + 2 * halo;
     std::vector<cf> dpp((size_t)NPOLY * M_SUB), cpp((size_t)NPOLY * crow);
@@ -147,7 +149,7 @@ int emul_cell2(const float* dspec, const float* cspec, int halo, int dop, int S,
             cpp[(size_t)q * crow + h] = cpp[(size_t)q * crow + M_SUB + h];
             cpp[(size_t)q * crow + halo + M_SUB + h] = cpp[(size_t)q * crow + halo + h];
         }
-    std::vector<cf> lds(M_SUB);
+    std::vector<cf> lds(L::SIZE);
     constexpr int MC = 22;
     std::vector<cf> acc((size_t)WG * MC, mk(0.f, 0.f));
     for (int q = 0; q < NPOLY; ++q) {
@@ -164,20 +166,14 @@ int emul_cell2(const float* dspec, const float* cspec, int halo, int dop, int S,
             }
             corr_mul<0, 5>(d, c, x0, x1);
             corr_mul<5, RA>(d, c, x0, x1);
-            corr_phase1_store(tid, x0, x1, w1, lds.data());
+            corr_phase1_store<L>(tid, x0, x1, w1, lds.data());
         }
-        for (int vt = 0; vt < (roles ? TAIL_E0 : NBF2); ++vt) {
-            if (pipe) pass2_pipe<+1>(vt, T.t2u.data(), lds.data());
-            else pass2_inplace<+1>(vt, T.t2.data(), lds.data());
-        }
-        if (roles) {
-            for (int L = 0; L < TAIL_LANES; ++L) pass2_tail1<+1>(L, T.t2.data(), lds.data());
-            std::vector<cf> y((size_t)TAIL_LANES * 5);
-            for (int L = 0; L < TAIL_LANES; ++L) pass2_tail2_load<+1>(L, lds.data(), &y[(size_t)L * 5]);
-            for (int L = 0; L < TAIL_LANES; ++L) pass2_tail2_store<+1>(L, T.t2.data(), &y[(size_t)L * 5], lds.data());
+        for (int vt = 0; vt < NBF2; ++vt) {
+            if (pipe) pass2_pipe<+1, L>(vt, T.t2u.data(), lds.data());
+            else pass2_inplace<+1, L>(vt, T.t2.data(), lds.data());
         }
         for (int tid = 0; tid < WG; ++tid)
-            corr_phase3<MC>(tid, T.bq[(size_t)q * NBF3 + (tid < NBF3 ? tid : 0)], &T.wq[(size_t)q * WQ_STRIDE], lds.data(), &acc[(size_t)tid * MC]);
+            corr_phase3<MC, L>(tid, T.bq[(size_t)q * NBF3 + (tid < NBF3 ? tid : 0)], &T.wq[(size_t)q * WQ_STRIDE], lds.data(), &acc[(size_t)tid * MC]);
     }
     float mx = 0.f, sum = 0.f;
     int mi = 0;
@@ -192,6 +188,12 @@ int emul_cell2(const float* dspec, const float* cspec, int halo, int dop, int S,
     *max_i = mi;
     *tot_pwr = sum;
     return 0;
+}
+
+}  // extern "C++"
+int emul_cell2(const float* dspec, const float* cspec, int halo, int dop, int S, int pre, int layb, int pipe, float* max_pwr, int* max_i, float* tot_pwr) {
+    return layb ? emul_cell2_t<LayB>(dspec, cspec, halo, dop, S, pre, pipe, max_pwr, max_i, tot_pwr)
+                : emul_cell2_t<LayA>(dspec, cspec, halo, dop, S, pre, pipe, max_pwr, max_i, tot_pwr);
 }
 
 // host-side table/code helpers of the product, exposed for bit-exact checks against the oracle

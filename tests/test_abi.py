@@ -132,3 +132,4 @@ def test_c99_client_on_gpu(tmp_path):
     r = subprocess.run([exe, os.path.join(ROOT, "tests", "golden", "gps_sig_tmp.bin"), "2.046e6", "8.184e6"], capture_output=True, text=True)
     assert r.returncode == 0, r.stderr
     assert r.stdout.startswith("bins 49 lags 8184 best sv 7 snr 713.6 lo_shift 0 ca_shift 260 doppler 0.0 Hz")
+    assert "half-bin grid: 97 points of 102.30 Hz; multi (1 device) block 7 sv 7 snr 713.6 lo_shift 0 ca_shift 260" in r.stdout

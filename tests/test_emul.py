@@ -83,9 +83,9 @@ def test_emulated_kernels_vs_oracle(emul, golden_dir, fc, fs, file, mc):
         assert abs(mp.value / ref["max_pwr"] - 1) < 2e-5 and abs(tp.value / ref["tot_pwr"] - 1) < 2e-5
         assert mi.value == ref["max_i"]
         if mc == 22:  # k_corr2's phase functions (split input requests, pass 2 by wave role): same numbers as k_corr's
-            for pre, roles, pipe in ((5, 1, 0), (10, 0, 1), (5, 1, 1)):
+            for pre, layb, pipe in ((5, 0, 0), (10, 0, 1), (5, 1, 0), (10, 1, 1)):
                 mp2, mi2, tp2 = ctypes.c_float(), ctypes.c_int(), ctypes.c_float()
-                assert emul.emul_cell2(_p(d_in), _p(c_in), 24, dop, orc.num_lags, pre, roles, pipe, ctypes.byref(mp2), ctypes.byref(mi2), ctypes.byref(tp2)) == 0
+                assert emul.emul_cell2(_p(d_in), _p(c_in), 24, dop, orc.num_lags, pre, layb, pipe, ctypes.byref(mp2), ctypes.byref(mi2), ctypes.byref(tp2)) == 0
                 assert abs(mp2.value / mp.value - 1) < 1e-6 and abs(tp2.value / tp.value - 1) < 1e-6 and mi2.value == mi.value
 
 

@@ -172,6 +172,27 @@ def test_noncoherent_on_fine_grid(gpsacq_mod, golden_dir):
         assert summed["max_pwr"][0].max() <= single["max_pwr"].astype(np.float64).sum(axis=0).max() * (1 + 1e-5)
 
 
+def test_multi_gpu_entry_single_device(gpsacq_mod, golden_dir):
+    """gpsacq_multi_search_grid (C ABI: engines + ncclCommInitAll + ncclAllReduce(MAX) of the packed keys) in its
+    world-size-1 degenerate case on the one GPU of the box: same peaks as the engine's own search, on the reference
+    grid and on the 50 Hz grid of configs[4]."""
+    fc, fs, mfo = 4.092e6, 5.456e6, 100000.0
+    buf = open(os.path.join(golden_dir, "synth_nott_fs5456.bin"), "rb").read()[:2 * 5120]
+    tasks = [(b, sv) for b in range(2) for sv in range(32)]
+    with gpsacq_mod.Engine(fc, fs, mfo) as eng, gpsacq_mod.MultiEngine(fc, fs, mfo, devices=(0,)) as multi:
+        assert multi.n_devices == 1 and multi.num_doppler_total == 1467
+        for step in (0.0, 50.0):
+            eng.set_doppler_step(step)
+            multi.set_doppler_step(step)
+            assert multi.num_doppler_total == eng.num_doppler_total
+            _, ref = eng.search(buf, tasks=tasks, want_cells=False)
+            got = multi.search_grid(buf, tasks)
+            assert np.array_equal(got["lo_shift"], ref["lo_shift"]) and np.array_equal(got["ca_shift"], ref["ca_shift"])
+            assert np.array_equal(got["snr"].view(np.uint32), ref["snr"].view(np.uint32))
+    with pytest.raises(gpsacq_mod.GpsAcqError):
+        gpsacq_mod.MultiEngine(fc, fs, mfo, devices=(0, 99))
+
+
 # ---- reference-held pin: the Nottingham capture (absent from the reference checkout, .MISSING_LARGE_BLOBS) -------------
 NOTT = os.environ.get("GPSACQ_NOTTINGHAM")
 

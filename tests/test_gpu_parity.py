@@ -34,13 +34,38 @@ CONFIGS = {
 }
 
 
-def _cmp_cells(gc, oc, what):
-    """gc, oc: structured arrays of the same shape."""
+def _cmp_cells(gc, oc, what, tie=None):
+    """gc, oc: structured arrays [tasks, bins].  Magnitudes to REL; the argmax (code-phase bin) must be IDENTICAL unless
+    the oracle's own powers at the two lags differ by less than 1e-5 relative -- a float-rounding tie, which `tie(t, d)`
+    (returning the oracle's per-lag powers of cell (t, d)) is asked to prove for every mismatch."""
     np.testing.assert_allclose(gc["max_pwr"], oc["max_pwr"], rtol=REL, err_msg=what + " max_pwr")
     np.testing.assert_allclose(gc["tot_pwr"], oc["tot_pwr"], rtol=REL, err_msg=what + " tot_pwr")
     np.testing.assert_allclose(gc["snr"], oc["snr"], rtol=2 * REL, err_msg=what + " snr")
-    bad = gc["max_i"] != oc["max_i"]
-    assert bad.mean() < 0.002, f"{what}: {bad.sum()} argmax mismatches of {bad.size}"
+    bad = np.argwhere(gc["max_i"] != oc["max_i"])
+    assert len(bad) <= 3, f"{what}: {len(bad)} argmax mismatches of {gc.size}"
+    for t, d in bad:
+        assert tie is not None, f"{what}: argmax mismatch at task {t} bin {d} and no tie check available"
+        pw = tie(int(t), int(d))
+        a, b = float(pw[gc["max_i"][t, d]]), float(pw[oc["max_i"][t, d]])
+        assert abs(a - b) <= 1e-5 * b, f"{what}: task {t} bin {d}: lags {gc['max_i'][t, d]} / {oc['max_i'][t, d]} are not a tie ({a} vs {b})"
+
+
+def _tie_fn(orc, buf, tasks):
+    """per-lag powers of the oracle for cell (task index, bin index)"""
+    def f(t, d):
+        b, sv = tasks[t]
+        orc.L.oracle_sample(orc.h, _np_ptr(np.frombuffer(buf[b * 5120:(b + 1) * 5120], dtype=np.uint8).copy()))
+        pw = np.zeros(orc.num_lags, np.float32)
+        orc.L.oracle_cell_power(orc.h, sv, d - orc.dmax, _np_ptr(pw))
+        return pw
+    return f
+
+
+def _np_ptr(a):
+    import ctypes
+    f = _np_ptr
+    f.keep = a  # the array must outlive the call
+    return a.ctypes.data_as(ctypes.c_void_p)
 
 
 @pytest.mark.parametrize("name", ["nott", "sigtmp", "rtl"])
@@ -72,12 +97,31 @@ def test_cells_vs_oracle(gpsacq_mod, golden_dir, name):
     with gpsacq_mod.Engine(cfg["fc"], cfg["fs"], 5000.0) as eng:
         gcells, gpeaks = eng.search(buf)
         orc = Oracle(cfg["fc"], cfg["fs"], 5000.0)
-        sel = [0, 1, 7, 12, 20, 28, 29, 30, 31, 32]
-        ocells, opeaks = orc.search(buf, [(b, b % 32) for b in sel])
-        _cmp_cells(gcells[sel], ocells, name)
-        assert np.array_equal(gpeaks["ca_shift"][sel], opeaks["ca_shift"])
-        assert np.array_equal(gpeaks["lo_shift"][sel], opeaks["lo_shift"])
-        np.testing.assert_allclose(gpeaks["snr"][sel], opeaks["snr"], rtol=1e-4)
+        tasks = [(b, b % 32) for b in range(nblk)]  # all 33 tasks: one whole run plus the first block of the next
+        ocells, opeaks = orc.search(buf, tasks)
+        _cmp_cells(gcells, ocells, name, _tie_fn(orc, buf, tasks))
+        assert np.array_equal(gpeaks["ca_shift"], opeaks["ca_shift"])
+        assert np.array_equal(gpeaks["lo_shift"], opeaks["lo_shift"])
+        np.testing.assert_allclose(gpeaks["snr"], opeaks["snr"], rtol=1e-4)
+
+
+def test_full_run_with_reference_quirk(gpsacq_mod, golden_dir):
+    """One complete run of the reference schedule (32 PRN x 73 bins) at fs 5.456 MHz with ref_quirks = 1: PRN index 0 is
+    correlated against code[0] with its first 960 bins replaced by the block's samples 40000..40959, as a real gps_test
+    binary does; every cell against the oracle run the same way."""
+    from oracle_lib import Oracle
+    buf = open(os.path.join(golden_dir, "synth_nott_fs5456.bin"), "rb").read()[:32 * 5120]
+    tasks = [(b, b) for b in range(32)]
+    with gpsacq_mod.Engine(4.092e6, 5.456e6, 5000.0, ref_quirks=True) as eng:
+        gcells, gpeaks = eng.search(buf)
+    orc = Oracle(4.092e6, 5.456e6, 5000.0, ref_quirks=True)
+    ocells, opeaks = orc.search(buf, tasks)
+    _cmp_cells(gcells, ocells, "quirk run")  # (no tie helper: oracle_cell_power would need the patched code[0])
+    assert np.array_equal(gpeaks["ca_shift"], opeaks["ca_shift"]) and np.array_equal(gpeaks["lo_shift"], opeaks["lo_shift"])
+    # the quirk matters: without it PRN index 0 reads differently
+    with gpsacq_mod.Engine(4.092e6, 5.456e6, 5000.0) as eng:
+        plain, _ = eng.search(buf[:5120])
+    assert not np.allclose(plain["max_pwr"][0], gcells["max_pwr"][0], rtol=1e-3)
 
 
 @pytest.mark.parametrize("name,npz", [("nott", "np64_cells_nott.npz"), ("sigtmp", "np64_cells_sigtmp.npz"), ("rtl", "np64_cells_rtl.npz")])
@@ -93,7 +137,10 @@ def test_cells_vs_numpy_golden(gpsacq_mod, golden_dir, name, npz):
         for t, (b, sv) in enumerate(pairs):
             np.testing.assert_allclose(cells["max_pwr"][t], z[f"max_pwr_{b}_{sv}"], rtol=REL)
             np.testing.assert_allclose(cells["tot_pwr"][t], z[f"tot_pwr_{b}_{sv}"], rtol=REL)
-            assert (cells["max_i"][t] != z[f"max_i_{b}_{sv}"]).sum() <= 1
+            bad = np.flatnonzero(cells["max_i"][t] != z[f"max_i_{b}_{sv}"])
+            assert len(bad) <= 1
+            for d in bad:  # only a rounding tie may differ: the two lags' powers agree to the comparison tolerance
+                assert abs(cells["max_pwr"][t][d] / z[f"max_pwr_{b}_{sv}"][d] - 1) < REL
 
 
 def test_gps_sig_tmp_known_answers(gpsacq_mod, golden_dir):

@@ -8,9 +8,10 @@ for n in "$@"; do
   d=build/abl/o$n; mkdir -p $d
   F="--offload-arch=gfx950 -O3 -std=c++17 -fPIC -Wno-unused-function -DACQ_ABL=$n"
   /opt/rocm/bin/hipcc $F -ffp-contract=off -c gnss-gps-sdr_amd/csrc/gpsacq_engine.cpp -o $d/e.o
+  /opt/rocm/bin/hipcc $F -c gnss-gps-sdr_amd/csrc/gpsacq_multi.cpp -o $d/m.o
   /opt/rocm/bin/hipcc $F -c gnss-gps-sdr_amd/csrc/acq_kernels.hip -o $d/k.o
   /opt/rocm/bin/hipcc $F -c gnss-gps-sdr_amd/csrc/iq_kernels.hip -o $d/i.o
   /opt/rocm/bin/hipcc $F -c gnss-gps-sdr_amd/csrc/gen_kernels.hip -o $d/g.o
-  /opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o build/abl/libgpsacq_abl$n.so $d/k.o $d/i.o $d/g.o $d/e.o
+  /opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o build/abl/libgpsacq_abl$n.so $d/k.o $d/i.o $d/g.o $d/e.o $d/m.o -ldl
   echo built build/abl/libgpsacq_abl$n.so
 done
