@@ -9,15 +9,12 @@
 //
 // Design: one workgroup (256 threads, 4 waves) owns one (block, PRN, Doppler)
 // cell.  The 40000-point inverse transform is 8 polyphase 5000-point transforms done in a
-// 40 KB LDS buffer (radix 10 x 25 x 20, in place, conflict-free slot map), whose outputs are
+// 45 KB LDS buffer (radix 10 x 25 x 20, in place, 16-byte pass-1 stores / pass-3 reads), whose outputs are
 // rotated and accumulated in registers; only the FS/1000 lags the reference scans are ever
 // formed and nothing but 16 bytes per cell is written back.  The two spectra a cell reads
 // are shared by all Doppler bins of a (block, PRN) pair and stay in the XCD's L2: cells of
 // one pair are mapped to one XCD.
 #include <hip/hip_runtime.h>
-
-#include <cstdlib>
-#include <type_traits>
 
 #include "acq_launch.hpp"
 #include "acq_phases.hpp"
@@ -96,17 +93,20 @@ __global__ __launch_bounds__(WG) void k_quirk_patch(QuirkArgs a) {
 }
 
 // ---------------------------------------------------------------------------------------
-// One workgroup per (task, Doppler bin).  blockIdx -> cell map keeps the 2*dmax+1 cells of a
-// task on one XCD (block b runs on XCD b % 8) so both spectra are read from that XCD's L2.
-// NC = true: non-coherent mode (no reference equivalent): the powers |y[n]|^2
-// are summed in an LDS array indexed by lag, so that block k's lags can be re-aligned by the whole
-// samples the code has crept since block 0 at this cell's Doppler (a.creep samples per block per bin;
-// 0 = plain sum): power of lag n goes to lag (n - round(k * creep * dop)) mod S.
-// of a.n_acc consecutive block spectra (a.acc_step apart) are summed per lag before the peak scan.
-template <int MC, int WPS, int NB, bool NC>
+// One workgroup per (task, Doppler grid point).  blockIdx -> cell map keeps the cells of a task on one XCD (block
+// b runs on XCD b % 8) and close in time, so both spectra are read from that XCD's L2 (workgroups that each walk many
+// cells of different tasks were measured 3..20 % slower: the working set leaves the 4 MB L2, profiles/r02_experiments/h).
+// NC = true: non-coherent mode (no reference equivalent): the powers |y[n]|^2 of a.n_acc
+// consecutive block spectra (a.acc_step apart) are summed in an LDS array indexed by lag, so that block k's lags can be
+// re-aligned by the whole samples the code has crept since block 0 at this cell's Doppler (a.creep samples per block per
+// grid point; 0 = plain sum): power of lag n goes to lag (n - round(k * creep * point)) mod S.
+// W1H: half of the pass-1 twiddles derived instead of held (acq_math.hpp): 18 registers for 18 packed multiplies.
+// PROF: s_memtime stamps per segment, summed over the launch into a.prof (GPSACQ_PROF=1; costs a few per cent).
+template <int MC, int WPS, int NB, bool NC, bool W1H = false, bool PROF = false>
 __global__ __launch_bounds__(WG, WPS) void k_corr(CorrArgs a) {
-    __shared__ cf lds[M_SUB];  // transform buffer
+    __shared__ __attribute__((aligned(16))) cf lds[LayB::SIZE];  // transform buffer, slot map LayB
     __shared__ cf t2s[NT2];    // the 500 pass-2 twiddles
+    __shared__ float red[4 * (WG / 64)];
     __shared__ float pws[NC ? MC * NBF3 : 1];  // non-coherent power per lag of this pass
     const int tid = threadIdx.x;
     const int g = blockIdx.x, xcd = g & 7, slot = g >> 3;
@@ -134,7 +134,7 @@ __global__ __launch_bounds__(WG, WPS) void k_corr(CorrArgs a) {
     // q-independent twiddles: pass 2's table into LDS (16-byte copies), pass 1's into registers
     for (int i = tid; i < NT2; i += WG) t2s[i] = a.t2[i];
     cf w1[2][RA - 1];
-    load_tw1(tid, a.t1, w1);
+    load_tw1<W1H>(tid, a.t1, w1);
 
     cf acc[MC];
 #pragma unroll
@@ -143,6 +143,13 @@ __global__ __launch_bounds__(WG, WPS) void k_corr(CorrArgs a) {
     if (NC && tid < NBF3) {
 #pragma unroll
         for (int m = 0; m < MC; ++m) pws[NBF3 * m + tid] = 0.f;  // first read-modify-write is >= 3 barriers away
+    }
+    unsigned long long tprof[8] = {0, 0, 0, 0, 0, 0, 0, 0}, tm = PROF ? __builtin_amdgcn_s_memtime() : 0;
+#define ACQ_STAMP(k)                                                  \
+    if (PROF) {                                                       \
+        const unsigned long long now_ = __builtin_amdgcn_s_memtime(); \
+        tprof[k] += now_ - tm;                                        \
+        tm = now_;                                                    \
     }
     const int t3 = tid < NBF3 ? tid : 0;
     const int n_acc = NC ? a.n_acc : 1;
@@ -153,12 +160,18 @@ __global__ __launch_bounds__(WG, WPS) void k_corr(CorrArgs a) {
             cf wqv[MC];                        // wave-uniform rotations: scalar loads, SGPR operands
 #pragma unroll
             for (int m = 0; m < MC; ++m) wqv[m] = c_wq[q * WQ_STRIDE + a.m0 + m];
-            corr_phase1<NB>(tid, q, dop, dk, cpp, a.crow, a.halo, w1, lds);
+            corr_phase1<NB, W1H>(tid, q, dop, dk, cpp, a.crow, a.halo, w1, lds);
+            ACQ_STAMP(1);  // inputs loaded and multiplied, pass 1, its LDS stores drained (the stamp waits on lgkmcnt)
             __syncthreads();  // also orders the t2s fill before its first use
+            ACQ_STAMP(2);
             corr_phase2(tid, t2s, lds);
+            ACQ_STAMP(3);
             __syncthreads();
+            ACQ_STAMP(4);
             corr_phase3<MC>(tid, b, wqv, lds, acc);
+            ACQ_STAMP(5);
             __syncthreads();
+            ACQ_STAMP(6);
         }
         if (NC) {
             // every lag has one owner per block, so the scatter needs no atomics; successive blocks'
@@ -183,7 +196,6 @@ __global__ __launch_bounds__(WG, WPS) void k_corr(CorrArgs a) {
         peak_merge(mx, mi, omx, omi);
         sum += os;
     }
-    float* red = reinterpret_cast<float*>(lds);
     const int wave = tid >> 6;
     if ((tid & 63) == 0) {
         red[wave * 4 + 0] = mx;
@@ -204,174 +216,9 @@ __global__ __launch_bounds__(WG, WPS) void k_corr(CorrArgs a) {
         c.snr = (sum > 0.f) ? mx / ave : 0.f;    // :196; 0/0 of the reference defined as 0
         a.cells[(size_t)task * a.ndop + di] = c;
     }
-}
-
-// ---------------------------------------------------------------------------------------
-// k_corr2: same arithmetic as k_corr, restructured around what the profiles showed to be the limiter --
-// not a pipe but the time a wave spends waiting (L2 latency after every third barrier, barrier skew):
-//   * PRE rows (of 10) of the next sub-transform's inputs are requested before the barrier that ends
-//     pass 3, the rest after it
-//   * LAYB: LDS slot map with 16-byte pass-1 stores and pass-3 reads (acq_math.hpp)
-//   * one workgroup walks a contiguous chunk of a task's Doppler bins (a.nchunk workgroups per task):
-//     the q-independent twiddles are fetched once per chunk and the next cell's first loads are in
-//     flight during the peak scan
-// ABL != 0: timing-only ablations (WRONG results; GPSACQ_KVAR 30..): 1 no global loads in the loop, 2 no LDS stores in
-// pass 1, 3 pass 2 skipped, 4 no barriers, 5 no pass-3 arithmetic
-template <int MC, int WPS, int PRE, bool LAYB, bool PROF, bool PIPE2 = true, int ABL = 0>
-__global__ __launch_bounds__(WG, WPS) void k_corr2(CorrArgs a) {
-    static_assert(PRE >= 0 && PRE <= RA, "prefetch rows");
-    using L = typename std::conditional<LAYB, LayB, LayA>::type;
-    __shared__ __attribute__((aligned(16))) cf lds[L::SIZE];
-    __shared__ __attribute__((aligned(16))) cf t2s[PIPE2 ? NT2U : NT2];  // pass-2 twiddles (order of use / [beta][j''])
-    __shared__ float red[4 * (WG / 64)];
-    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-    const int g = blockIdx.x, xcd = g & 7, slot = g >> 3;
-    const int grp = slot / a.nchunk, ch = slot - grp * a.nchunk;
-    const int task = grp * 8 + xcd;
-    if (task >= a.n_tasks) return;
-    const int di0 = (int)(((long)ch * a.ndop) / a.nchunk), di1 = (int)(((long)(ch + 1) * a.ndop) / a.nchunk);
-    const Task tk = a.tasks[task];
-    if (tk.spec < 0 || tk.spec >= a.n_spec || tk.code < 0 || tk.code >= a.n_code) {
-        for (int di = di0 + (int)threadIdx.x; di < di1; di += WG) {
-            Cell c;
-            c.max_pwr = 0.f;
-            c.max_i = -1;
-            c.tot_pwr = 0.f;
-            c.snr = 0.f;
-            a.cells[(size_t)task * a.ndop + di] = c;
-        }
-        return;
-    }
-    const int tid = threadIdx.x;
-    const cf* dpp0 = a.dpp + (size_t)tk.spec * a.sub * NPOLY * M_SUB;  // the block's first spectrum (sub-bin offset 0)
-    const cf* cpp = a.cpp + (size_t)tk.code * NPOLY * a.crow;
-
-    if (PIPE2) {
-        for (int i = threadIdx.x; i < NT2U; i += WG) t2s[i] = a.t2u[i];
-    } else {
-        for (int i = threadIdx.x; i < NT2; i += WG) t2s[i] = a.t2[i];
-    }
-    cf w1[2][RA - 1];
-    load_tw1(tid, a.t1, w1);
-    const int t3 = tid < NBF3 ? tid : 0;
-
-    cf2 pd[RA], pc[RA];
-    int dop, rsub;
-    grid_point(di0 + a.dop_first, a.sub, a.dstride, dop, rsub);
-    const cf* dpp = dpp0 + (size_t)rsub * NPOLY * M_SUB;
-    if (PRE > 0) corr_issue<0, PRE>(tid, 0, dop, dpp, cpp, a.crow, a.halo, pd, pc);
-    unsigned long long tprof[8] = {0, 0, 0, 0, 0, 0, 0, 0}, tm = 0;
-#define ACQ_STAMP(k)                                          \
-    if (PROF) {                                               \
-        const unsigned long long now_ = __builtin_amdgcn_s_memtime(); \
-        tprof[k] += now_ - tm;                                \
-        tm = now_;                                            \
-    }
-    for (int di = di0; di < di1; ++di) {
-        // this cell's and the next cell's grid points (the last sub-transform requests the next cell's first rows)
-        int ndop_next, rnext;
-        grid_point(di + 1 + a.dop_first, a.sub, a.dstride, ndop_next, rnext);
-        const cf* dpp_next = dpp0 + (size_t)rnext * NPOLY * M_SUB;
-        cf acc[MC];
-#pragma unroll
-        for (int m = 0; m < MC; ++m) acc[m] = mk(0.f, 0.f);
-        if (PROF) tm = __builtin_amdgcn_s_memtime();
-        for (int q = 0; q < NPOLY; ++q) {
-            const cf b = a.bq[q * NBF3 + t3];
-            cf wqv[MC];
-#pragma unroll
-            for (int m = 0; m < MC; ++m) wqv[m] = c_wq[q * WQ_STRIDE + a.m0 + m];
-            {
-                cf x0[RA], x1[RA];
-                // rows [0, PRE) were requested before the last barrier; their products and the remaining
-                // requests share one scheduling region so that hipcc can interleave them
-                if (PRE > 0) corr_mul<0, PRE>(pd, pc, x0, x1);
-                if (PRE < RA && !(ABL == 1 && (q > 0 || di > di0))) {
-                    constexpr int H = PRE > 0 ? RA : RA / 2;  // no prefetch: two batches like k_corr
-                    corr_issue<PRE, H>(tid, q, dop, dpp, cpp, a.crow, a.halo, pd, pc);
-                    ACQ_SCHED_FENCE();
-                    corr_mul<PRE, H>(pd, pc, x0, x1);
-                    if (H < RA) {
-                        corr_issue<H, RA>(tid, q, dop, dpp, cpp, a.crow, a.halo, pd, pc);
-                        ACQ_SCHED_FENCE();
-                        corr_mul<H, RA>(pd, pc, x0, x1);
-                    }
-                }
-                ACQ_STAMP(0);  // inputs loaded and multiplied
-                if (ABL == 2) {
-                    cf sink = mk(0.f, 0.f);
-                    for (int i = 0; i < RA; ++i) sink = sink + x0[i] * w1[0][i % 9] + x1[i] * w1[1][i % 9];
-                    if (sink.x == 12345.f) lds[tid] = sink;
-                } else
-                corr_phase1_store<L>(tid, x0, x1, w1, lds);
-            }
-            ACQ_STAMP(1);  // pass 1 done
-            if (ABL != 4) __syncthreads();
-            ACQ_STAMP(2);  // barrier 1
-            if (ABL == 3) {}
-            else if (PIPE2) { if (tid < NBF2) pass2_pipe<+1, L>(tid, t2s, lds); }
-            else if (tid < NBF2) pass2_inplace<+1, L>(tid, t2s, lds);
-            ACQ_STAMP(3);  // pass 2 done
-            if (ABL != 4) __syncthreads();
-            ACQ_STAMP(4);  // barrier 2
-            // next sub-transform (or the next cell's first one)
-            const int nq = (q + 1) & 7, ndp = (q == NPOLY - 1) ? ndop_next : dop;
-            const cf* ndpp = (q == NPOLY - 1) ? dpp_next : dpp;
-            // (requested unconditionally: after the chunk's last sub-transform the rows of bin di1 are fetched and dropped --
-            // a conditional request would keep the old rows alive through passes 2 and 3 as the other arm of the merge)
-            if (ABL == 5) { if (tid < NBF3) acc[q] = acc[q] + lds[tid] * b; }
-            else corr_phase3<MC, L>(tid, b, wqv, lds, acc);
-            if (PRE > 0) {
-                ACQ_SCHED_FENCE();
-                corr_issue<0, PRE>(tid, nq, ndp, ndpp, cpp, a.crow, a.halo, pd, pc);
-                ACQ_SCHED_FENCE();
-            }
-            ACQ_STAMP(5);  // pass 3 done
-            if (ABL != 4) __syncthreads();
-            ACQ_STAMP(6);  // barrier 3
-        }
-        float mx, sum;
-        int mi;
-        int tid_scan = tid;  // opaque per cell: keeps hipcc from hoisting the 22 lag indices out of the cell loop (and spilling them)
-        asm volatile("" : "+v"(tid_scan));
-        corr_scan<MC>(tid_scan, a.nlags, a.m0, acc, mx, mi, sum);
-#pragma unroll
-        for (int off = 32; off > 0; off >>= 1) {
-            const float omx = __shfl_down(mx, off, 64);
-            const int omi = __shfl_down(mi, off, 64);
-            const float os = __shfl_down(sum, off, 64);
-            peak_merge(mx, mi, omx, omi);
-            sum += os;
-        }
-        // the previous cell's reader of `red` is at least 24 barriers behind
-        if (lane == 0) {
-            red[wave * 4 + 0] = mx;
-            red[wave * 4 + 1] = __int_as_float(mi);
-            red[wave * 4 + 2] = sum;
-        }
-        __syncthreads();
-        if (threadIdx.x == 0) {
-            mx = red[0];
-            mi = __float_as_int(red[1]);
-            sum = red[2];
-            for (int w = 1; w < WG / 64; ++w) {
-                peak_merge(mx, mi, red[w * 4 + 0], __float_as_int(red[w * 4 + 1]));
-                sum += red[w * 4 + 2];
-            }
-            Cell c;
-            c.max_pwr = mx;
-            c.max_i = mi;
-            c.tot_pwr = sum;
-            const float ave = sum / (float)a.nlags;  // :195 tot_pwr / i
-            c.snr = (sum > 0.f) ? mx / ave : 0.f;    // :196; 0/0 of the reference defined as 0
-            a.cells[(size_t)task * a.ndop + di] = c;
-        }
-        ACQ_STAMP(7);  // scan + reduction
-        dop = ndop_next;
-        dpp = dpp_next;
-    }
+    ACQ_STAMP(7);  // scan + reduction
 #undef ACQ_STAMP
-    if (PROF && a.prof && lane == 0 && (wave == 0 || wave == 3)) {
+    if (PROF && a.prof && (tid & 63) == 0 && (wave == 0 || wave == 3)) {
         for (int k = 0; k < 8; ++k) atomicAdd(a.prof + (wave == 0 ? 0 : 8) + k, tprof[k]);
     }
 }
@@ -463,65 +310,18 @@ void launch_quirk_patch(const QuirkArgs& a, int n_patch, hipStream_t s) {
 }
 int corr_columns(int nlags) {  // accumulator columns of the smallest instance that covers nlags
     const int need = (nlags + NBF3 - 1) / NBF3;
-    const int have[] = {12, 22, 33, 40};
+    const int have[] = {12, 22, 28, 33, 40};
     for (int m : have)
         if (need <= m) return m;
     return MC_MAX;  // several passes of 40 columns
 }
-// Experiment switch (round-2 kernel work): GPSACQ_KVAR picks the 22-column coherent instance.
-static int kvar() {
-    static int v = -2;
-    if (v == -2) {
-        const char* e = getenv("GPSACQ_KVAR");
-        v = e ? atoi(e) : -1;
-    }
-    return v;
-}
-int corr_chunks(int ndop) {  // workgroups per task for k_corr2
-    static int cpw = -1;
-    if (cpw < 0) {
-        const char* e = getenv("GPSACQ_CPW");
-        cpw = e ? atoi(e) : 9;
-        if (cpw < 1) cpw = 1;
-    }
-    return (ndop + cpw - 1) / cpw;
-}
-int launch_corr(const CorrArgs& a0, int mc, hipStream_t s) {
-    CorrArgs a = a0;
+int launch_corr(const CorrArgs& a, int mc, hipStream_t s) {
     const int groups = (a.n_tasks + 7) / 8;
-    const dim3 block(WG);
-    const int kv = kvar();
-#ifndef ONE_ONLY
-    if (mc == 22 && a.n_acc == 1 && kv >= 1) {
-        a.nchunk = corr_chunks(a.ndop);
-        const dim3 grid2((unsigned)groups * 8u * (unsigned)a.nchunk);
-#define K2(PRE, LAYB, PROF, PIPE2) hipLaunchKernelGGL((k_corr2<22, 3, PRE, LAYB, PROF, PIPE2>), grid2, block, 0, s, a)
-#define K2A(ABL) hipLaunchKernelGGL((k_corr2<22, 3, 0, false, false, true, ABL>), grid2, block, 0, s, a)
-        switch (kv) {
-            case 1: K2(0, false, false, false); break;  // k_corr's structure, chunked cells
-            case 2: K2(0, false, false, true); break;   // + pipelined pass 2
-            case 3: K2(5, false, false, true); break;   // + half the rows requested before the barrier
-            case 4: K2(0, true, false, true); break;    // layout B
-            case 5: K2(5, true, false, true); break;
-            case 6: K2(0, true, false, false); break;   // layout B, pass 2 as in k_corr
-            case 31: K2A(1); break;  // ablations (wrong results, timing only)
-            case 32: K2A(2); break;
-            case 33: K2A(3); break;
-            case 34: K2A(4); break;
-            case 35: K2A(5); break;
-            case 20: K2(0, false, true, true); break;   // s_memtime phase profiles
-            case 21: K2(0, true, true, true); break;
-            default: return -1;
-        }
-#undef K2
-#undef K2A
-        return 0;
-    }
-#endif
-    const dim3 grid((unsigned)groups * 8u * (unsigned)a.ndop);
-    // waves per SIMD the register allocator is held to (k workgroups per CU <=> k waves per SIMD):
-    // <columns, waves per SIMD the allocator is held to, load batches>.  LDS (44 KB per workgroup)
-    // admits 3 workgroups per CU; the two small instances fit 168 VGPRs without spilling.
+    const dim3 grid((unsigned)groups * 8u * (unsigned)a.ndop), block(WG);
+    // <columns, waves per SIMD the register allocator is held to (k workgroups per CU <=> k waves per SIMD), load batches,
+    // non-coherent, W1H>.  LDS (49 KB per workgroup) admits 3 workgroups per CU; 12, 22 and 28 columns fit 168 VGPRs,
+    // 28 and 33 columns do with half the pass-1 twiddles derived (W1H); 40 columns then spill 40 bytes per lane and are still
+    // faster at 3 per CU (14.4 vs 13.5 M cells/s; without W1H 116 bytes and slower: profiles/r02_experiments/i, r02j).
     switch (mc) {
         case 12:
             if (a.n_acc > 1) hipLaunchKernelGGL((k_corr<12, 2, 2, true>), grid, block, 0, s, a);
@@ -529,17 +329,20 @@ int launch_corr(const CorrArgs& a0, int mc, hipStream_t s) {
             break;
         case 22:
             if (a.n_acc > 1) hipLaunchKernelGGL((k_corr<22, 2, 2, true>), grid, block, 0, s, a);
+            else if (a.prof) hipLaunchKernelGGL((k_corr<22, 3, 2, false, false, true>), grid, block, 0, s, a);
             else hipLaunchKernelGGL((k_corr<22, 3, 2, false>), grid, block, 0, s, a);
+            break;
+        case 28:
+            if (a.n_acc > 1) hipLaunchKernelGGL((k_corr<28, 2, 2, true>), grid, block, 0, s, a);
+            else hipLaunchKernelGGL((k_corr<28, 3, 2, false, true>), grid, block, 0, s, a);
             break;
         case 33:
             if (a.n_acc > 1) hipLaunchKernelGGL((k_corr<33, 2, 2, true>), grid, block, 0, s, a);
-            else if (getenv("GPSACQ_WIDE3")) hipLaunchKernelGGL((k_corr<33, 3, 2, false>), grid, block, 0, s, a);
-            else hipLaunchKernelGGL((k_corr<33, 2, 2, false>), grid, block, 0, s, a);
+            else hipLaunchKernelGGL((k_corr<33, 3, 2, false, true>), grid, block, 0, s, a);
             break;
         case 40:
-            if (a.n_acc > 1) hipLaunchKernelGGL((k_corr<40, 1, 2, true>), grid, block, 0, s, a);  // 84 KB of LDS: one workgroup per CU
-            else if (getenv("GPSACQ_WIDE3")) hipLaunchKernelGGL((k_corr<40, 3, 2, false>), grid, block, 0, s, a);
-            else hipLaunchKernelGGL((k_corr<40, 2, 2, false>), grid, block, 0, s, a);
+            if (a.n_acc > 1) hipLaunchKernelGGL((k_corr<40, 1, 2, true>), grid, block, 0, s, a);  // 89 KB of LDS: one workgroup per CU
+            else hipLaunchKernelGGL((k_corr<40, 3, 2, false, true>), grid, block, 0, s, a);  // 40 bytes of spills: still 7 % faster than 2 per CU
             break;
         default: return -1;
     }

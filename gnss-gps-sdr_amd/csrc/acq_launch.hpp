@@ -39,7 +39,6 @@ struct CorrArgs {
     const Task* tasks; // [n_tasks]
     const cf* t1;
     const cf* t2;
-    const cf* t2u;     // pass-2 twiddles in order of use (k_corr2)
     const cf* bq;
     Cell* cells;       // [n_tasks][ndop]
     int n_tasks, ndop, dop_first, nlags, crow, halo;  // bins dop_first .. dop_first+ndop-1
@@ -48,8 +47,7 @@ struct CorrArgs {
     float creep;          // non-coherent mode: code creep in samples per accumulated block per Doppler bin (0 = off)
     int n_spec, n_code;   // rows of dpp / cpp: tasks pointing outside get an empty cell (max_i = -1)
     int sub, dstride;     // Doppler grid (acq_phases.hpp grid_point): dop_first/ndop count grid points; spectrum of (block, r) at row block*sub + r
-    int nchunk;           // k_corr2: workgroups per task; each takes a contiguous share of the ndop bins
-    unsigned long long* prof;  // k_corr2<PROF>: [16] accumulated s_memtime deltas (experiments only), else NULL
+    unsigned long long* prof;  // k_corr<..., PROF>: [16] accumulated s_memtime deltas per segment (GPSACQ_PROF=1 diagnostic), else NULL
 };
 
 void launch_fwd_bits(const FwdArgs& a, int n_items, hipStream_t s);

@@ -38,16 +38,6 @@
 #define ACQ_PK_ASM 0
 #endif
 
-// Timing-only ablation builds (tools/ablate.sh; WRONG results, never shipped): ACQ_ABL = 6 drops pass 1's LDS stores,
-// 7 pass 2's stores, 8 pass 3's LDS reads, 9 pass 2's reads (data + twiddles); the arithmetic is kept alive by empty asm sinks.
-#ifndef ACQ_ABL
-#define ACQ_ABL 0
-#endif
-#if ACQ_ABL && defined(__HIP_DEVICE_COMPILE__)
-#define ACQ_SINK(v) asm volatile("" ::"v"(v))
-#define ACQ_JUNK(v) asm volatile("" : "=v"(v))
-#endif
-
 namespace acq {
 
 constexpr int N_FFT = 40000;  // FFT_LEN, c/gps_offline.h:15
@@ -324,9 +314,9 @@ ACQ_HD void ld2u(const cf* p, cf& a, cf& b) {
 }
 
 // Where element (alpha, j'', b) of the in-place transform lives in the workgroup's LDS buffer (complex units):
-//   LayA (k_corr, k_fwd)   500 alpha + 25 j'' + b : a pass-2 butterfly's 25 elements are contiguous (paired 8-byte accesses),
+//   LayA (k_fwd)           500 alpha + 25 j'' + b : a pass-2 butterfly's 25 elements are contiguous (paired 8-byte accesses),
 //                          pass-1 stores and pass-3 reads are strided and pay 2-way bank conflicts
-//   LayB (k_corr2)         564 alpha + 22 b + j'' : the two butterflies a pass-1 thread owns (j' = 2 tid, 2 tid + 1) are
+//   LayB (k_corr)          564 alpha + 22 b + j'' : the two butterflies a pass-1 thread owns (j' = 2 tid, 2 tid + 1) are
 //                          neighbours, so their outputs leave as ONE 16-byte store per alpha, and a pass-3 thread's 20
 //                          elements are contiguous (ten 16-byte reads); 22 and 564 keep every access conflict-free
 //                          (176-byte lane stride for the 16-byte reads, 564 - 20 = 17 * 32 across the alpha boundary of pass 2)
@@ -339,36 +329,57 @@ template <int DIR, class L = LayA> ACQ_HD void pass1_store(const cf* x, int jp, 
     radix10<DIR>(x, y);
     const int b = jp / RC, jpp = jp - b * RC;
     cf* dst = lds + L::SJ * jpp + L::SB * b;
-#if ACQ_ABL == 6 && defined(__HIP_DEVICE_COMPILE__)
-    ACQ_SINK(y[0]);
-#pragma unroll
-    for (int al = 1; al < RA; ++al) { cf v = tw<DIR>(y[al], w[al - 1]); ACQ_SINK(v); }
-    (void)dst;
-#else
     dst[0] = y[0];
 #pragma unroll
     for (int al = 1; al < RA; ++al) dst[L::SA * al] = tw<DIR>(y[al], w[al - 1]);
-#endif
 }
-// LayB: butterflies jp = 2 t and 2 t + 1 together, one 16-byte store per alpha
-template <int DIR> ACQ_HD void pass1_store_pair(const cf* x0, const cf* x1, int t, const cf* w0, const cf* w1, cf* lds) {
+// forward value of W_5000^al, al = 1..9: the ratio of the pass-1 twiddles of two neighbouring butterflies
+template <int AL> ACQ_HD cf w5000() {
+    static_assert(AL >= 1 && AL <= 9, "w5000");
+    return AL == 1   ? mk(0.99999921043206784f, -0.0012566367307361701f)
+           : AL == 2 ? mk(0.99999684172951656f, -0.0025132714770690740f)
+           : AL == 3 ? mk(0.99999289389607086f, -0.0037699022546219146f)
+           : AL == 4 ? mk(0.99998736693796492f, -0.0050265270790207270f)
+           : AL == 5 ? mk(0.99998026086392511f, -0.0062831439655589511f)
+           : AL == 6 ? mk(0.99997157568517318f, -0.0075397509301827640f)
+           : AL == 7 ? mk(0.99996131141542431f, -0.0087963459885950153f)
+           : AL == 8 ? mk(0.99994946807088674f, -0.010052927156601628f)
+                     : mk(0.99993604567026163f, -0.011309492350427326f);
+}
+// LayB: butterflies jp = 2 t and 2 t + 1 together, one 16-byte store per alpha.  w0[al-1] = W_5000^{2 t al}.
+// W1H = false: w1[al-1] = W_5000^{(2 t + 1) al} comes from registers too (36 twiddle registers per thread);
+// W1H = true: it is formed as w0 * W_5000^al (wave-uniform constant): 9 more complex multiplies per sub-transform,
+// 18 registers fewer -- what lets the 33-column instance run three workgroups per CU.
+template <int DIR, bool W1H, int AL> ACQ_HD void pass1_pair_one(const cf* y0, const cf* y1, const cf* w0, const cf* w1, cf* dst) {
+    cf a0, a1;
+    if (AL == 0) {
+        a0 = y0[0];
+        a1 = y1[0];
+    } else {
+        a0 = tw<DIR>(y0[AL], w0[AL - 1]);
+        a1 = W1H ? tw<DIR>(tw_u<DIR>(y1[AL], w5000<(AL ? AL : 1)>()), w0[AL - 1]) : tw<DIR>(y1[AL], w1[AL - 1]);
+    }
+    cf2 v;
+    v.xy = a0;
+    v.zw = a1;
+    *reinterpret_cast<cf2*>(dst + LayB::SA * AL) = v;
+}
+template <int DIR, bool W1H = false> ACQ_HD void pass1_store_pair(const cf* x0, const cf* x1, int t, const cf* w0, const cf* w1, cf* lds) {
     cf y0[RA], y1[RA];
     radix10<DIR>(x0, y0);
     radix10<DIR>(x1, y1);
     const int jp = 2 * t, b = jp / RC, jpp = jp - b * RC;  // jpp even: the pair never straddles a row of 20
     cf* dst = lds + LayB::SB * b + jpp;
-#pragma unroll
-    for (int al = 0; al < RA; ++al) {
-        const cf a0 = al ? tw<DIR>(y0[al], w0[al - 1]) : y0[0], a1 = al ? tw<DIR>(y1[al], w1[al - 1]) : y1[0];
-        cf2 v;
-        v.xy = a0;
-        v.zw = a1;
-#if ACQ_ABL == 6 && defined(__HIP_DEVICE_COMPILE__)
-        ACQ_SINK(v);
-#else
-        *reinterpret_cast<cf2*>(dst + LayB::SA * al) = v;
-#endif
-    }
+    pass1_pair_one<DIR, W1H, 0>(y0, y1, w0, w1, dst);
+    pass1_pair_one<DIR, W1H, 1>(y0, y1, w0, w1, dst);
+    pass1_pair_one<DIR, W1H, 2>(y0, y1, w0, w1, dst);
+    pass1_pair_one<DIR, W1H, 3>(y0, y1, w0, w1, dst);
+    pass1_pair_one<DIR, W1H, 4>(y0, y1, w0, w1, dst);
+    pass1_pair_one<DIR, W1H, 5>(y0, y1, w0, w1, dst);
+    pass1_pair_one<DIR, W1H, 6>(y0, y1, w0, w1, dst);
+    pass1_pair_one<DIR, W1H, 7>(y0, y1, w0, w1, dst);
+    pass1_pair_one<DIR, W1H, 8>(y0, y1, w0, w1, dst);
+    pass1_pair_one<DIR, W1H, 9>(y0, y1, w0, w1, dst);
 }
 
 // pass 2 for butterfly e (0..199), in place; t2 may live in LDS (its own allocation, so the
@@ -390,11 +401,6 @@ template <int DIR, class L = LayA> ACQ_HD void pass3_load(int t3, const cf* lds,
     const int al = t3 / RB, be = t3 - al * RB;
     const cf* p = lds + L::SA * al + L::SB * be;
     cf x[RC];
-#if ACQ_ABL == 8 && defined(__HIP_DEVICE_COMPILE__)
-    (void)p;
-#pragma unroll
-    for (int jpp = 0; jpp < RC; ++jpp) ACQ_JUNK(x[jpp]);
-#else
     if (L::SJ == 1) {  // contiguous: 16-byte reads (SA and SB keep p 16-byte aligned)
 #pragma unroll
         for (int jpp = 0; jpp < RC; jpp += 2) ld2(p + jpp, x[jpp], x[jpp + 1]);
@@ -402,7 +408,6 @@ template <int DIR, class L = LayA> ACQ_HD void pass3_load(int t3, const cf* lds,
 #pragma unroll
         for (int jpp = 0; jpp < RC; ++jpp) x[jpp] = p[L::SJ * jpp];
     }
-#endif
     radix20<DIR>(x, y);
 }
 ACQ_HD int pass3_rho(int t3) {

@@ -45,10 +45,15 @@ struct Task {  // one (block spectrum, code spectrum) pair to search over all Do
 
 // Thread tid (< 250) owns the pass-1 butterflies jp = 2 tid and 2 tid + 1.
 // Their 2 x 9 twiddles W_5000^{jp alpha}; loaded once per cell by the correlator.
+// W1H: only butterfly 2 tid's (the neighbour's are derived, acq_math.hpp pass1_store_pair)
+template <bool W1H = false>
 ACQ_HD void load_tw1(int tid, const cf* __restrict__ t1, cf (&w)[2][RA - 1]) {
     if (tid >= NBF3) return;
 #pragma unroll
-    for (int al = 1; al < RA; ++al) ld2(t1 + al * NBF1 + 2 * tid, w[0][al - 1], w[1][al - 1]);
+    for (int al = 1; al < RA; ++al) {
+        if (W1H) w[0][al - 1] = t1[al * NBF1 + 2 * tid];
+        else ld2(t1 + al * NBF1 + 2 * tid, w[0][al - 1], w[1][al - 1]);
+    }
 }
 
 // ---------------------------------------------------------------------------------------
@@ -60,7 +65,7 @@ ACQ_HD void load_tw1(int tid, const cf* __restrict__ t1, cf (&w)[2][RA - 1]) {
 #else
 #define ACQ_SCHED_FENCE() ((void)0)
 #endif
-template <int NB>
+template <int NB, bool W1H = false>
 ACQ_HD void corr_phase1(int tid, int q, int dop, const cf* __restrict__ dpp, const cf* __restrict__ cpp,
                         int crow, int halo, const cf (&w)[2][RA - 1], cf* lds) {
     if (tid >= NBF3) return;
@@ -102,181 +107,26 @@ ACQ_HD void corr_phase1(int tid, int q, int dop, const cf* __restrict__ dpp, con
             x1[b * PER + i] = cmul(d[i].zw, cc[i].zw);
         }
     }
-    pass1_store<+1>(x0, 2 * tid, w[0], lds);
-    pass1_store<+1>(x1, 2 * tid + 1, w[1], lds);
+    pass1_store_pair<+1, W1H>(x0, x1, tid, w[0], w[1], lds);  // LDS slot map LayB (acq_math.hpp)
 }
 
 ACQ_HD void corr_phase2(int tid, const cf* t2, cf* lds) {
-    if (tid < NBF2) pass2_inplace<+1>(tid, t2, lds);
+    if (tid < NBF2) pass2_inplace<+1, LayB>(tid, t2, lds);
 }
 
 // acc[m] accumulates y[n] for n = 250 (m0 + m) + rho over the 8 polyphase components (m0, the first
 // column of this pass, is a multiple of 20 so that column m0 + m reads radix-20 output m % 20):
 // W_N^{-q n} = conj(b) (per thread, b = bq[q][tid]) * conj(wqv[m]) (wave-uniform, wqv[m] = W_160^{q m}).
-template <int MC, class L = LayA>
+template <int MC>
 ACQ_HD void corr_phase3(int tid, cf b, const cf* wqv, const cf* lds, cf* acc) {
     if (tid >= NBF3) return;
     cf y[RC];
-    pass3_load<+1, L>(tid, lds, y);
+    pass3_load<+1, LayB>(tid, lds, y);
 #pragma unroll
     for (int n = 0; n < RC; ++n) y[n] = cmulc(y[n], b);
 #pragma unroll
     for (int m = 0; m < MC; ++m) acc[m] = cmacc_u(acc[m], y[m % RC], wqv[m]);
 }
-
-// ---------------------------------------------------------------------------------------
-// Software-pipelined form of the same three phases (k_corr2): the global loads of sub-transform
-// q+1 are issued while sub-transform q is still in pass 3 / waiting at its last barrier, so the L2
-// latency and the barrier wait overlap instead of adding up.  Rows [R0, R1) of the 10 input rows
-// (element 2 tid, 2 tid + 1 of row a = elements jp + 500 a of the two butterflies this thread owns).
-template <int R0, int R1>
-ACQ_HD void corr_issue(int tid, int q, int dop, const cf* __restrict__ dpp, const cf* __restrict__ cpp, int crow, int halo,
-                       cf2 (&d)[RA], cf2 (&cc)[RA]) {
-    int qp, c;
-    shift_split(q, dop, qp, c);
-#if defined(__HIP_DEVICE_COMPILE__)
-    // no exec mask: lanes 250..255 read 16 bytes further along the row (inside the descriptor, or 0 past its end)
-    const __amdgpu_buffer_rsrc_t rd = __builtin_amdgcn_make_buffer_rsrc((void*)dpp, 0, NPOLY * M_SUB * (int)sizeof(cf), 0x00020000);
-    const __amdgpu_buffer_rsrc_t rc = __builtin_amdgcn_make_buffer_rsrc((void*)cpp, 0, NPOLY * crow * (int)sizeof(cf), 0x00020000);
-    const int sd = q * M_SUB * (int)sizeof(cf), sc = (qp * crow + halo + c) * (int)sizeof(cf);
-    const int lane = 2 * tid * (int)sizeof(cf);
-    constexpr int ROW = NBF1 * (int)sizeof(cf);
-#pragma unroll
-    for (int i = R0; i < R1; ++i) {
-        d[i] = __builtin_bit_cast(cf2, __builtin_amdgcn_raw_buffer_load_b128(rd, lane, sd + ROW * i, 0));
-        cc[i] = __builtin_bit_cast(cf2, __builtin_amdgcn_raw_buffer_load_b128(rc, lane, sc + ROW * i, 0));
-    }
-#else
-    if (tid >= NBF3) return;
-    const cf* drow = dpp + q * M_SUB + 2 * tid;
-    const cf* crw = cpp + (long)qp * crow + halo + c + 2 * tid;
-    for (int i = R0; i < R1; ++i) {
-        d[i] = *reinterpret_cast<const cf2*>(drow + NBF1 * i);
-        cc[i] = *reinterpret_cast<const cf2_a8*>(crw + NBF1 * i);
-    }
-#endif
-}
-// products of rows [R0, R1) -> the two butterflies' inputs
-template <int R0, int R1>
-ACQ_HD void corr_mul(const cf2 (&d)[RA], const cf2 (&cc)[RA], cf (&x0)[RA], cf (&x1)[RA]) {
-#pragma unroll
-    for (int i = R0; i < R1; ++i) {
-        x0[i] = cmul(d[i].xy, cc[i].xy);
-        x1[i] = cmul(d[i].zw, cc[i].zw);
-    }
-}
-template <class L>
-ACQ_HD void corr_phase1_store(int tid, const cf (&x0)[RA], const cf (&x1)[RA], const cf (&w)[2][RA - 1], cf* lds) {
-    if (tid >= NBF3) return;
-    if (L::SJ == 1) {
-        pass1_store_pair<+1>(x0, x1, tid, w[0], w[1], lds);
-    } else {
-        pass1_store<+1, L>(x0, 2 * tid, w[0], lds);
-        pass1_store<+1, L>(x1, 2 * tid + 1, w[1], lds);
-    }
-}
-
-// Pass 2 with its LDS traffic software-pipelined.  The s_memtime profile of round 2 (profiles/r02a) showed
-// the waves losing their time INSIDE the passes, not at the barriers: hipcc put every pass-2 twiddle read
-// right before its use (read, s_waitcnt lgkmcnt(0), two multiplies, write, read ...), a chain of about twelve
-// exposed LDS round trips per butterfly.  Here the second 5-point stage runs group by group (k1 = 0..4) and
-// the twiddles of group k1 + 1 are requested before group k1 is computed.  The table is stored per j'' in
-// the order of use, 26 entries per row (208 bytes: ds_read_b128 of two entries, conflict-free across lanes):
-//   t2u[26 j'' + i]: i = 0..3 -> beta = 5, 10, 15, 20 (group 0; beta = 0 needs none),
-//                    i = 4 + 5 (k1 - 1) + k2 -> beta = k1 + 5 k2 (groups 1..4)
-constexpr int T2U_ROW = 26;
-constexpr int NT2U = RC * T2U_ROW;  // 520
-ACQ_HD int t2u_beta(int i) { return i < 4 ? 5 * (i + 1) : ((i - 4) / 5 + 1) + 5 * ((i - 4) % 5); }
-#if ACQ_ABL == 7 && defined(__HIP_DEVICE_COMPILE__)
-#define ACQ_ST(n, expr) do { cf v_ = (expr); ACQ_SINK(v_); } while (0)
-#else
-#define ACQ_ST(n, expr) p[L::SB * (n)] = (expr)
-#endif
-template <int DIR, class L = LayA> ACQ_HD void pass2_pipe(int e, const cf* __restrict__ t2u, cf* lds) {
-    const int al = e / RC, jpp = e - al * RC;
-    cf* p = lds + L::SA * al + L::SJ * jpp;
-    const cf2* twp = reinterpret_cast<const cf2*>(t2u + T2U_ROW * jpp);
-    cf x[RB];
-    cf2 c[12];
-#if ACQ_ABL == 9 && defined(__HIP_DEVICE_COMPILE__)
-#pragma unroll
-    for (int b = 0; b < RB; ++b) ACQ_JUNK(x[b]);
-#pragma unroll
-    for (int i = 0; i < 12; ++i) ACQ_JUNK(c[i]);
-#define ACQ_TWLD(i) ((void)0)
-#else
-#pragma unroll
-    for (int b = 0; b < RB; ++b) x[b] = p[L::SB * b];
-#define ACQ_TWLD(i) c[i] = twp[i]
-#endif
-    ACQ_TWLD(0);
-    ACQ_TWLD(1);
-    ACQ_SCHED_FENCE();
-    cf v[5][5];  // v[k1][n2]
-#pragma unroll
-    for (int n2 = 0; n2 < 5; ++n2) {
-        cf a = x[n2], b = x[5 + n2], cc = x[10 + n2], d = x[15 + n2], f = x[20 + n2];
-        dft5<DIR>(a, b, cc, d, f);
-        v[0][n2] = a; v[1][n2] = b; v[2][n2] = cc; v[3][n2] = d; v[4][n2] = f;
-    }
-    v[1][1] = tw_u<DIR>(v[1][1], w25<1>());  v[1][2] = tw_u<DIR>(v[1][2], w25<2>());
-    v[1][3] = tw_u<DIR>(v[1][3], w25<3>());  v[1][4] = tw_u<DIR>(v[1][4], w25<4>());
-    v[2][1] = tw_u<DIR>(v[2][1], w25<2>());  v[2][2] = tw_u<DIR>(v[2][2], w25<4>());
-    v[2][3] = tw_u<DIR>(v[2][3], w25<6>());  v[2][4] = tw_u<DIR>(v[2][4], w25<8>());
-    v[3][1] = tw_u<DIR>(v[3][1], w25<3>());  v[3][2] = tw_u<DIR>(v[3][2], w25<6>());
-    v[3][3] = tw_u<DIR>(v[3][3], w25<9>());  v[3][4] = tw_u<DIR>(v[3][4], w25<12>());
-    v[4][1] = tw_u<DIR>(v[4][1], w25<4>());  v[4][2] = tw_u<DIR>(v[4][2], w25<8>());
-    v[4][3] = tw_u<DIR>(v[4][3], w25<12>()); v[4][4] = tw_u<DIR>(v[4][4], w25<16>());
-    // group 0 (twiddles c[0..1]); request group 1's (entries 4..9)
-    ACQ_SCHED_FENCE();
-    ACQ_TWLD(2); ACQ_TWLD(3); ACQ_TWLD(4);
-    ACQ_SCHED_FENCE();
-    dft5<DIR>(v[0][0], v[0][1], v[0][2], v[0][3], v[0][4]);
-    ACQ_ST(0, v[0][0]);
-    ACQ_ST(5, tw<DIR>(v[0][1], c[0].xy));
-    ACQ_ST(10, tw<DIR>(v[0][2], c[0].zw));
-    ACQ_ST(15, tw<DIR>(v[0][3], c[1].xy));
-    ACQ_ST(20, tw<DIR>(v[0][4], c[1].zw));
-    // group 1 (entries 4..8); request group 2's remaining (10..13)
-    ACQ_SCHED_FENCE();
-    ACQ_TWLD(5); ACQ_TWLD(6);
-    ACQ_SCHED_FENCE();
-    dft5<DIR>(v[1][0], v[1][1], v[1][2], v[1][3], v[1][4]);
-    ACQ_ST(1, tw<DIR>(v[1][0], c[2].xy));
-    ACQ_ST(6, tw<DIR>(v[1][1], c[2].zw));
-    ACQ_ST(11, tw<DIR>(v[1][2], c[3].xy));
-    ACQ_ST(16, tw<DIR>(v[1][3], c[3].zw));
-    ACQ_ST(21, tw<DIR>(v[1][4], c[4].xy));
-    // group 2 (entries 9..13); request group 3's (14..19)
-    ACQ_SCHED_FENCE();
-    ACQ_TWLD(7); ACQ_TWLD(8); ACQ_TWLD(9);
-    ACQ_SCHED_FENCE();
-    dft5<DIR>(v[2][0], v[2][1], v[2][2], v[2][3], v[2][4]);
-    ACQ_ST(2, tw<DIR>(v[2][0], c[4].zw));
-    ACQ_ST(7, tw<DIR>(v[2][1], c[5].xy));
-    ACQ_ST(12, tw<DIR>(v[2][2], c[5].zw));
-    ACQ_ST(17, tw<DIR>(v[2][3], c[6].xy));
-    ACQ_ST(22, tw<DIR>(v[2][4], c[6].zw));
-    // group 3 (entries 14..18); request group 4's remaining (20..23)
-    ACQ_SCHED_FENCE();
-    ACQ_TWLD(10); ACQ_TWLD(11);
-    ACQ_SCHED_FENCE();
-    dft5<DIR>(v[3][0], v[3][1], v[3][2], v[3][3], v[3][4]);
-    ACQ_ST(3, tw<DIR>(v[3][0], c[7].xy));
-    ACQ_ST(8, tw<DIR>(v[3][1], c[7].zw));
-    ACQ_ST(13, tw<DIR>(v[3][2], c[8].xy));
-    ACQ_ST(18, tw<DIR>(v[3][3], c[8].zw));
-    ACQ_ST(23, tw<DIR>(v[3][4], c[9].xy));
-    // group 4 (entries 19..23)
-    dft5<DIR>(v[4][0], v[4][1], v[4][2], v[4][3], v[4][4]);
-    ACQ_ST(4, tw<DIR>(v[4][0], c[9].zw));
-    ACQ_ST(9, tw<DIR>(v[4][1], c[10].xy));
-    ACQ_ST(14, tw<DIR>(v[4][2], c[10].zw));
-    ACQ_ST(19, tw<DIR>(v[4][3], c[11].xy));
-    ACQ_ST(24, tw<DIR>(v[4][4], c[11].zw));
-}
-#undef ACQ_ST
-#undef ACQ_TWLD
 
 // Doppler grid point k (in units of the grid step) -> whole-bin shift `dop` of the code spectrum (:182) and the
 // index r of the sub-bin-offset spectrum of the block.  sub > 1: step = bin / sub, k = dop * sub + r with

@@ -23,19 +23,16 @@ inline cf unit_fwd(long long num, long long den) {  // exp(-2 pi i num/den)
 struct Tables {
     std::vector<cf> t1;  // [10][500]   W_5000^{j' alpha}
     std::vector<cf> t2;  // [25][20]    W_500^{j'' beta}
-    std::vector<cf> t2u; // [20][26]    the same values per j'' in pass2_pipe's order of use (acq_phases.hpp)
     std::vector<cf> bq;  // [8][250]    W_40000^{q rho(t3)}, rho = 10 (t3 % 25) + t3 / 25
     std::vector<cf> wq;  // [8][40]     W_160^{q m}
     std::vector<cf> tn;  // [8][5000]   W_40000^{n' kappa}: forward transform's decimation-in-frequency twiddle
-    Tables() : t1(RA * NBF1), t2((size_t)NT2), t2u((size_t)NT2U, mk(1.f, 0.f)), bq((size_t)NPOLY * NBF3), wq(NPOLY * WQ_STRIDE), tn((size_t)NPOLY * M_SUB) {
+    Tables() : t1(RA * NBF1), t2((size_t)NT2), bq((size_t)NPOLY * NBF3), wq(NPOLY * WQ_STRIDE), tn((size_t)NPOLY * M_SUB) {
         for (int ka = 0; ka < NPOLY; ++ka)
             for (int n = 0; n < M_SUB; ++n) tn[(size_t)ka * M_SUB + n] = unit_fwd((long long)n * ka, N_FFT);
         for (int al = 0; al < RA; ++al)
             for (int jp = 0; jp < NBF1; ++jp) t1[al * NBF1 + jp] = unit_fwd((long long)jp * al, M_SUB);
         for (int be = 0; be < RB; ++be)
             for (int jpp = 0; jpp < RC; ++jpp) t2[(size_t)be * RC + jpp] = unit_fwd((long long)jpp * be, NBF1);
-        for (int jpp = 0; jpp < RC; ++jpp)
-            for (int i = 0; i < 24; ++i) t2u[(size_t)jpp * T2U_ROW + i] = t2[(size_t)t2u_beta(i) * RC + jpp];
         for (int q = 0; q < NPOLY; ++q)
             for (int t3 = 0; t3 < NBF3; ++t3) bq[(size_t)q * NBF3 + t3] = unit_fwd((long long)q * pass3_rho(t3), N_FFT);
         for (int q = 0; q < NPOLY; ++q)

@@ -64,7 +64,7 @@ struct gpsacq_engine {
     int64_t ring_cells[kTimingRing] = {};
     long searches = 0;  // searches enqueued so far; search k uses ring slot k % kTimingRing
     // constants
-    cf *d_t1 = nullptr, *d_t2 = nullptr, *d_t2u = nullptr, *d_bq = nullptr, *d_tn = nullptr;
+    cf *d_t1 = nullptr, *d_t2 = nullptr, *d_bq = nullptr, *d_tn = nullptr;
     uint8_t *d_cos = nullptr, *d_sin = nullptr;
     uint64_t *d_cos_t = nullptr, *d_sin_t = nullptr;  // bit-transposed masks for k_fwd
     cf* d_code = nullptr;  // [32 + patch_cap][8][crow]
@@ -91,7 +91,7 @@ struct gpsacq_engine {
     size_t sats_cap = 0;
     uint8_t* d_gen = nullptr;
     size_t gen_cap = 0;
-    unsigned long long* d_prof = nullptr;  // GPSACQ_PROF=1: s_memtime phase profile of k_corr2<PROF> (kernel experiments)
+    unsigned long long* d_prof = nullptr;  // GPSACQ_PROF=1: s_memtime phase profile of k_corr (diagnostic; 22-column coherent instance)
     // cached default schedule
     size_t sched_tasks = 0;
     bool sched_valid = false;
@@ -162,7 +162,7 @@ extern "C" void gpsacq_destroy(gpsacq_engine* e) {
     if (!e) return;
     (void)hipSetDevice(e->p.device);
     if (e->stream) (void)hipStreamSynchronize(e->stream);
-    void* bufs[] = {e->d_t1, e->d_t2, e->d_t2u, e->d_bq, e->d_tn, e->d_cos, e->d_sin, e->d_cos_t, e->d_sin_t, e->d_code, e->d_patch_blocks, e->d_bits, e->d_iq, e->d_iqbits, e->d_sums, e->d_sats, e->d_gen, e->d_prof, e->d_rot8,
+    void* bufs[] = {e->d_t1, e->d_t2, e->d_bq, e->d_tn, e->d_cos, e->d_sin, e->d_cos_t, e->d_sin_t, e->d_code, e->d_patch_blocks, e->d_bits, e->d_iq, e->d_iqbits, e->d_sums, e->d_sats, e->d_gen, e->d_prof, e->d_rot8,
                     e->d_dpp, e->d_parts, e->d_tasks, e->d_cells, e->d_peaks};
     for (void* b : bufs)
         if (b) (void)hipFree(b);
@@ -186,6 +186,7 @@ extern "C" int gpsacq_create(const gpsacq_params* params, gpsacq_engine** out) {
     const int mc = corr_columns(nlags);
     if (dmax >= N_FFT / 2) return fail(GPSACQ_ERR_UNSUPPORTED, "max_fo = %g Hz exceeds half the sampling rate", params->max_fo);
 
+    (void)hipGetLastError();  // HIP's last-error slot is sticky: do not inherit an earlier, unrelated failure of this thread
     int ndev = 0;
     hipError_t he = hipGetDeviceCount(&ndev);
     if (he != hipSuccess || ndev <= 0)
@@ -249,8 +250,6 @@ extern "C" int gpsacq_create(const gpsacq_params* params, gpsacq_engine** out) {
     HCK(hipMemcpy(e->d_bq, T.bq.data(), T.bq.size() * sizeof(cf), hipMemcpyHostToDevice));
     HCK(hipMemcpy(e->d_t1, T.t1.data(), T.t1.size() * sizeof(cf), hipMemcpyHostToDevice));
     HCK(hipMemcpy(e->d_t2, T.t2.data(), T.t2.size() * sizeof(cf), hipMemcpyHostToDevice));
-    HCK(hipMalloc((void**)&e->d_t2u, T.t2u.size() * sizeof(cf)));
-    HCK(hipMemcpy(e->d_t2u, T.t2u.data(), T.t2u.size() * sizeof(cf), hipMemcpyHostToDevice));
 
     std::vector<uint8_t> cosm(BLOCK_BYTES), sinm(BLOCK_BYTES);
     lo_masks(params->fc, params->fs, BLOCK_BYTES, cosm.data(), sinm.data());
@@ -398,7 +397,6 @@ static int search_core(gpsacq_engine* e, const uint8_t* d_bits, size_t n_blocks,
     ca.tasks = e->d_tasks;
     ca.t1 = e->d_t1;
     ca.t2 = e->d_t2;
-    ca.t2u = e->d_t2u;
     ca.bq = e->d_bq;
     ca.cells = d_cells;
     ca.n_tasks = (int)n_tasks;
@@ -443,10 +441,10 @@ static int search_core(gpsacq_engine* e, const uint8_t* d_bits, size_t n_blocks,
         unsigned long long h[16];
         HIPCHK(hipMemcpyAsync(h, e->d_prof, sizeof h, hipMemcpyDeviceToHost, e->stream));
         HIPCHK(hipStreamSynchronize(e->stream));
-        static const char* seg[8] = {"load+mul", "pass1", "barrier1", "pass2", "barrier2", "pass3(+prefetch)", "barrier3", "scan"};
+        static const char* seg[8] = {"load+mul", "pass1", "barrier1", "pass2", "barrier2", "pass3", "barrier3", "scan"};
         const double cells = (double)n_tasks * e->ndop;
         for (int r = 0; r < 2; ++r) {
-            fprintf(stderr, "k_corr2 profile, role %d, cycles per cell:", r ? 3 : 0);
+            fprintf(stderr, "k_corr profile, wave %d, cycles per cell:", r ? 3 : 0);
             double tot = 0;
             for (int k = 0; k < 8; ++k) { fprintf(stderr, " %s %.0f", seg[k], h[8 * r + k] / cells); tot += h[8 * r + k] / cells; }
             fprintf(stderr, " | total %.0f\n", tot);

@@ -90,8 +90,9 @@ struct gpsacq_multi {
 extern "C" void gpsacq_multi_destroy(gpsacq_multi* m) {
     if (!m) return;
     for (size_t i = 0; i < m->eng.size(); ++i) {
+        if (!m->eng[i]) continue;  // creation stopped before this device
         (void)hipSetDevice(m->dev[i]);
-        if (m->eng[i]) (void)gpsacq_synchronize(m->eng[i]);
+        (void)gpsacq_synchronize(m->eng[i]);
         if (i < m->comm.size() && m->comm[i]) (void)g_rccl.CommDestroy(m->comm[i]);
         for (void* p : {(void*)m->d_bits[i], (void*)m->d_tasks[i], (void*)m->d_peaks[i], (void*)m->d_keys[i]})
             if (p) (void)hipFree(p);

@@ -77,7 +77,8 @@ void emul_forward_real(const float* x, float* out) {
 
 // One cell of Correlate(): data/code spectra given in natural order (data un-conjugated).
 // mc = accumulator columns of the kernel instance (12, 22, 33 or 40).
-int emul_cell(const float* dspec, const float* cspec, int halo, int dop, int S, int mc, float* max_pwr,
+// w1h: the instance derives half of its pass-1 twiddles (33 and 28 columns in the product).
+int emul_cell(const float* dspec, const float* cspec, int halo, int dop, int S, int mc, int w1h, float* max_pwr,
               int* max_i, float* tot_pwr) {
     const Tables& T = tables();
     const int crow = M_SUB + 2 * halo;
@@ -91,20 +92,27 @@ int emul_cell(const float* dspec, const float* cspec, int halo, int dop, int S, 
             cpp[(size_t)q * crow + h] = cpp[(size_t)q * crow + M_SUB + h];
             cpp[(size_t)q * crow + halo + M_SUB + h] = cpp[(size_t)q * crow + halo + h];
         }
-    std::vector<cf> lds(M_SUB);
+    std::vector<cf> lds(LayB::SIZE);
     std::vector<cf> acc((size_t)WG * MC_MAX, mk(0.f, 0.f));
     std::vector<cf> w1((size_t)WG * 2 * (RA - 1));
-    for (int tid = 0; tid < WG; ++tid) load_tw1(tid, T.t1.data(), *reinterpret_cast<cf(*)[2][RA - 1]>(&w1[(size_t)tid * 2 * (RA - 1)]));
+    for (int tid = 0; tid < WG; ++tid) {
+        auto& w = *reinterpret_cast<cf(*)[2][RA - 1]>(&w1[(size_t)tid * 2 * (RA - 1)]);
+        if (w1h) load_tw1<true>(tid, T.t1.data(), w);
+        else load_tw1<false>(tid, T.t1.data(), w);
+    }
     for (int q = 0; q < NPOLY; ++q) {
-        for (int tid = 0; tid < WG; ++tid)
-            corr_phase1<2>(tid, q, dop, dpp.data(), cpp.data(), crow, halo,
-                           *reinterpret_cast<cf(*)[2][RA - 1]>(&w1[(size_t)tid * 2 * (RA - 1)]), lds.data());
+        for (int tid = 0; tid < WG; ++tid) {
+            auto& w = *reinterpret_cast<cf(*)[2][RA - 1]>(&w1[(size_t)tid * 2 * (RA - 1)]);
+            if (w1h) corr_phase1<2, true>(tid, q, dop, dpp.data(), cpp.data(), crow, halo, w, lds.data());
+            else corr_phase1<2, false>(tid, q, dop, dpp.data(), cpp.data(), crow, halo, w, lds.data());
+        }
         for (int tid = 0; tid < WG; ++tid) corr_phase2(tid, T.t2.data(), lds.data());
         for (int tid = 0; tid < WG; ++tid) {
             cf* a = &acc[(size_t)tid * MC_MAX];
             switch (mc) {
                 case 12: corr_phase3<12>(tid, T.bq[(size_t)q * NBF3 + (tid < NBF3 ? tid : 0)], &T.wq[(size_t)q * WQ_STRIDE], lds.data(), a); break;
                 case 22: corr_phase3<22>(tid, T.bq[(size_t)q * NBF3 + (tid < NBF3 ? tid : 0)], &T.wq[(size_t)q * WQ_STRIDE], lds.data(), a); break;
+                case 28: corr_phase3<28>(tid, T.bq[(size_t)q * NBF3 + (tid < NBF3 ? tid : 0)], &T.wq[(size_t)q * WQ_STRIDE], lds.data(), a); break;
                 case 33: corr_phase3<33>(tid, T.bq[(size_t)q * NBF3 + (tid < NBF3 ? tid : 0)], &T.wq[(size_t)q * WQ_STRIDE], lds.data(), a); break;
                 case 40: corr_phase3<40>(tid, T.bq[(size_t)q * NBF3 + (tid < NBF3 ? tid : 0)], &T.wq[(size_t)q * WQ_STRIDE], lds.data(), a); break;
                 default: return -1;
@@ -120,6 +128,7 @@ int emul_cell(const float* dspec, const float* cspec, int halo, int dop, int S, 
         switch (mc) {
             case 12: corr_scan<12>(tid, S, 0, a, tmx, tmi, tsum); break;
             case 22: corr_scan<22>(tid, S, 0, a, tmx, tmi, tsum); break;
+            case 28: corr_scan<28>(tid, S, 0, a, tmx, tmi, tsum); break;
             case 33: corr_scan<33>(tid, S, 0, a, tmx, tmi, tsum); break;
             default: corr_scan<40>(tid, S, 0, a, tmx, tmi, tsum); break;
         }
@@ -130,70 +139,6 @@ int emul_cell(const float* dspec, const float* cspec, int halo, int dop, int S, 
     *max_i = mi;
     *tot_pwr = sum;
     return 0;
-}
-
-// Same cell through the phase functions of k_corr2: inputs requested in two calls (rows [0, pre) "before the
-// barrier", the rest after), pipelined pass 2, LDS slot map LayA / LayB.
-extern "C++" {
-template <class L>
-static int emul_cell2_t(const float* dspec, const float* cspec, int halo, int dop, int S, int pre, int pipe, float* max_pwr, int* max_i, float* tot_pwr) {
-    const Tables& T = tables();
-    const int crow = M_SUB + 2 * halo;
-    std::vector<cf> dpp((size_t)NPOLY * M_SUB), cpp((size_t)NPOLY * crow);
-    for (int k = 0; k < N_FFT; ++k) {
-        dpp[(size_t)(k & 7) * M_SUB + (k >> 3)] = mk(dspec[2 * k], -dspec[2 * k + 1]);
-        cpp[(size_t)(k & 7) * crow + halo + (k >> 3)] = mk(cspec[2 * k], cspec[2 * k + 1]);
-    }
-    for (int q = 0; q < NPOLY; ++q)
-        for (int h = 0; h < halo; ++h) {
-            cpp[(size_t)q * crow + h] = cpp[(size_t)q * crow + M_SUB + h];
-            cpp[(size_t)q * crow + halo + M_SUB + h] = cpp[(size_t)q * crow + halo + h];
-        }
-    std::vector<cf> lds(L::SIZE);
-    constexpr int MC = 22;
-    std::vector<cf> acc((size_t)WG * MC, mk(0.f, 0.f));
-    for (int q = 0; q < NPOLY; ++q) {
-        for (int tid = 0; tid < NBF3; ++tid) {
-            cf w1[2][RA - 1];
-            load_tw1(tid, T.t1.data(), w1);
-            cf2 d[RA], c[RA];
-            cf x0[RA], x1[RA];
-            if (pre == 5) {
-                corr_issue<0, 5>(tid, q, dop, dpp.data(), cpp.data(), crow, halo, d, c);
-                corr_issue<5, RA>(tid, q, dop, dpp.data(), cpp.data(), crow, halo, d, c);
-            } else {
-                corr_issue<0, RA>(tid, q, dop, dpp.data(), cpp.data(), crow, halo, d, c);
-            }
-            corr_mul<0, 5>(d, c, x0, x1);
-            corr_mul<5, RA>(d, c, x0, x1);
-            corr_phase1_store<L>(tid, x0, x1, w1, lds.data());
-        }
-        for (int vt = 0; vt < NBF2; ++vt) {
-            if (pipe) pass2_pipe<+1, L>(vt, T.t2u.data(), lds.data());
-            else pass2_inplace<+1, L>(vt, T.t2.data(), lds.data());
-        }
-        for (int tid = 0; tid < WG; ++tid)
-            corr_phase3<MC, L>(tid, T.bq[(size_t)q * NBF3 + (tid < NBF3 ? tid : 0)], &T.wq[(size_t)q * WQ_STRIDE], lds.data(), &acc[(size_t)tid * MC]);
-    }
-    float mx = 0.f, sum = 0.f;
-    int mi = 0;
-    for (int tid = 0; tid < WG; ++tid) {
-        float tmx, tsum;
-        int tmi;
-        corr_scan<MC>(tid, S, 0, &acc[(size_t)tid * MC], tmx, tmi, tsum);
-        peak_merge(mx, mi, tmx, tmi);
-        sum += tsum;
-    }
-    *max_pwr = mx;
-    *max_i = mi;
-    *tot_pwr = sum;
-    return 0;
-}
-
-}  // extern "C++"
-int emul_cell2(const float* dspec, const float* cspec, int halo, int dop, int S, int pre, int layb, int pipe, float* max_pwr, int* max_i, float* tot_pwr) {
-    return layb ? emul_cell2_t<LayB>(dspec, cspec, halo, dop, S, pre, pipe, max_pwr, max_i, tot_pwr)
-                : emul_cell2_t<LayA>(dspec, cspec, halo, dop, S, pre, pipe, max_pwr, max_i, tot_pwr);
 }
 
 // host-side table/code helpers of the product, exposed for bit-exact checks against the oracle

@@ -114,3 +114,11 @@ def test_shard_helpers():
             assert all(parts[i][0] + parts[i][1] == parts[i + 1][0] for i in range(w - 1))
             assert max(p[1] for p in parts) - min(p[1] for p in parts) <= 1
     assert D.shard_doppler(36, 0, 2) == (-36, 37) and D.shard_doppler(36, 1, 2) == (1, 36)
+    # Doppler grids of any step (gpsacq_set_doppler_step): configs[4]'s 4399 points over 8 ranks, and more ranks than points
+    parts = [D.shard_doppler_grid(4399, -2199, r, 8) for r in range(8)]
+    assert parts[0][0] == -2199 and parts[-1][0] + parts[-1][1] - 1 == 2199 and sum(p[1] for p in parts) == 4399
+    assert all(parts[i][0] + parts[i][1] == parts[i + 1][0] for i in range(7))
+    parts = [D.shard_doppler_grid(3, -1, r, 8) for r in range(8)]
+    assert [p[1] for p in parts] == [1, 1, 1, 0, 0, 0, 0, 0]
+    # strong scaling of bench.py: 340 runs (the Nottingham capture) over 8 ranks
+    assert [D.shard_runs(340, r, 8)[1] for r in range(8)] == [43, 43, 43, 43, 42, 42, 42, 42]

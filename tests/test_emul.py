@@ -23,8 +23,7 @@ def emul():
     E.emul_forward_bits.argtypes = [vp] * 4
     E.emul_forward_bits_sub.argtypes = [vp, vp, vp, i, i, vp]
     E.emul_forward_real.argtypes = [vp] * 2
-    E.emul_cell.argtypes = [vp, vp, i, i, i, i, vp, vp, vp]
-    E.emul_cell2.argtypes = [vp, vp, i, i, i, i, i, i, vp, vp, vp]
+    E.emul_cell.argtypes = [vp, vp, i, i, i, i, i, vp, vp, vp]
     E.emul_code_replica.argtypes = [d, i, vp]
     E.emul_lo_masks.argtypes = [d, d, vp, vp]
     E.emul_search_code.argtypes = [i, i]
@@ -52,9 +51,9 @@ def test_host_tables_bit_exact(emul):
         assert emul.emul_nlags(fs) == L.oracle_nlags(fs)
 
 
-@pytest.mark.parametrize("fc,fs,file,mc", [(4.092e6, 5.456e6, "synth_nott_fs5456.bin", 22), (2.046e6, 8.184e6, "gps_sig_tmp.bin", 33),
-                                           (0.62e6, 2.8e6, "synth_rtl_fs2800.bin", 12)])
-def test_emulated_kernels_vs_oracle(emul, golden_dir, fc, fs, file, mc):
+@pytest.mark.parametrize("fc,fs,file,mc,w1h", [(4.092e6, 5.456e6, "synth_nott_fs5456.bin", 22, 0), (2.046e6, 8.184e6, "gps_sig_tmp.bin", 33, 1),
+                                               (0.62e6, 2.8e6, "synth_rtl_fs2800.bin", 12, 0), (4.092e6, 5.456e6, "synth_nott_fs5456.bin", 28, 1)])
+def test_emulated_kernels_vs_oracle(emul, golden_dir, fc, fs, file, mc, w1h):
     buf = open(os.path.join(golden_dir, file), "rb").read()
     blk = np.frombuffer(buf[7 * 5120:8 * 5120], np.uint8).copy()
     orc = Oracle(fc, fs, 5000.0)
@@ -78,15 +77,10 @@ def test_emulated_kernels_vs_oracle(emul, golden_dir, fc, fs, file, mc):
     c_in = np.ascontiguousarray(c_orc).view(np.float32)
     for dop in (-orc.dmax, -9, 0, 1, orc.dmax):
         mp, mi, tp = ctypes.c_float(), ctypes.c_int(), ctypes.c_float()
-        assert emul.emul_cell(_p(d_in), _p(c_in), 24, dop, orc.num_lags, mc, ctypes.byref(mp), ctypes.byref(mi), ctypes.byref(tp)) == 0
+        assert emul.emul_cell(_p(d_in), _p(c_in), 24, dop, orc.num_lags, mc, w1h, ctypes.byref(mp), ctypes.byref(mi), ctypes.byref(tp)) == 0
         ref = cells[dop + orc.dmax]
         assert abs(mp.value / ref["max_pwr"] - 1) < 2e-5 and abs(tp.value / ref["tot_pwr"] - 1) < 2e-5
         assert mi.value == ref["max_i"]
-        if mc == 22:  # k_corr2's phase functions (split input requests, pass 2 by wave role): same numbers as k_corr's
-            for pre, layb, pipe in ((5, 0, 0), (10, 0, 1), (5, 1, 0), (10, 1, 1)):
-                mp2, mi2, tp2 = ctypes.c_float(), ctypes.c_int(), ctypes.c_float()
-                assert emul.emul_cell2(_p(d_in), _p(c_in), 24, dop, orc.num_lags, pre, layb, pipe, ctypes.byref(mp2), ctypes.byref(mi2), ctypes.byref(tp2)) == 0
-                assert abs(mp2.value / mp.value - 1) < 1e-6 and abs(tp2.value / tp.value - 1) < 1e-6 and mi2.value == mi.value
 
 
 def test_emulated_subbin_forward_vs_oracle(emul, golden_dir):

@@ -19,19 +19,31 @@ lines = [f"# rocprofv3 summary {tag}", "", note, ""]
 ks = os.path.join(src, "trace", "t_kernel_stats.csv")
 if os.path.exists(ks):
     shutil.copy(ks, os.path.join(dst, f"{tag}_kernel_stats.csv"))
-    lines += ["## `rocprofv3 --kernel-trace --stats -- python bench.py --steps 5 --warmup 1 --no-cpu-baseline` (acq kernels)", "",
+    cmd = open(os.path.join(src, "command.txt")).read().strip() if os.path.exists(os.path.join(src, "command.txt")) else "bench.py --steps 5 --warmup 1 --no-cpu-baseline"
+    lines += [f"## `rocprofv3 --kernel-trace --stats -- python {cmd}` (acq kernels; every launch of a kernel has the same size)", "",
               "| kernel | calls | avg us | min us | max us | % of GPU time |", "|---|---|---|---|---|---|"]
     for r in csv.DictReader(open(ks)):
         if "acq::" in r["Name"]:
             lines.append(f"| `{r['Name'][:60]}` | {r['Calls']} | {float(r['AverageNs'])/1e3:.1f} | {float(r['MinNs'])/1e3:.1f} | "
                          f"{float(r['MaxNs'])/1e3:.1f} | {float(r['Percentage']):.2f} |")
     lines.append("")
-bl = os.path.join(src, "bench_traced.log")
-if os.path.exists(bl):
-    for l in open(bl):
-        if l.startswith("{"):
-            j = json.loads(l)
-            lines += ["bench line of the traced run: " + json.dumps({k: j[k] for k in ("value", "ms_per_step", "roofline", "stage_ms") if k in j}), ""]
+cells_per_launch = None
+for name, what in (("bench_traced.log", "traced"), ("bench_unprofiled.log", "un-profiled")):
+    bl = os.path.join(src, name)
+    if os.path.exists(bl):
+        for l in open(bl):
+            if l.startswith("{"):
+                j = json.loads(l)
+                cells_per_launch = j.get("roofline", {}).get("cells_per_launch", cells_per_launch)
+                r = j.get("roofline", {})
+                lines += [f"bench line of the {what} run of the same command: " + json.dumps(
+                    {"value": j.get("value"), "ms_per_step": j.get("ms_per_step"), "stage_ms": j.get("stage_ms"),
+                     "roofline": {k: r.get(k) for k in ("bound", "kernel", "achieved", "peak", "unit", "frac", "kernel_ms", "cells_per_launch", "flops_per_cell")}}), ""]
+pp = os.path.join(src, "phase_profile.log")
+if os.path.exists(pp):
+    ph = [l.strip() for l in open(pp) if "k_corr profile" in l]
+    if ph:
+        lines += ["## s_memtime phase profile (`GPSACQ_PROF=1`, k_corr<22,...,PROF>; cycles per cell per wave, summed over the launch / cells)", ""] + ["    " + l for l in ph[-2:]] + [""]
 
 agg = collections.defaultdict(list)
 for f in sorted(glob.glob(os.path.join(src, "pmc*", "p_counter_collection.csv"))):
@@ -41,7 +53,7 @@ for f in sorted(glob.glob(os.path.join(src, "pmc*", "p_counter_collection.csv"))
             agg[(r["Kernel_Name"][:48], "_vgpr")] = [float(r["VGPR_Count"]) + float(r["Accum_VGPR_Count"])]
             agg[(r["Kernel_Name"][:48], "_grid")] = [float(r["Grid_Size"])]
 if agg:
-    lines += ["## PMC passes (`rocprofv3 --pmc <set>`, separate runs, `bench.py --steps 2 --warmup 1 --blocks 1024`), per-launch averages", ""]
+    lines += ["## PMC passes (`rocprofv3 --pmc <set>`, one run per set, the same command with --steps 2), per-launch averages", ""]
     kernels = sorted({k for k, _ in agg})
     for k in kernels:
         lines.append(f"### `{k}`")
@@ -62,7 +74,7 @@ if agg:
 # per-cell HBM traffic of the dominant kernel for bench.py's roofline.traffic
 try:
     d = {c: sum(v) / len(v) for (kk, c), v in agg.items() if "k_corr" in kk}
-    cells = d["_grid"] / 256.0 if "_grid" in d else None  # grid = workgroups*256 threads; one workgroup per cell (padded)
+    cells = cells_per_launch or (d["_grid"] / 256.0 if "_grid" in d else None)  # the bench line's count; else grid / 256 (one workgroup per cell, padded)
     if cells and "FETCH_SIZE" in d and "WRITE_SIZE" in d:
         onchip = {}
         for key, name in (("SQ_INSTS_VALU", "valu_wave_instr_per_cell"), ("SQ_INSTS_LDS", "lds_wave_instr_per_cell"),
@@ -74,9 +86,11 @@ try:
             onchip["l2_hit_rate"] = d["TCC_HIT_sum"] / (d["TCC_HIT_sum"] + d["TCC_MISS_sum"])
         if "SQ_WAVE_CYCLES" in d:
             for key, name in (("SQ_ACTIVE_INST_VALU", "valu_share_of_wave_cycles"), ("SQ_WAIT_INST_ANY", "issue_stall_share_of_wave_cycles"),
-                              ("SQ_WAIT_ANY", "waitcnt_barrier_share_of_wave_cycles")):
+                              ("SQ_WAIT_INST_LDS", "lds_issue_stall_share_of_wave_cycles"), ("SQ_WAIT_ANY", "waitcnt_barrier_share_of_wave_cycles")):
                 if key in d:
                     onchip[name] = d[key] / d["SQ_WAVE_CYCLES"]
+        if "GRBM_GUI_ACTIVE" in d and "TCP_TCC_READ_REQ_sum" in d:
+            onchip["l2_to_l1_bytes_per_cell"] = d["TCP_TCC_READ_REQ_sum"] * 64.0 / cells
         json.dump({"tag": tag, "kernel": "k_corr", "cells_per_launch_profiled": cells,
                    "hbm_read_bytes_per_cell": d["FETCH_SIZE"] * 1024 * 2 / cells,
                    "hbm_write_bytes_per_cell": d["WRITE_SIZE"] * 1024 / cells,
