@@ -99,12 +99,16 @@ struct gpsacq_engine {
 
 static const size_t kFwdChunk = 32768;  // blocks per forward-transform launch (grid.y bound)
 
-template <class T> static int grow(T*& p, size_t& cap, size_t need, size_t elem_bytes = sizeof(T)) {
+// Scratch buffers grow on demand, stream-ordered (hipFreeAsync / hipMallocAsync on the engine's stream): work already
+// enqueued keeps the old buffer until it has run, and no device-wide synchronisation happens in mid-stream.  They grow by at
+// least half so that a caller creeping up in batch size does not reallocate every call.
+template <class T> static int grow(T*& p, size_t& cap, size_t need, hipStream_t stream, size_t elem_bytes = sizeof(T)) {
     if (need <= cap) return GPSACQ_OK;
-    if (p) HIPCHK(hipFree(p));
+    need = std::max(need, cap + cap / 2);
+    if (p) HIPCHK(hipFreeAsync(p, stream));
     p = nullptr;
     cap = 0;
-    HIPCHK(hipMalloc((void**)&p, need * elem_bytes));
+    HIPCHK(hipMallocAsync((void**)&p, need * elem_bytes, stream));
     cap = need;
     return GPSACQ_OK;
 }
@@ -319,7 +323,7 @@ static int prepare_tasks(gpsacq_engine* e, const gpsacq_task* h_tasks, const voi
     if (!h_tasks && !d_user_tasks) {
         if (e->sched_valid && n_tasks <= e->sched_tasks && !quirks && e->n_acc == 1) return GPSACQ_OK;  // cached (a prefix is the same schedule)
     }
-    if (int rc = grow(e->d_tasks, e->task_cap, n_tasks)) return rc;
+    if (int rc = grow(e->d_tasks, e->task_cap, n_tasks, e->stream)) return rc;
     e->sched_valid = false;
     std::vector<gpsacq_task> tmp;
     if (!h_tasks && d_user_tasks) {
@@ -380,9 +384,9 @@ static int search_core(gpsacq_engine* e, const uint8_t* d_bits, size_t n_blocks,
     if (n_blocks > 0x7fffffffu) return fail(GPSACQ_ERR_ARG, "batch too large: %zu blocks", n_blocks);
     if (n_tasks * (size_t)e->ndop > 0x7fffff00u) return fail(GPSACQ_ERR_ARG, "batch too large: %zu tasks x %d bins", n_tasks, e->ndop);
     if (n_blocks * (size_t)e->sub > 0x7fffffffu) return fail(GPSACQ_ERR_ARG, "batch too large: %zu blocks x %d sub-bin spectra", n_blocks, e->sub);
-    if (int rc = grow(e->d_dpp, e->dpp_cap, n_blocks * (size_t)e->sub, (size_t)NPOLY * M_SUB * sizeof(cf))) return rc;
+    if (int rc = grow(e->d_dpp, e->dpp_cap, n_blocks * (size_t)e->sub, e->stream, (size_t)NPOLY * M_SUB * sizeof(cf))) return rc;
     if (!d_cells) {
-        if (int rc = grow(e->d_cells, e->cell_cap, n_tasks * (size_t)e->ndop)) return rc;
+        if (int rc = grow(e->d_cells, e->cell_cap, n_tasks * (size_t)e->ndop, e->stream)) return rc;
         d_cells = e->d_cells;
     }
     if (int rc = prepare_tasks(e, h_tasks, d_user_tasks, n_blocks, n_tasks, d_bits, stride)) return rc;
@@ -427,7 +431,7 @@ static int search_core(gpsacq_engine* e, const uint8_t* d_bits, size_t n_blocks,
         if (launch_corr(ca, e->mc, e->stream) != 0) return fail(GPSACQ_ERR_UNSUPPORTED, "no correlate kernel for %d columns", e->mc);
     } else {
         const size_t n_cells = n_tasks * (size_t)e->ndop;
-        if (int rc = grow(e->d_parts, e->parts_cap, n_cells * (size_t)n_pass)) return rc;
+        if (int rc = grow(e->d_parts, e->parts_cap, n_cells * (size_t)n_pass, e->stream)) return rc;
         for (int p = 0; p < n_pass; ++p) {
             ca.m0 = p * MC_MAX;
             ca.cells = e->d_parts + (size_t)p * n_cells;
@@ -476,10 +480,10 @@ extern "C" int gpsacq_search(gpsacq_engine* e, const uint8_t* bits, size_t n_blo
     if (n_blocks == 0 || n_tasks == 0) return fail(GPSACQ_ERR_ARG, "empty batch");
     HIPCHK(hipSetDevice(e->p.device));
     const size_t nbytes = (n_blocks - 1) * stride + (stride < (size_t)BLOCK_BYTES ? stride : (size_t)BLOCK_BYTES);
-    if (int rc = grow(e->d_bits, e->bits_cap, nbytes)) return rc;
+    if (int rc = grow(e->d_bits, e->bits_cap, nbytes, e->stream)) return rc;
     HIPCHK(hipMemcpyAsync(e->d_bits, bits, nbytes, hipMemcpyHostToDevice, e->stream));
-    if (int rc = grow(e->d_cells, e->cell_cap, n_tasks * (size_t)e->ndop)) return rc;
-    if (int rc = grow(e->d_peaks, e->peak_cap, n_tasks)) return rc;
+    if (int rc = grow(e->d_cells, e->cell_cap, n_tasks * (size_t)e->ndop, e->stream)) return rc;
+    if (int rc = grow(e->d_peaks, e->peak_cap, n_tasks, e->stream)) return rc;
     if (int rc = search_core(e, e->d_bits, n_blocks, stride, tasks, nullptr, n_tasks, e->d_cells, e->d_peaks)) return rc;
     if (cells) HIPCHK(hipMemcpyAsync(cells, e->d_cells, n_tasks * (size_t)e->ndop * sizeof(Cell), hipMemcpyDeviceToHost, e->stream));
     if (peaks) HIPCHK(hipMemcpyAsync(peaks, e->d_peaks, n_tasks * sizeof(Peak), hipMemcpyDeviceToHost, e->stream));
@@ -598,7 +602,7 @@ extern "C" int gpsacq_generate_device(gpsacq_engine* e, void* d_bits, size_t n_b
         gs[i].carrier_phase = sats[i].carrier_phase_cycles;
     }
     if (n_sats > 0) {
-        if (int rc = grow(e->d_sats, e->sats_cap, (size_t)n_sats)) return rc;
+        if (int rc = grow(e->d_sats, e->sats_cap, (size_t)n_sats, e->stream)) return rc;
         HIPCHK(hipMemcpyAsync(e->d_sats, gs.data(), gs.size() * sizeof(GenSat), hipMemcpyHostToDevice, e->stream));
         HIPCHK(hipStreamSynchronize(e->stream));  // gs goes out of scope
     }
@@ -620,7 +624,7 @@ extern "C" int gpsacq_generate(gpsacq_engine* e, uint8_t* bits_out, size_t n_byt
                                float noise_sigma, uint64_t seed) {
     if (!e || !bits_out || n_bytes == 0) return fail(GPSACQ_ERR_ARG, "gpsacq_generate: bad argument");
     HIPCHK(hipSetDevice(e->p.device));
-    if (int rc = grow(e->d_gen, e->gen_cap, n_bytes)) return rc;
+    if (int rc = grow(e->d_gen, e->gen_cap, n_bytes, e->stream)) return rc;
     if (int rc = gpsacq_generate_device(e, e->d_gen, n_bytes, sats, n_sats, noise_sigma, seed, 0)) return rc;
     HIPCHK(hipMemcpyAsync(bits_out, e->d_gen, n_bytes, hipMemcpyDeviceToHost, e->stream));
     HIPCHK(hipStreamSynchronize(e->stream));
@@ -665,8 +669,8 @@ extern "C" int gpsacq_iq8_to_bits(gpsacq_engine* e, const void* iq, size_t n_sam
     if (!e || !iq || !bits_out || n_samples == 0) return fail(GPSACQ_ERR_ARG, "gpsacq_iq8_to_bits: bad argument");
     HIPCHK(hipSetDevice(e->p.device));
     const size_t n_bytes = (n_samples + 7) / 8;
-    if (int rc = grow(e->d_iq, e->iq_cap, 2 * n_samples + 16)) return rc;
-    if (int rc = grow(e->d_iqbits, e->iqbits_cap, n_bytes)) return rc;
+    if (int rc = grow(e->d_iq, e->iq_cap, 2 * n_samples + 16, e->stream)) return rc;
+    if (int rc = grow(e->d_iqbits, e->iqbits_cap, n_bytes, e->stream)) return rc;
     HIPCHK(hipMemcpyAsync(e->d_iq, iq, 2 * n_samples, hipMemcpyHostToDevice, e->stream));
     if (int rc = gpsacq_iq8_to_bits_device(e, e->d_iq, n_samples, format, remove_dc, mix_hz, fs, e->d_iqbits, 0)) return rc;
     HIPCHK(hipMemcpyAsync(bits_out, e->d_iqbits, n_bytes, hipMemcpyDeviceToHost, e->stream));
@@ -711,8 +715,8 @@ static void pp_to_natural(const std::vector<cf>& pp, long row, int off, bool con
 extern "C" int gpsacq_sample_spectrum(gpsacq_engine* e, const uint8_t* block, float* out) {
     if (!e || !block || !out) return fail(GPSACQ_ERR_ARG, "gpsacq_sample_spectrum: null argument");
     HIPCHK(hipSetDevice(e->p.device));
-    if (int rc = grow(e->d_bits, e->bits_cap, (size_t)BLOCK_BYTES)) return rc;
-    if (int rc = grow(e->d_dpp, e->dpp_cap, (size_t)1, (size_t)NPOLY * M_SUB * sizeof(cf))) return rc;
+    if (int rc = grow(e->d_bits, e->bits_cap, (size_t)BLOCK_BYTES, e->stream)) return rc;
+    if (int rc = grow(e->d_dpp, e->dpp_cap, (size_t)1, e->stream, (size_t)NPOLY * M_SUB * sizeof(cf))) return rc;
     HIPCHK(hipMemcpyAsync(e->d_bits, block, BLOCK_BYTES, hipMemcpyHostToDevice, e->stream));
     if (int rc = run_forward(e, true, e->d_bits, BLOCK_BYTES, 1, e->d_dpp, (size_t)NPOLY * M_SUB, M_SUB, 0, true)) return rc;
     std::vector<cf> pp((size_t)NPOLY * M_SUB);

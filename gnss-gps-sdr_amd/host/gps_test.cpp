@@ -50,6 +50,7 @@ int main(int argc, char **argv) {
     }
     std::fflush(stdout);
     SearchTask(&capture[0]);
+    const int status = SearchStatus();  // a device failure in mid-file: nonzero exit (the reference cannot fail there)
     SearchFree();
-    return 0;
+    return status;
 }

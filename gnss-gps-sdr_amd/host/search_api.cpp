@@ -21,6 +21,7 @@
 
 static std::vector<gpsacq_engine *> g_engines;
 static bool g_busy[GPSACQ_NUM_SATS];
+static int g_status = 0;  // status of the last SearchTask(): 0, or the gpsacq error that stopped it (SearchStatus())
 
 static int env_int(const char *name, int dflt) {
     const char *v = getenv(name);
@@ -76,7 +77,10 @@ void SearchEnable(int sv) {
 
 int SearchCode(int sv, int g1) { return gpsacq_search_code(sv, g1); }
 
+int SearchStatus() { return g_status; }
+
 void SearchTask(char *filename_1bit_bin) {
+    g_status = 0;
     FILE *fp = fopen(filename_1bit_bin, "rb");
     if (fp == NULL) {
         printf("can not open file!\n");
@@ -85,6 +89,7 @@ void SearchTask(char *filename_1bit_bin) {
     if (g_engines.empty()) {
         fprintf(stderr, "gpsacq: SearchTask() before a successful SearchInit()\n");
         fclose(fp);
+        g_status = GPSACQ_ERR_ARG;
         return;
     }
     const size_t run_bytes = (size_t)GPSACQ_NUM_SATS * GPSACQ_BLOCK_BYTES;
@@ -123,11 +128,11 @@ void SearchTask(char *filename_1bit_bin) {
             }
             for (std::thread &w : workers) w.join();
             for (size_t d = 0; d < n_dev; d++)
-                if (rcs[d] != GPSACQ_OK) {
+                if (rcs[d] != GPSACQ_OK) {  // a library function does not exit(): report, stop, leave the status for the caller
                     fprintf(stderr, "gpsacq: %s\n", errs[d].c_str());
-                    fclose(fp);
-                    exit(2);
+                    g_status = rcs[d];
                 }
+            if (g_status != 0) break;
             for (size_t r = 0; r < runs; r++, run_count++) {
                 const gpsacq_peak *pk = &peaks[r * GPSACQ_NUM_SATS];
                 int hit[GPSACQ_NUM_SATS], hit_count = 0;
@@ -148,6 +153,7 @@ void SearchTask(char *filename_1bit_bin) {
                 for (int sv = 0; sv < GPSACQ_NUM_SATS; sv++) printf("%2.0f ", pk[sv].snr);
                 printf("\n\n");
             }
+            fflush(stdout);  // the reference prints run by run; here a batch of runs at a time
         }
         if (got < buf.size()) {
             printf("run out of file!\n");

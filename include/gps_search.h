@@ -16,4 +16,8 @@ void SearchTask(char *filename_1bit_bin); // c/search_offline.cpp:219  prints th
 void SearchEnable(int sv);                // c/search_offline.cpp:213
 int SearchCode(int sv, int g1);           // c/search_offline.cpp:205
 
+// Not in the reference (its SearchTask is void and cannot fail after fopen): 0, or the gpsacq error code that made the last
+// SearchTask() stop early (message on stderr).  A caller that does not know about it -- the reference's own main() -- loses nothing.
+int SearchStatus();
+
 #endif
