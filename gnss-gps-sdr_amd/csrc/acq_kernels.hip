@@ -101,7 +101,7 @@ __global__ __launch_bounds__(WG) void k_quirk_patch(QuirkArgs a) {
 // re-aligned by the whole samples the code has crept since block 0 at this cell's Doppler (a.creep samples per block per
 // grid point; 0 = plain sum): power of lag n goes to lag (n - round(k * creep * point)) mod S.
 // W1H: half of the pass-1 twiddles derived instead of held (acq_math.hpp): 18 registers for 18 packed multiplies.
-// PROF: s_memtime stamps per segment, summed over the launch into a.prof (GPSACQ_PROF=1; costs a few per cent).
+// PROF: s_memtime stamps per segment, summed over the launch into a.prof[1024][16] (GPSACQ_PROF=1; costs a few per cent).
 template <int MC, int WPS, int NB, bool NC, bool W1H = false, bool PROF = false>
 __global__ __launch_bounds__(WG, WPS) void k_corr(CorrArgs a) {
     __shared__ __attribute__((aligned(16))) cf lds[LayB::SIZE];  // transform buffer, slot map LayB
@@ -219,7 +219,9 @@ __global__ __launch_bounds__(WG, WPS) void k_corr(CorrArgs a) {
     ACQ_STAMP(7);  // scan + reduction
 #undef ACQ_STAMP
     if (PROF && a.prof && (tid & 63) == 0 && (wave == 0 || wave == 3)) {
-        for (int k = 0; k < 8; ++k) atomicAdd(a.prof + (wave == 0 ? 0 : 8) + k, tprof[k]);
+        // 1024 buckets of 16 counters (summed by the host): 16 addresses for the whole launch would serialise ~13 M atomics in L2
+        unsigned long long* bucket = a.prof + (size_t)(blockIdx.x & 1023) * 16 + (wave == 0 ? 0 : 8);
+        for (int k = 0; k < 8; ++k) atomicAdd(bucket + k, tprof[k]);
     }
 }
 

@@ -47,7 +47,7 @@ struct CorrArgs {
     float creep;          // non-coherent mode: code creep in samples per accumulated block per Doppler bin (0 = off)
     int n_spec, n_code;   // rows of dpp / cpp: tasks pointing outside get an empty cell (max_i = -1)
     int sub, dstride;     // Doppler grid (acq_phases.hpp grid_point): dop_first/ndop count grid points; spectrum of (block, r) at row block*sub + r
-    unsigned long long* prof;  // k_corr<..., PROF>: [16] accumulated s_memtime deltas per segment (GPSACQ_PROF=1 diagnostic), else NULL
+    unsigned long long* prof;  // k_corr<..., PROF>: [1024][16] accumulated s_memtime deltas per segment (bucket = workgroup % 1024) (GPSACQ_PROF=1 diagnostic), else NULL
 };
 
 void launch_fwd_bits(const FwdArgs& a, int n_items, hipStream_t s);

@@ -24,7 +24,19 @@ struct GenArgs {
     float noise_sigma;
 };
 
+// gps_sig_gen.m's own signal (gen_kernels.hip, k_siggen)
+struct SigArgs {
+    uint8_t* bits;       // [n_bytes] output, LSB first
+    size_t n_bytes;
+    long long n_samples; // n_data * 20 * 1023 * 8 + 48 (the tail of the shaping filter); bits beyond it are 0
+    const int8_t* data;  // [n_data] navigation bits +-1 (device)
+    int n_data;
+    int sv;              // PRN index 0..31
+    double two_pi_fc;    // (2 pi) * (ca_rate / 4), rounded like the script's left-to-right product
+    double inv_rate;     // 1 / ca_rate
+};
 hipError_t upload_chips(const uint32_t* host);
+void launch_siggen(const SigArgs& a, hipStream_t s);
 void launch_generate(const GenArgs& a, hipStream_t s);
 
 }  // namespace acq

@@ -417,8 +417,8 @@ static int search_core(gpsacq_engine* e, const uint8_t* d_bits, size_t n_blocks,
     ca.sub = e->sub;
     ca.dstride = e->dstride;
     if (getenv("GPSACQ_PROF")) {
-        if (!e->d_prof) HIPCHK(hipMalloc((void**)&e->d_prof, 16 * sizeof(unsigned long long)));
-        HIPCHK(hipMemsetAsync(e->d_prof, 0, 16 * sizeof(unsigned long long), e->stream));
+        if (!e->d_prof) HIPCHK(hipMalloc((void**)&e->d_prof, 1024 * 16 * sizeof(unsigned long long)));
+        HIPCHK(hipMemsetAsync(e->d_prof, 0, 1024 * 16 * sizeof(unsigned long long), e->stream));
         ca.prof = e->d_prof;
     }
     const int n_cols = (e->nlags + NBF3 - 1) / NBF3;
@@ -442,10 +442,12 @@ static int search_core(gpsacq_engine* e, const uint8_t* d_bits, size_t n_blocks,
     HIPCHK(hipGetLastError());
     HIPCHK(hipEventRecord(ev[2], e->stream));
     if (ca.prof) {  // wave-role 0 and role 3 (lane 0): cycles summed over all workgroups, per segment
-        unsigned long long h[16];
-        HIPCHK(hipMemcpyAsync(h, e->d_prof, sizeof h, hipMemcpyDeviceToHost, e->stream));
+        std::vector<unsigned long long> hb(1024 * 16);
+        HIPCHK(hipMemcpyAsync(hb.data(), e->d_prof, hb.size() * sizeof(unsigned long long), hipMemcpyDeviceToHost, e->stream));
         HIPCHK(hipStreamSynchronize(e->stream));
-        static const char* seg[8] = {"load+mul", "pass1", "barrier1", "pass2", "barrier2", "pass3", "barrier3", "scan"};
+        unsigned long long h[16] = {0};
+        for (size_t i = 0; i < hb.size(); ++i) h[i & 15] += hb[i];
+        static const char* seg[8] = {"-", "load+mul+pass1", "barrier1", "pass2", "barrier2", "pass3", "barrier3", "scan"};
         const double cells = (double)n_tasks * e->ndop;
         for (int r = 0; r < 2; ++r) {
             fprintf(stderr, "k_corr profile, wave %d, cycles per cell:", r ? 3 : 0);
@@ -626,6 +628,39 @@ extern "C" int gpsacq_generate(gpsacq_engine* e, uint8_t* bits_out, size_t n_byt
     HIPCHK(hipSetDevice(e->p.device));
     if (int rc = grow(e->d_gen, e->gen_cap, n_bytes, e->stream)) return rc;
     if (int rc = gpsacq_generate_device(e, e->d_gen, n_bytes, sats, n_sats, noise_sigma, seed, 0)) return rc;
+    HIPCHK(hipMemcpyAsync(bits_out, e->d_gen, n_bytes, hipMemcpyDeviceToHost, e->stream));
+    HIPCHK(hipStreamSynchronize(e->stream));
+    return GPSACQ_OK;
+}
+
+// gps_sig_gen.m's signal for any PRN / navigation bits (k_siggen)
+extern "C" size_t gpsacq_sig_bytes(int n_data_bits) {
+    if (n_data_bits < 1) return 0;
+    const long long n = (long long)n_data_bits * 20 * 1023 * 8 + 48;
+    return (size_t)((n + 7) / 8);
+}
+extern "C" int gpsacq_generate_sig(gpsacq_engine* e, int prn, const int8_t* data_bits, int n_data_bits, uint8_t* bits_out, size_t n_bytes) {
+    if (!e || !data_bits || !bits_out || n_data_bits < 1 || n_data_bits > 100000) return fail(GPSACQ_ERR_ARG, "gpsacq_generate_sig: bad argument");
+    if (prn < 1 || prn > GPSACQ_NUM_SATS) return fail(GPSACQ_ERR_ARG, "gpsacq_generate_sig: PRN %d out of 1..32", prn);
+    if (n_bytes != gpsacq_sig_bytes(n_data_bits)) return fail(GPSACQ_ERR_ARG, "gpsacq_generate_sig: %d bits make %zu bytes, not %zu", n_data_bits, gpsacq_sig_bytes(n_data_bits), n_bytes);
+    for (int i = 0; i < n_data_bits; ++i)
+        if (data_bits[i] != 1 && data_bits[i] != -1) return fail(GPSACQ_ERR_ARG, "gpsacq_generate_sig: navigation bit %d is %d, not +-1", i, data_bits[i]);
+    HIPCHK(hipSetDevice(e->p.device));
+    if (int rc = grow(e->d_gen, e->gen_cap, n_bytes + (size_t)n_data_bits, e->stream)) return rc;
+    int8_t* d_data = (int8_t*)(e->d_gen + n_bytes);
+    HIPCHK(hipMemcpyAsync(d_data, data_bits, (size_t)n_data_bits, hipMemcpyHostToDevice, e->stream));
+    const double ca_rate = 1.023e6 * 8, fc = ca_rate / 4;  // gps_sig_gen.m:8-9,14,34
+    SigArgs a{};
+    a.bits = e->d_gen;
+    a.n_bytes = n_bytes;
+    a.n_samples = (long long)n_data_bits * 20 * 1023 * 8 + 48;
+    a.data = d_data;
+    a.n_data = n_data_bits;
+    a.sv = prn - 1;
+    a.two_pi_fc = (2.0 * 3.141592653589793) * fc;  // 1i.*2.*pi.*fc, left to right (:36)
+    a.inv_rate = 1.0 / ca_rate;
+    launch_siggen(a, e->stream);
+    HIPCHK(hipGetLastError());
     HIPCHK(hipMemcpyAsync(bits_out, e->d_gen, n_bytes, hipMemcpyDeviceToHost, e->stream));
     HIPCHK(hipStreamSynchronize(e->stream));
     return GPSACQ_OK;

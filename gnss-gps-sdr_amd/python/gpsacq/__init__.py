@@ -55,7 +55,7 @@ class Sat(ctypes.Structure):
                 ("code_phase_samples", ctypes.c_double), ("carrier_phase_cycles", ctypes.c_double)]
 
 
-EXPORTS = ["gpsacq_generate", "gpsacq_generate_device", "gpsacq_handoff", "gpsacq_iq8_to_bits", "gpsacq_iq8_to_bits_device", "gpsacq_create", "gpsacq_destroy", "gpsacq_last_error", "gpsacq_get_info", "gpsacq_search",
+EXPORTS = ["gpsacq_generate", "gpsacq_generate_device", "gpsacq_generate_sig", "gpsacq_sig_bytes", "gpsacq_handoff", "gpsacq_iq8_to_bits", "gpsacq_iq8_to_bits_device", "gpsacq_create", "gpsacq_destroy", "gpsacq_last_error", "gpsacq_get_info", "gpsacq_search",
            "gpsacq_search_device", "gpsacq_set_doppler_window", "gpsacq_set_doppler_step", "gpsacq_set_noncoherent", "gpsacq_set_creep_compensation", "gpsacq_aligned_stride", "gpsacq_synchronize", "gpsacq_last_timing", "gpsacq_timing_ago", "gpsacq_stream", "gpsacq_search_code",
            "gpsacq_sample_spectrum", "gpsacq_code_spectrum", "gpsacq_multi_create", "gpsacq_multi_destroy",
            "gpsacq_multi_set_doppler_step", "gpsacq_multi_get_info", "gpsacq_multi_search_grid"]
@@ -132,6 +132,10 @@ def load_library(path=None):
     lib.gpsacq_generate.restype = ctypes.c_int
     lib.gpsacq_generate_device.argtypes = [vp, vp, sz, ctypes.POINTER(Sat), ctypes.c_int, ctypes.c_float, ctypes.c_uint64, ctypes.c_int]
     lib.gpsacq_generate_device.restype = ctypes.c_int
+    lib.gpsacq_sig_bytes.argtypes = [ctypes.c_int]
+    lib.gpsacq_sig_bytes.restype = ctypes.c_size_t
+    lib.gpsacq_generate_sig.argtypes = [vp, ctypes.c_int, vp, ctypes.c_int, vp, sz]
+    lib.gpsacq_generate_sig.restype = ctypes.c_int
     lib.gpsacq_handoff.argtypes = [vp, ctypes.c_double, ctypes.c_double, ctypes.c_double, ctypes.POINTER(Handoff)]
     lib.gpsacq_handoff.restype = ctypes.c_int
     lib.gpsacq_search_code.argtypes = [ctypes.c_int, ctypes.c_int]
@@ -306,6 +310,16 @@ class Engine:
         out = np.zeros(int(n_bytes), dtype=np.uint8)
         _check(self._lib, self._lib.gpsacq_generate(self._h, out.ctypes.data_as(ctypes.c_void_p), int(n_bytes), self._sats(sats),
                                                     len(sats), float(noise_sigma), int(seed)))
+        return out
+
+    def generate_sig(self, prn, data_bits):
+        """gps_sig_gen.m's signal on the device: PRN `prn`, navigation bits +-1 (20 code periods each), 8.184 Msps,
+        IF 2.046 MHz, raised-cosine BPSK, 1 bit per sample.  Returns the packed bytes."""
+        d = np.ascontiguousarray(np.asarray(data_bits, dtype=np.int8))
+        n = self._lib.gpsacq_sig_bytes(int(d.size))
+        out = np.zeros(n, dtype=np.uint8)
+        _check(self._lib, self._lib.gpsacq_generate_sig(self._h, int(prn), d.ctypes.data_as(ctypes.c_void_p), int(d.size),
+                                                        out.ctypes.data_as(ctypes.c_void_p), n))
         return out
 
     def generate_device(self, d_bits_ptr, n_bytes, sats=(), noise_sigma=1.0, seed=1, sync=True):

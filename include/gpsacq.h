@@ -20,7 +20,8 @@
  *   gpsacq_search_code       SearchCode()            c/search_offline.cpp:205-209
  *   gpsacq_iq8_to_bits       the MATLAB pre-processing that produces gps_test's input from an 8-bit IQ
  *                            capture: proc_rtl_bin_for_gps.m:12-26,31-47, proc_hackrf_bin_for_gps.m:7-19
- *   gpsacq_generate          gps_sig_gen.m:8-41 (synthetic 1-bit capture; here noise + any PRN set)
+ *   gpsacq_generate          the role of gps_sig_gen.m (synthetic 1-bit capture; here noise + any PRN set with Doppler)
+ *   gpsacq_generate_sig      gps_sig_gen.m:8-41 itself (one PRN, navigation bits, raised-cosine BPSK at fs/4), bit-exact
  *   gpsacq_handoff           CHANNEL::Start()'s NCO set-up from a search hit, c/channel.cpp:134-163
  *                            (the first consumer of the search result in the online receiver)
  *   gpsacq_sample_spectrum   Sample()'s fwd_buf      c/search_offline.cpp:161 (parity probe)
@@ -235,6 +236,18 @@ int gpsacq_generate(gpsacq_engine* e, uint8_t* bits_out, size_t n_bytes, const g
                     float noise_sigma, uint64_t seed);
 int gpsacq_generate_device(gpsacq_engine* e, void* d_bits_out, size_t n_bytes, const gpsacq_sat* sats, int n_sats,
                            float noise_sigma, uint64_t seed, int sync);
+
+/*
+ * The reference's own test signal (gps_sig_gen.m:8-41, the script that wrote gps_sig_tmp.bin), generated on the device:
+ * PRN `prn` (1..32), noise-free BPSK with the given navigation bits (+-1, 20 code periods each), 8 samples per chip
+ * (fs = 8.184 MHz), raised-cosine shaping (MATLAB rcosine(1, 8)), carrier at fs/4 = 2.046 MHz, 1 bit per sample, LSB first.
+ * Arithmetic in double in the script's own order: with the 100 bits of the bundled file (tests/golden/
+ * gps_sig_tmp_databits.json; the script draws them with an unseeded rand) the output equals gps_sig_tmp.bin bit for bit.
+ * n_bytes must be gpsacq_sig_bytes(n_data_bits) = ceil((n_data_bits * 20 * 1023 * 8 + 48) / 8).  Search it with
+ * fc = 2.046e6, fs = 8.184e6.
+ */
+size_t gpsacq_sig_bytes(int n_data_bits);
+int gpsacq_generate_sig(gpsacq_engine* e, int prn, const int8_t* data_bits, int n_data_bits, uint8_t* bits_out, size_t n_bytes);
 
 /*
  * Acquisition hand-off record: what the tracking channel derives from a search hit
