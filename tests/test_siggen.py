@@ -65,6 +65,7 @@ def test_device_generator_reproduces_the_reference_file(golden_dir):
         diff = np.unpackbits(out ^ ref).sum()
         assert diff == 0, f"{diff} of {8 * ref.size} samples differ"
         # another PRN / other bits: found by the search at zero Doppler like the reference's file
-        out2 = eng.generate_sig(21, [1, -1, -1, 1])
-        _, pk = eng.search(out2[:33 * 5120])
+        out2 = eng.generate_sig(21, [1, -1, -1, 1])  # 81 846 bytes = 15 whole blocks
+        _, pk = eng.search(out2, tasks=[(0, sv) for sv in range(32)] + [(9, 20)])
         assert pk["snr"][20] > 300 and pk["lo_shift"][20] == 0 and int(np.argmax(pk["snr"][:32])) == 20
+        assert pk["snr"][32] > 300 and pk["lo_shift"][32] == 0
