@@ -168,9 +168,9 @@ def cpu_baseline_all_cores(cfg, bits, ndop, target_s=8.0):
 class Leg:
     """One timed workload: `n_tasks` tasks over `nblk` resident blocks on this rank."""
 
-    def __init__(self, torch, gpsacq, gdist, eng, dev, dist, backend, nblk, n_tasks, d_bits, d_tasks, stride, grid):
+    def __init__(self, torch, gpsacq, gdist, eng, dev, dist, backend, nblk, n_tasks, d_bits, d_tasks, stride, grid, n_keys=32):
         self.torch, self.gdist, self.eng, self.dev, self.dist, self.backend = torch, gdist, eng, dev, dist, backend
-        self.nblk, self.n_tasks, self.d_bits, self.d_tasks, self.stride, self.grid = nblk, n_tasks, d_bits, d_tasks, stride, grid
+        self.nblk, self.n_tasks, self.d_bits, self.d_tasks, self.stride, self.grid, self.n_keys = nblk, n_tasks, d_bits, d_tasks, stride, grid, n_keys
         # The search runs on the engine's own HIP stream; the key packing and the collective run on torch's
         # stream, ordered after it by an event, so step i's reduction / all-reduce overlaps step i+1's search
         # (two peak buffers; the engine stream waits for a buffer's previous reader).
@@ -195,8 +195,12 @@ class Leg:
             torch.cuda.current_stream().wait_event(searched)
         # best peak per PRN (block schedule) / per (block, PRN) (grid), packed so that integer MAX reproduces
         # the reference's ordering (higher SNR; ties -> lower Doppler bin, :198)
-        key = self.gdist.pack_keys(buf[:self.n_tasks], eng.dmax) if self.n_tasks > 0 else torch.zeros(0, dtype=torch.int64, device=self.dev)
-        best = key if self.grid else self.gdist.per_prn_best(key)
+        # (a rank without work -- more ranks than runs / grid points -- contributes keys of 0, neutral for MAX)
+        if self.n_tasks > 0:
+            key = self.gdist.pack_keys(buf[:self.n_tasks], eng.kmax)
+            best = key if self.grid else self.gdist.per_prn_best(key)
+        else:
+            best = torch.zeros(self.n_keys, dtype=torch.int64, device=self.dev)
         if self.dist is not None:
             if self.backend == "nccl":
                 self.dist.all_reduce(best, op=self.dist.ReduceOp.MAX)  # RCCL over xGMI, 256 bytes
@@ -355,7 +359,8 @@ def main():
     else:
         d_bits = make_capture(nblk, data_seed, stride)
 
-    leg = Leg(torch, gpsacq, gdist, eng, dev, dist, backend, nblk, n_tasks, d_bits, d_tasks, stride, grid)
+    leg = Leg(torch, gpsacq, gdist, eng, dev, dist, backend, nblk, n_tasks, d_bits, d_tasks, stride, grid,
+              n_keys=(tasks.shape[0] if grid else 32))
     elapsed, kern_ms, best = leg.run(args.steps, args.warmup)
     timing = eng.last_timing() if n_tasks > 0 else None
 
@@ -422,7 +427,7 @@ def main():
         if weak is not None:
             out["weak_scaling"] = weak
         if not grid:
-            snr, lo, ca = gdist.unpack_keys(best.cpu(), eng.dmax)
+            snr, lo, ca = gdist.unpack_keys(best.cpu(), eng.kmax)
             hits = torch.nonzero(snr >= 25).flatten().tolist()
             out["detected_prns"] = [int(p) + 1 for p in hits]
             if args.capture:
