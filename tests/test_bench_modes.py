@@ -1,0 +1,36 @@
+"""bench.py's other modes on the GPU box (the driver only runs the default line): a capture file instead of synthetic data,
+and the configs[4] grid with a Doppler step.  Short runs; the numbers are not asserted, the results are."""
+import json
+import os
+import subprocess
+import sys
+
+import pytest
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _bench(*args):
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "1", "--warmup", "1", "--no-cpu-baseline", *args],
+                       capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, r.stdout
+    return json.loads(lines[0])
+
+
+def test_capture_mode_on_the_bundled_file(golden_dir):
+    """`bench.py --capture` (the hook for gps.samples.1bit.I.fs5456.if4092.bin) on the reference's gps_sig_tmp.bin:
+    12 whole runs, PRN 8 at zero Doppler (README.md:45,57)."""
+    j = _bench("--config", "2", "--capture", os.path.join(golden_dir, "gps_sig_tmp.bin"))
+    assert j["data"] == "capture file" and j["config"]["cells_per_step_job"] == 12 * 32 * 49
+    assert j["scaling"] == "strong" and j["roofline"]["bound"] == "valu_fp32" and 0 < j["roofline"]["frac"] < 1
+    best = {d["prn"]: d for d in j["detected"]}
+    assert 8 in best and best[8]["lo_shift"] == 0 and best[8]["snr"] > 500
+
+
+def test_config4_line():
+    j = _bench("--config", "4", "--doppler-step", "50", "--grid-blocks", "1")
+    assert "4399 Doppler points" in j["config"]["workload"] and j["config"]["cells_per_step_job"] == 32 * 4399
+    assert j["value"] > 0 and j["roofline"]["kernel"] == "k_corr<22>"
