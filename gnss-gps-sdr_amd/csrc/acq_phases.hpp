@@ -72,6 +72,7 @@ ACQ_HD void corr_phase1(int tid, int q, int dop, const cf* __restrict__ dpp, con
     int qp, c;
     shift_split(q, dop, qp, c);
     cf x0[RA], x1[RA];
+    static_assert(RA % NB == 0, "load batches must divide the 10 rows");
     constexpr int PER = RA / NB;
 #if defined(__HIP_DEVICE_COMPILE__)
     // Buffer loads: address = descriptor base + SGPR offset (row of this q / shift, scalar adds) +
