@@ -6,7 +6,6 @@ mkdir -p $OUT
 timeout 1500 python -m pytest tests -m gpu -x -q > $OUT/pytest_gpu.log 2>&1; echo "pytest rc $?" >> $OUT/pytest_gpu.log
 timeout 300 python __graft_entry__.py smoke > $OUT/smoke.log 2>&1
 timeout 300 python tools/rate_other_fs.py > $OUT/rates.log 2>&1
-GPSACQ_WIDE3=1 timeout 300 python tools/rate_other_fs.py > $OUT/rates_wide3.log 2>&1
 timeout 600 python bench.py --steps 5 --warmup 2 > $OUT/bench.json 2> $OUT/bench.err
-tail -5 $OUT/pytest_gpu.log; tail -2 $OUT/smoke.log; cat $OUT/rates.log $OUT/rates_wide3.log | grep -v amdgpu.ids; cut -c1-600 $OUT/bench.json; tail -3 $OUT/bench.err
+tail -5 $OUT/pytest_gpu.log; tail -2 $OUT/smoke.log; cat $OUT/rates.log | grep -v amdgpu.ids; cut -c1-600 $OUT/bench.json; tail -3 $OUT/bench.err
 GPSACQ_PROF=1 timeout 300 python bench.py --steps 1 --warmup 1 --weak-blocks 0 --no-cpu-baseline > $OUT/phase_profile.log 2>&1; grep "profile" $OUT/phase_profile.log | tail -2
