@@ -37,12 +37,13 @@ emul: tests/emul/libemul_acq.so
 tests/emul/libemul_acq.so: tests/emul/emul_acq.cpp $(CSRC)/*.hpp
 	$(CLANGXX) -x c++ $(HOSTFLAGS) -shared -o $@ tests/emul/emul_acq.cpp
 
-# Drop-in check (authoring container only): the reference's own front end, compiled from where
-# it lies and never copied, linked against our SearchInit/SearchTask.  Output is git-ignored.
+# Drop-in check (authoring container only): the reference's own front end, compiled from where it lies and never copied,
+# linked against our SearchInit/SearchTask.  The binary goes to oracle/_ref/ (git-ignored; it travels to the GPU box, where
+# tests/test_gpu_parity.py::test_reference_main_against_our_library runs it).
 dropin-check: $(LIBDIR)/libgps_search.so
-	@mkdir -p build
-	$(CXX) -O2 -I/root/reference/c /root/reference/c/test_search_offline.cpp -o build/gps_test_refmain \
-	    -L$(LIBDIR) -lgps_search -lgpsacq -Wl,-rpath,'$$ORIGIN/../$(LIBDIR)'
+	@mkdir -p oracle/_ref
+	$(CXX) -O2 -I/root/reference/c /root/reference/c/test_search_offline.cpp -o oracle/_ref/gps_test_refmain \
+	    -L$(LIBDIR) -lgps_search -lgpsacq -Wl,-rpath,'$$ORIGIN/../../$(LIBDIR)'
 
 clean:
 	rm -rf $(LIBDIR) $(BINDIR) build tests/emul/libemul_acq.so

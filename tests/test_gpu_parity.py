@@ -269,3 +269,20 @@ def test_gps_test_cli_stdout(golden_dir):
     # missing file: same message as the reference, exit code 0
     r = subprocess.run([GPS_TEST, "/nonexistent.bin", "2.046e6", "8.184e6", "5000"], capture_output=True, text=True, timeout=120)
     assert r.returncode == 0 and r.stdout == BANNER + "can not open file!\n"
+
+
+def test_reference_main_against_our_library(golden_dir):
+    """The reference's UNMODIFIED front end (c/test_search_offline.cpp, compiled in the authoring container by `make
+    dropin-check` into oracle/_ref/gps_test_refmain) linked against libgps_search.so / libgpsacq.so: same stdout as our own
+    gps_test -- the drop-in boundary of SURVEY.md section 8(b) exercised end to end."""
+    import subprocess
+    from test_host import GPS_TEST, ROOT
+    exe = os.path.join(ROOT, "oracle", "_ref", "gps_test_refmain")
+    if not os.path.exists(exe):
+        pytest.skip("oracle/_ref/gps_test_refmain not built (make dropin-check needs /root/reference)")
+    path = os.path.join(golden_dir, "gps_sig_tmp.bin")
+    env = dict(os.environ, GPSACQ_REF_QUIRKS="1")
+    a = subprocess.run([exe, path, "2.046e6", "8.184e6", "5000"], capture_output=True, text=True, env=env, timeout=300)
+    b = subprocess.run([GPS_TEST, path, "2.046e6", "8.184e6", "5000"], capture_output=True, text=True, env=env, timeout=300)
+    assert a.returncode == 0 and b.returncode == 0, a.stderr + b.stderr
+    assert a.stdout == b.stdout and a.stdout.count("satellite:") == 12 and a.stdout.endswith("run out of file!\n")
