@@ -50,6 +50,9 @@ struct CorrArgs {
     unsigned long long* prof;  // k_corr<..., PROF>: [1024][16] accumulated s_memtime deltas per segment (bucket = workgroup % 1024) (GPSACQ_PROF=1 diagnostic), else NULL
 };
 
+// sets this thread's gpsacq_last_error() text and returns `code` (gpsacq_engine.cpp)
+__attribute__((visibility("hidden"))) int set_last_error(int code, const char* msg);
+
 void launch_fwd_bits(const FwdArgs& a, int n_items, hipStream_t s);
 void launch_fwd_real(const FwdArgs& a, int n_items, hipStream_t s);
 void launch_code_halo(cf* cpp, int n_rows, int crow, int halo, hipStream_t s);

@@ -34,7 +34,8 @@ static int fail(int code, const char* fmt, ...) {
     g_err = buf;
     return code;
 }
-extern "C" int gpsacq_set_error_(int code, const char* msg) {  // for the other translation units of the library
+// for the other translation units of the library (acq_launch.hpp); not exported
+__attribute__((visibility("hidden"))) int acq::set_last_error(int code, const char* msg) {
     g_err = msg ? msg : "";
     return code;
 }

@@ -21,8 +21,6 @@
 
 using namespace acq;
 
-extern "C" int gpsacq_set_error_(int code, const char* msg);  // gpsacq_engine.cpp: sets gpsacq_last_error() of this thread
-
 namespace {
 struct Rccl {
     void* so = nullptr;
@@ -59,7 +57,7 @@ int failf(int code, const char* fmt, ...) {
     va_start(ap, fmt);
     vsnprintf(buf, sizeof buf, fmt, ap);
     va_end(ap);
-    return gpsacq_set_error_(code, buf);
+    return acq::set_last_error(code, buf);
 }
 }  // namespace
 
