@@ -8,7 +8,7 @@ CSRC     := $(PKG)/csrc
 HOST     := $(PKG)/host
 LIBDIR   := $(PKG)/lib
 BINDIR   := $(PKG)/bin
-HIPFLAGS := --offload-arch=$(ARCH) -O3 -std=c++17 -fPIC -Wall -Wno-unused-function $(HIPFLAGS_EXTRA)
+HIPFLAGS := --offload-arch=$(ARCH) -O3 -std=c++17 -fPIC -fvisibility=hidden -Wall -Wno-unused-function $(HIPFLAGS_EXTRA)
 HOSTFLAGS:= -O2 -std=c++17 -fPIC -Wall -Wno-unknown-pragmas -ffp-contract=off
 
 all: lib host oracle emul

@@ -102,9 +102,11 @@ __global__ __launch_bounds__(WG) void k_quirk_patch(QuirkArgs a) {
 // grid point; 0 = plain sum): power of lag n goes to lag (n - round(k * creep * point)) mod S.
 // W1H: half of the pass-1 twiddles derived instead of held (acq_math.hpp): 18 registers for 18 packed multiplies.
 // PROF: s_memtime stamps per segment, summed over the launch into a.prof[1024][16] (GPSACQ_PROF=1; costs a few per cent).
-template <int MC, int WPS, int NB, bool NC, bool W1H = false, bool PROF = false>
+// L: LDS slot map (acq_math.hpp): LayB everywhere except the two widest non-coherent instances, whose per-lag power array
+// leaves room for the 40 KB map only (33 columns: 77 KB -> still two workgroups per CU).
+template <int MC, int WPS, int NB, bool NC, bool W1H = false, bool PROF = false, class L = LayB>
 __global__ __launch_bounds__(WG, WPS) void k_corr(CorrArgs a) {
-    __shared__ __attribute__((aligned(16))) cf lds[LayB::SIZE];  // transform buffer, slot map LayB
+    __shared__ __attribute__((aligned(16))) cf lds[L::SIZE];  // transform buffer
     __shared__ cf t2s[NT2];    // the 500 pass-2 twiddles
     __shared__ float red[4 * (WG / 64)];
     __shared__ float pws[NC ? MC * NBF3 : 1];  // non-coherent power per lag of this pass
@@ -160,15 +162,15 @@ __global__ __launch_bounds__(WG, WPS) void k_corr(CorrArgs a) {
             cf wqv[MC];                        // wave-uniform rotations: scalar loads, SGPR operands
 #pragma unroll
             for (int m = 0; m < MC; ++m) wqv[m] = c_wq[q * WQ_STRIDE + a.m0 + m];
-            corr_phase1<NB, W1H>(tid, q, dop, dk, cpp, a.crow, a.halo, w1, lds);
+            corr_phase1<NB, W1H, L>(tid, q, dop, dk, cpp, a.crow, a.halo, w1, lds);
             ACQ_STAMP(1);  // inputs loaded and multiplied, pass 1, its LDS stores drained (the stamp waits on lgkmcnt)
             __syncthreads();  // also orders the t2s fill before its first use
             ACQ_STAMP(2);
-            corr_phase2(tid, t2s, lds);
+            corr_phase2<L>(tid, t2s, lds);
             ACQ_STAMP(3);
             __syncthreads();
             ACQ_STAMP(4);
-            corr_phase3<MC>(tid, b, wqv, lds, acc);
+            corr_phase3<MC, L>(tid, b, wqv, lds, acc);
             ACQ_STAMP(5);
             __syncthreads();
             ACQ_STAMP(6);
@@ -339,11 +341,11 @@ int launch_corr(const CorrArgs& a, int mc, hipStream_t s) {
             else hipLaunchKernelGGL((k_corr<28, 3, 2, false, true>), grid, block, 0, s, a);
             break;
         case 33:
-            if (a.n_acc > 1) hipLaunchKernelGGL((k_corr<33, 2, 2, true>), grid, block, 0, s, a);
+            if (a.n_acc > 1) hipLaunchKernelGGL((k_corr<33, 2, 2, true, false, false, LayA>), grid, block, 0, s, a);
             else hipLaunchKernelGGL((k_corr<33, 3, 2, false, true>), grid, block, 0, s, a);
             break;
         case 40:
-            if (a.n_acc > 1) hipLaunchKernelGGL((k_corr<40, 1, 2, true>), grid, block, 0, s, a);  // 89 KB of LDS: one workgroup per CU
+            if (a.n_acc > 1) hipLaunchKernelGGL((k_corr<40, 1, 2, true, false, false, LayA>), grid, block, 0, s, a);  // 84 KB of LDS: one workgroup per CU
             else hipLaunchKernelGGL((k_corr<40, 3, 2, false, true>), grid, block, 0, s, a);  // 40 bytes of spills: still 7 % faster than 2 per CU
             break;
         default: return -1;

@@ -65,7 +65,7 @@ ACQ_HD void load_tw1(int tid, const cf* __restrict__ t1, cf (&w)[2][RA - 1]) {
 #else
 #define ACQ_SCHED_FENCE() ((void)0)
 #endif
-template <int NB, bool W1H = false>
+template <int NB, bool W1H = false, class L = LayB>
 ACQ_HD void corr_phase1(int tid, int q, int dop, const cf* __restrict__ dpp, const cf* __restrict__ cpp,
                         int crow, int halo, const cf (&w)[2][RA - 1], cf* lds) {
     if (tid >= NBF3) return;
@@ -108,21 +108,28 @@ ACQ_HD void corr_phase1(int tid, int q, int dop, const cf* __restrict__ dpp, con
             x1[b * PER + i] = cmul(d[i].zw, cc[i].zw);
         }
     }
-    pass1_store_pair<+1, W1H>(x0, x1, tid, w[0], w[1], lds);  // LDS slot map LayB (acq_math.hpp)
+    if (L::SJ == 1) {
+        pass1_store_pair<+1, W1H>(x0, x1, tid, w[0], w[1], lds);  // slot map LayB (acq_math.hpp): one 16-byte store per alpha
+    } else {
+        static_assert(L::SJ == 1 || !W1H, "derived twiddles are implemented for slot map LayB");
+        pass1_store<+1, L>(x0, 2 * tid, w[0], lds);
+        pass1_store<+1, L>(x1, 2 * tid + 1, w[1], lds);
+    }
 }
 
+template <class L = LayB>
 ACQ_HD void corr_phase2(int tid, const cf* t2, cf* lds) {
-    if (tid < NBF2) pass2_inplace<+1, LayB>(tid, t2, lds);
+    if (tid < NBF2) pass2_inplace<+1, L>(tid, t2, lds);
 }
 
 // acc[m] accumulates y[n] for n = 250 (m0 + m) + rho over the 8 polyphase components (m0, the first
 // column of this pass, is a multiple of 20 so that column m0 + m reads radix-20 output m % 20):
 // W_N^{-q n} = conj(b) (per thread, b = bq[q][tid]) * conj(wqv[m]) (wave-uniform, wqv[m] = W_160^{q m}).
-template <int MC>
+template <int MC, class L = LayB>
 ACQ_HD void corr_phase3(int tid, cf b, const cf* wqv, const cf* lds, cf* acc) {
     if (tid >= NBF3) return;
     cf y[RC];
-    pass3_load<+1, LayB>(tid, lds, y);
+    pass3_load<+1, L>(tid, lds, y);
 #pragma unroll
     for (int n = 0; n < RC; ++n) y[n] = cmulc(y[n], b);
 #pragma unroll

@@ -40,6 +40,9 @@
 extern "C" {
 #endif
 
+/* the library is built with -fvisibility=hidden: exactly the functions declared here are exported */
+#define GPSACQ_API __attribute__((visibility("default")))
+
 #define GPSACQ_FFT_LEN 40000      /* FFT_LEN, c/gps_offline.h:15 (compile-time in the reference) */
 #define GPSACQ_NUM_SATS 32        /* NUM_SATS, c/gps_offline.h:16 */
 #define GPSACQ_BLOCK_BYTES 5120   /* bytes consumed per Sample(): 10 packets x 512 B */
@@ -118,12 +121,12 @@ typedef struct {
 } gpsacq_timing;
 
 /* SearchInit(): builds the 32 code spectra, LO tables and twiddles on the device. */
-int gpsacq_create(const gpsacq_params* params, gpsacq_engine** out);
+GPSACQ_API int gpsacq_create(const gpsacq_params* params, gpsacq_engine** out);
 /* SearchFree() */
-void gpsacq_destroy(gpsacq_engine* e);
+GPSACQ_API void gpsacq_destroy(gpsacq_engine* e);
 /* message of the last failing call on this thread ("" if none) */
-const char* gpsacq_last_error(void);
-int gpsacq_get_info(const gpsacq_engine* e, gpsacq_info* info);
+GPSACQ_API const char* gpsacq_last_error(void);
+GPSACQ_API int gpsacq_get_info(const gpsacq_engine* e, gpsacq_info* info);
 
 /*
  * Search a batch.  `bits`: capture bytes, 1-bit real IF samples packed LSB first; block b
@@ -133,7 +136,7 @@ int gpsacq_get_info(const gpsacq_engine* e, gpsacq_info* info);
  * (SearchTask(), :239-246).  Outputs (either may be NULL): cells[n_tasks][num_doppler] in
  * ascending Doppler-bin order, peaks[n_tasks].  Host pointers; returns after completion.
  */
-int gpsacq_search(gpsacq_engine* e, const uint8_t* bits, size_t n_blocks, size_t stride,
+GPSACQ_API int gpsacq_search(gpsacq_engine* e, const uint8_t* bits, size_t n_blocks, size_t stride,
                   const gpsacq_task* tasks, size_t n_tasks, gpsacq_cell* cells, gpsacq_peak* peaks);
 
 /*
@@ -143,7 +146,7 @@ int gpsacq_search(gpsacq_engine* e, const uint8_t* bits, size_t n_blocks, size_t
  * a task whose block or prn is out of range is skipped by the kernel and reported as cells with
  * max_i = -1, snr = 0 (peak: snr = 0) instead of GPSACQ_ERR_ARG.
  */
-int gpsacq_search_device(gpsacq_engine* e, const void* d_bits, size_t n_blocks, size_t stride,
+GPSACQ_API int gpsacq_search_device(gpsacq_engine* e, const void* d_bits, size_t n_blocks, size_t stride,
                          const void* d_tasks, size_t n_tasks, void* d_cells, void* d_peaks, int sync);
 /*
  * Restrict the search to Doppler bins first_bin .. first_bin+n_bins-1 (within -dmax..+dmax).
@@ -151,7 +154,7 @@ int gpsacq_search_device(gpsacq_engine* e, const void* d_bits, size_t n_blocks, 
  * reference always scans the full range, :176).  cells rows then hold n_bins entries and
  * lo_shift stays an absolute bin number.
  */
-int gpsacq_set_doppler_window(gpsacq_engine* e, int first_bin, int n_bins);
+GPSACQ_API int gpsacq_set_doppler_window(gpsacq_engine* e, int first_bin, int n_bins);
 /*
  * Doppler grid step (extension; the reference's grid is whole FFT bins of fs/40000 Hz, c/search_offline.cpp:176,182,
  * and its front end ignores argv[4]).  step_hz <= 0 or within (bin, 2 bin): the reference grid.  step_hz < bin: the
@@ -165,7 +168,7 @@ int gpsacq_set_doppler_window(gpsacq_engine* e, int first_bin, int n_bins);
  * Costs R forward transforms and R x 320 KB of spectra per block; the correlate work per grid point is unchanged.
  */
 #define GPSACQ_MAX_DOPPLER_SUB 16
-int gpsacq_set_doppler_step(gpsacq_engine* e, double step_hz);
+GPSACQ_API int gpsacq_set_doppler_step(gpsacq_engine* e, double step_hz);
 /*
  * Non-coherent accumulation (extension; the reference scans one coherent block per cell,
  * c/search_offline.cpp:176-199): every task then sums |IFFT|^2 per lag over n_acc block spectra
@@ -176,7 +179,7 @@ int gpsacq_set_doppler_step(gpsacq_engine* e, double step_hz);
  * reference behaviour.  With tasks == NULL the schedule is task t = (block t, prn t % 32) for
  * t < n_tasks <= n_blocks - (n_acc-1)*block_step.
  */
-int gpsacq_set_noncoherent(gpsacq_engine* e, int n_acc, int block_step);
+GPSACQ_API int gpsacq_set_noncoherent(gpsacq_engine* e, int n_acc, int block_step);
 /*
  * Code-creep compensation for the non-coherent mode (off by default).  A carrier offset f -- true
  * Doppler, or the crystal error of a single-oscillator front end such as the rtl-sdr, which is what
@@ -188,17 +191,17 @@ int gpsacq_set_noncoherent(gpsacq_engine* e, int n_acc, int block_step);
  * Doppler bin; ca_shift then refers to block 0.  Ignored (plain sum) when fs > 10 MHz (more than
  * 10000 lags are searched in several passes).
  */
-int gpsacq_set_creep_compensation(gpsacq_engine* e, int on);
-int gpsacq_aligned_stride(const gpsacq_engine* e);
-int gpsacq_synchronize(gpsacq_engine* e);
+GPSACQ_API int gpsacq_set_creep_compensation(gpsacq_engine* e, int on);
+GPSACQ_API int gpsacq_aligned_stride(const gpsacq_engine* e);
+GPSACQ_API int gpsacq_synchronize(gpsacq_engine* e);
 /* stage times of the most recent search (waits for it to finish) ... */
-int gpsacq_last_timing(const gpsacq_engine* e, gpsacq_timing* t);
+GPSACQ_API int gpsacq_last_timing(const gpsacq_engine* e, gpsacq_timing* t);
 /* ... and of the search n_back calls earlier (0 = last; the 8 most recent are kept): lets a caller
  * that enqueues searches with sync = 0 read a finished search's times while the next one runs */
-int gpsacq_timing_ago(const gpsacq_engine* e, int n_back, gpsacq_timing* t);
+GPSACQ_API int gpsacq_timing_ago(const gpsacq_engine* e, int n_back, gpsacq_timing* t);
 /* the engine's HIP stream (a hipStream_t) for callers that order their own device work after an
  * asynchronous gpsacq_*_device call with an event instead of a host wait; NULL for a NULL engine */
-void* gpsacq_stream(gpsacq_engine* e);
+GPSACQ_API void* gpsacq_stream(gpsacq_engine* e);
 
 /*
  * 8-bit IQ capture -> the 1-bit real-IF stream gpsacq_search() takes.  format GPSACQ_IQ_U8: rtl-sdr
@@ -211,9 +214,9 @@ void* gpsacq_stream(gpsacq_engine* e);
  */
 #define GPSACQ_IQ_U8 0
 #define GPSACQ_IQ_S8 1
-int gpsacq_iq8_to_bits(gpsacq_engine* e, const void* iq, size_t n_samples, int format, int remove_dc,
+GPSACQ_API int gpsacq_iq8_to_bits(gpsacq_engine* e, const void* iq, size_t n_samples, int format, int remove_dc,
                        double mix_hz, double fs, uint8_t* bits_out);
-int gpsacq_iq8_to_bits_device(gpsacq_engine* e, const void* d_iq, size_t n_samples, int format, int remove_dc,
+GPSACQ_API int gpsacq_iq8_to_bits_device(gpsacq_engine* e, const void* d_iq, size_t n_samples, int format, int remove_dc,
                               double mix_hz, double fs, void* d_bits_out, int sync);
 
 /*
@@ -232,9 +235,9 @@ typedef struct {
     double code_phase_samples;
     double carrier_phase_cycles;
 } gpsacq_sat;
-int gpsacq_generate(gpsacq_engine* e, uint8_t* bits_out, size_t n_bytes, const gpsacq_sat* sats, int n_sats,
+GPSACQ_API int gpsacq_generate(gpsacq_engine* e, uint8_t* bits_out, size_t n_bytes, const gpsacq_sat* sats, int n_sats,
                     float noise_sigma, uint64_t seed);
-int gpsacq_generate_device(gpsacq_engine* e, void* d_bits_out, size_t n_bytes, const gpsacq_sat* sats, int n_sats,
+GPSACQ_API int gpsacq_generate_device(gpsacq_engine* e, void* d_bits_out, size_t n_bytes, const gpsacq_sat* sats, int n_sats,
                            float noise_sigma, uint64_t seed, int sync);
 
 /*
@@ -246,8 +249,8 @@ int gpsacq_generate_device(gpsacq_engine* e, void* d_bits_out, size_t n_bytes, c
  * n_bytes must be gpsacq_sig_bytes(n_data_bits) = ceil((n_data_bits * 20 * 1023 * 8 + 48) / 8).  Search it with
  * fc = 2.046e6, fs = 8.184e6.
  */
-size_t gpsacq_sig_bytes(int n_data_bits);
-int gpsacq_generate_sig(gpsacq_engine* e, int prn, const int8_t* data_bits, int n_data_bits, uint8_t* bits_out, size_t n_bytes);
+GPSACQ_API size_t gpsacq_sig_bytes(int n_data_bits);
+GPSACQ_API int gpsacq_generate_sig(gpsacq_engine* e, int prn, const int8_t* data_bits, int n_data_bits, uint8_t* bits_out, size_t n_bytes);
 
 /*
  * Acquisition hand-off record: what the tracking channel derives from a search hit
@@ -262,7 +265,7 @@ typedef struct {
     uint32_t ca_pause;  /* NCO pause to align the code generator = (2*spm - ca_shift) % spm, spm = samples
                            per millisecond (the reference hard-codes 20000 / 10000 for its 10 MHz FPGA, :163) */
 } gpsacq_handoff_t;
-int gpsacq_handoff(const gpsacq_peak* peak, double fc, double fs, double secs_since_sample, gpsacq_handoff_t* out);
+GPSACQ_API int gpsacq_handoff(const gpsacq_peak* peak, double fc, double fs, double secs_since_sample, gpsacq_handoff_t* out);
 
 /*
  * Single-process multi-GPU search of ONE capture's PRN x Doppler grid (BASELINE.json configs[4]; the reference is
@@ -275,19 +278,19 @@ int gpsacq_handoff(const gpsacq_peak* peak, double fc, double fs, double secs_si
  * RCCL is dlopen'ed on first use (librccl.so.1); GPSACQ_ERR_DEVICE if it is missing.
  */
 typedef struct gpsacq_multi gpsacq_multi;
-int gpsacq_multi_create(const gpsacq_params* params, const int32_t* devices, int n_devices, gpsacq_multi** out);
-void gpsacq_multi_destroy(gpsacq_multi* m);
-int gpsacq_multi_set_doppler_step(gpsacq_multi* m, double step_hz);
-int gpsacq_multi_get_info(const gpsacq_multi* m, gpsacq_info* info, int32_t* n_devices);
-int gpsacq_multi_search_grid(gpsacq_multi* m, const uint8_t* bits, size_t n_blocks, size_t stride,
+GPSACQ_API int gpsacq_multi_create(const gpsacq_params* params, const int32_t* devices, int n_devices, gpsacq_multi** out);
+GPSACQ_API void gpsacq_multi_destroy(gpsacq_multi* m);
+GPSACQ_API int gpsacq_multi_set_doppler_step(gpsacq_multi* m, double step_hz);
+GPSACQ_API int gpsacq_multi_get_info(const gpsacq_multi* m, gpsacq_info* info, int32_t* n_devices);
+GPSACQ_API int gpsacq_multi_search_grid(gpsacq_multi* m, const uint8_t* bits, size_t n_blocks, size_t stride,
                              const gpsacq_task* tasks, size_t n_tasks, gpsacq_peak* peaks);
 
 /* SearchCode(): chips to clock PRN sv's generator until its G1 register reads g1 (-1 if never) */
-int gpsacq_search_code(int sv, int g1);
+GPSACQ_API int gpsacq_search_code(int sv, int g1);
 
 /* Parity probes (natural bin order, interleaved re/im, 40000 complex floats each). */
-int gpsacq_sample_spectrum(gpsacq_engine* e, const uint8_t* block5120, float* out);
-int gpsacq_code_spectrum(gpsacq_engine* e, int sv, float* out);
+GPSACQ_API int gpsacq_sample_spectrum(gpsacq_engine* e, const uint8_t* block5120, float* out);
+GPSACQ_API int gpsacq_code_spectrum(gpsacq_engine* e, int sv, float* out);
 
 #ifdef __cplusplus
 }

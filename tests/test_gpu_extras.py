@@ -317,3 +317,26 @@ def test_noncoherent_creep_compensation():
         eng.set_creep_compensation(False)
         b, _ = eng.search(bits, tasks=tasks, stride=stride)
         assert np.array_equal(a, b)
+
+
+@pytest.mark.parametrize("fc,fs,cols", [(2.046e6, 8.184e6, 33), (2.6e6, 10e6, 40)])
+def test_noncoherent_wide_instances(golden_dir, fc, fs, cols):
+    """The 33- and 40-column non-coherent instances (the only users of the 40 KB LDS slot map in k_corr: their per-lag
+    power array leaves no room for the 45 KB one) against the oracle's restatement."""
+    import gpsacq
+    from oracle_lib import Oracle
+    orc = Oracle(fc, fs, 5000.0)
+    with gpsacq.Engine(fc, fs, 5000.0) as eng:
+        assert eng.acc_columns == cols
+        stride = eng.aligned_stride()
+        assert stride % (eng.num_lags // 8) == 0 and stride >= 5120
+        buf = eng.generate(4 * stride + 5120, [(8, 0.4, 1200.0, 777.0, 0.1), (19, 0.3, -2600.0, 4321.0, 0.6)], noise_sigma=1.0, seed=5).tobytes()
+        eng.set_noncoherent(3, 1)
+        tasks = [(0, 7), (1, 18), (0, 2)]
+        cells, peaks = eng.search(buf, tasks=tasks, stride=stride)
+        for t, (b, sv) in enumerate(tasks):
+            want = orc.search_noncoherent(buf, stride, b, sv, 3, 1)
+            np.testing.assert_allclose(cells["max_pwr"][t], want["max_pwr"], rtol=2e-5)
+            np.testing.assert_allclose(cells["tot_pwr"][t], want["tot_pwr"], rtol=2e-5)
+            assert (cells["max_i"][t] != want["max_i"]).sum() <= 1
+        assert peaks["snr"][0] > 2 * peaks["snr"][2] and peaks["snr"][1] > 2 * peaks["snr"][2]
