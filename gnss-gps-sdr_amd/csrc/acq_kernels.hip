@@ -27,34 +27,40 @@ __constant__ cf c_wq[NPOLY * WQ_STRIDE];
 hipError_t upload_wq(const cf* host) { return hipMemcpyToSymbol(HIP_SYMBOL(c_wq), host, sizeof(cf) * NPOLY * WQ_STRIDE); }
 
 // ---------------------------------------------------------------------------------------
-// Forward transform (Sample() :141-161 / SearchInit() :101-106): grid (8, n_items), one workgroup per
-// (item, kappa) computes row kappa of the item's polyphase spectrum and writes it once, coalesced.
+// Forward transform (Sample() :141-161 / SearchInit() :101-106): grid (n_items), one workgroup per item computes the
+// eight rows of its polyphase spectrum one after the other and writes each once, coalesced.
 template <bool BITS>
 __global__ __launch_bounds__(WG) void k_fwd(FwdArgs a) {
     __shared__ cf lds[M_SUB];
     __shared__ uint64_t ib[BITS ? USED_BYTES / NPOLY : 1], qb[BITS ? USED_BYTES / NPOLY : 1];
     __shared__ cf lut[BITS ? 256 : 1];
-    const int tid = threadIdx.x, kappa = blockIdx.x, item = blockIdx.y;
+    const int tid = threadIdx.x, item = blockIdx.x;
     const int srci = item / a.sub, r = item - srci * a.sub;
-    const cf* tn_row = a.tn + ((size_t)r * NPOLY + kappa) * M_SUB;
-    if (BITS) {
-        fwd_build_lut(tid, a.rot8 + (r * NPOLY + kappa) * NPOLY, lut);
-        fwd_stage_bits(tid, (const uint8_t*)a.src + (size_t)srci * a.src_stride, a.cos_t, a.sin_t, ib, qb);
+    // once per workgroup: the bit-transposed block and the row-independent pass-1 twiddles
+    if (BITS) fwd_stage_bits(tid, (const uint8_t*)a.src + (size_t)srci * a.src_stride, a.cos_t, a.sin_t, ib, qb);
+    cf w[2][RA - 1];
+    load_tw1(tid, a.t1, w);
+    for (int kappa = 0; kappa < NPOLY; ++kappa) {
+        const cf* tn_row = a.tn + ((size_t)r * NPOLY + kappa) * M_SUB;
+        if (BITS) {
+            fwd_build_lut(tid, a.rot8 + (r * NPOLY + kappa) * NPOLY, lut);
+            __syncthreads();  // table (and, first time, the staged bits) ready; previous row's copy-out finished
+            fwd_phase1(tid, kappa, BitsSrc{reinterpret_cast<const uint8_t*>(ib), reinterpret_cast<const uint8_t*>(qb), lut}, tn_row, w, lds);
+        } else {
+            __syncthreads();
+            fwd_phase1(tid, kappa, RealSrc{(const float*)a.src + (size_t)srci * a.src_stride}, tn_row, w, lds);
+        }
         __syncthreads();
-        fwd_phase1(tid, kappa, BitsSrc{reinterpret_cast<const uint8_t*>(ib), reinterpret_cast<const uint8_t*>(qb), lut}, tn_row, a.t1, lds);
-    } else {
-        fwd_phase1(tid, kappa, RealSrc{(const float*)a.src + (size_t)srci * a.src_stride}, tn_row, a.t1, lds);
+        fwd_phase2(tid, a.t2, lds);
+        __syncthreads();
+        cf y[RC];
+        fwd_phase3_load(tid, lds, y);
+        __syncthreads();
+        fwd_phase3_store(tid, a.conj_out != 0, y, lds);
+        __syncthreads();
+        cf* dst = a.out + (size_t)item * a.item_stride + (size_t)kappa * a.row + a.off;
+        for (int i = tid; i < M_SUB / 2; i += WG) reinterpret_cast<cf2*>(dst)[i] = reinterpret_cast<const cf2*>(lds)[i];
     }
-    __syncthreads();
-    fwd_phase2(tid, a.t2, lds);
-    __syncthreads();
-    cf y[RC];
-    fwd_phase3_load(tid, lds, y);
-    __syncthreads();
-    fwd_phase3_store(tid, a.conj_out != 0, y, lds);
-    __syncthreads();
-    cf* dst = a.out + (size_t)item * a.item_stride + (size_t)kappa * a.row + a.off;
-    for (int i = tid; i < M_SUB / 2; i += WG) reinterpret_cast<cf2*>(dst)[i] = reinterpret_cast<const cf2*>(lds)[i];
 }
 
 // cyclic halo of the code rows: grid (8 * n_codes), any block size
@@ -301,10 +307,10 @@ __global__ void k_pack_keys(const Peak* peaks, unsigned long long* keys, int n, 
 // ---------------------------------------------------------------------------------------
 // launchers (host)
 void launch_fwd_bits(const FwdArgs& a, int n_items, hipStream_t s) {
-    hipLaunchKernelGGL(k_fwd<true>, dim3(NPOLY, n_items), dim3(WG), 0, s, a);
+    hipLaunchKernelGGL(k_fwd<true>, dim3(n_items), dim3(WG), 0, s, a);
 }
 void launch_fwd_real(const FwdArgs& a, int n_items, hipStream_t s) {
-    hipLaunchKernelGGL(k_fwd<false>, dim3(NPOLY, n_items), dim3(WG), 0, s, a);
+    hipLaunchKernelGGL(k_fwd<false>, dim3(n_items), dim3(WG), 0, s, a);
 }
 void launch_code_halo(cf* cpp, int n_rows, int crow, int halo, hipStream_t s) {
     hipLaunchKernelGGL(k_code_halo, dim3(n_rows), dim3(WG), 0, s, cpp, crow, halo);

@@ -214,8 +214,8 @@ ACQ_HD void peak_merge(float& mx, int& mi, float omx, int omi) {
 // Forward transform of Sample() (:141-161) and SearchInit() (:101-106), decimation in frequency:
 //   X[8 k' + kappa] = DFT_5000( z_kappa )[k'],
 //   z_kappa[n'] = W_N^{n' kappa} * sum_{nu<8} x[n' + 5000 nu] W_8^{nu kappa}
-// One workgroup per (block, kappa): row kappa of the polyphase spectrum layout comes out in natural
-// order and is written once, already conjugated -- no scratch round trip.  The eight samples of a
+// One workgroup per block walks the eight rows kappa (bits staged and pass-1 twiddles loaded once): row kappa of the
+// polyphase spectrum layout comes out in natural order and is written once, already conjugated -- no scratch round trip.  The eight samples of a
 // term sit in bytes (n' >> 3) + 625 nu at bit n' & 7 (5000 = 8 * 625).
 ACQ_HD float pm1(unsigned bit) {  // 0 -> +1.0f, 1 -> -1.0f   (Bipolar(), :68-70)
     union { unsigned u; float f; } v;
@@ -275,10 +275,9 @@ ACQ_HD void fwd_stage_bits(int tid, const uint8_t* __restrict__ bytes, const uin
 
 template <class Src>
 // tn_row: the 5000 decimation-in-frequency twiddles of this row, W_N^{n' (kappa + eps)}
-ACQ_HD void fwd_phase1(int tid, int kappa, const Src& src, const cf* __restrict__ tn_row, const cf* __restrict__ t1, cf* lds) {
+// w: the thread's pass-1 twiddles (load_tw1), row-independent: loaded once per workgroup
+ACQ_HD void fwd_phase1(int tid, int kappa, const Src& src, const cf* __restrict__ tn_row, const cf (&w)[2][RA - 1], cf* lds) {
     if (tid >= NBF3) return;
-    cf w[2][RA - 1];
-    load_tw1(tid, t1, w);
     const cf c4 = w8(4 * kappa), c2 = w8(2 * kappa), c1 = w8(kappa);
     const cf* tk = tn_row + 2 * tid;
     cf x0[RA], x1[RA];

@@ -24,7 +24,11 @@ static void emul_fwd_row(const Src& src, int kappa, bool conj_out, cf* row /*[50
     std::vector<cf> lds(M_SUB);
     std::vector<cf> regs((size_t)WG * RC);
     if (!tn_row) tn_row = T.tn.data() + (size_t)kappa * M_SUB;
-    for (int tid = 0; tid < WG; ++tid) fwd_phase1(tid, kappa, src, tn_row, T.t1.data(), lds.data());
+    for (int tid = 0; tid < WG; ++tid) {
+        cf w[2][RA - 1];
+        load_tw1(tid, T.t1.data(), w);
+        fwd_phase1(tid, kappa, src, tn_row, w, lds.data());
+    }
     for (int tid = 0; tid < WG; ++tid) fwd_phase2(tid, T.t2.data(), lds.data());
     for (int tid = 0; tid < WG; ++tid) fwd_phase3_load(tid, lds.data(), &regs[(size_t)tid * RC]);
     for (int tid = 0; tid < WG; ++tid) fwd_phase3_store(tid, conj_out, &regs[(size_t)tid * RC], lds.data());
