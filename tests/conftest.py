@@ -61,8 +61,8 @@ def hip_artifacts():
     return HIP_ARTIFACTS
 
 
-def pytest_collection_modifyitems(config, items):
-    # gpu-marked tests always need the HIP artefacts
-    for item in items:
-        if item.get_closest_marker("gpu") and "hip_artifacts" not in item.fixturenames:
-            item.fixturenames.append("hip_artifacts")
+@pytest.fixture(autouse=True)
+def _hip_artifacts_for_gpu_tests(request):
+    """gpu-marked tests always need the HIP artefacts (built on first use; on the GPU box they arrive prebuilt)"""
+    if request.node.get_closest_marker("gpu"):
+        request.getfixturevalue("hip_artifacts")
