@@ -1,3 +1,7 @@
+#!/usr/bin/env python3
+"""Power-limit check (needs an MI355X): the correlate kernel on random capture bits against all-zero bits -- the same
+instruction stream on data that toggles far fewer multiplier inputs.  A faster zero run means the chip clock is set by
+power, not by the kernel.  Run from the repo root."""
 import os, sys
 sys.path.insert(0, "gnss-gps-sdr_amd/python")
 import torch, gpsacq
