@@ -41,7 +41,7 @@ for name, what in (("bench_traced.log", "traced"), ("bench_unprofiled.log", "un-
                      "roofline": {k: r.get(k) for k in ("bound", "kernel", "achieved", "peak", "unit", "frac", "kernel_ms", "cells_per_launch", "flops_per_cell")}}), ""]
 pp = os.path.join(src, "phase_profile.log")
 if os.path.exists(pp):
-    ph = [l.strip() for l in open(pp) if "k_corr profile" in l]
+    ph = [l.strip() for l in open(pp) if "k_corr profile" in l and not l.strip().endswith("total 0")]  # (only the 22-column instance carries the profiler)
     if ph:
         lines += ["## s_memtime phase profile (`GPSACQ_PROF=1`, k_corr<22,...,PROF>; cycles per cell per wave, summed over the launch / cells)", ""] + ["    " + l for l in ph[-2:]] + [""]
 
