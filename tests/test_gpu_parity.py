@@ -155,6 +155,8 @@ def test_gps_sig_tmp_known_answers(gpsacq_mod, golden_dir):
     with gpsacq_mod.Engine(2.046e6, 8.184e6, 5000.0, ref_quirks=True) as eng:
         _, peaks = eng.search(buf, want_cells=False)
     sv7 = peaks[7::32]
+    # derived from gps_sig_gen.m alone (tests/test_oracle.py::test_code_phase_follows_from_gps_sig_gen): all 12 runs
+    assert list(sv7["ca_shift"]) == [(40960 * (32 * r + 7) - 20) % 8184 for r in range(12)]
     assert list(sv7["lo_shift"]) == known["sv7_lo_shift"]
     assert list(sv7["ca_shift"]) == known["sv7_ca_shift"]
     assert ["%.1f" % s for s in sv7["snr"]] == ["%.1f" % s for s in known["sv7_snr"]]

@@ -93,6 +93,24 @@ def test_reference_known_answers_gps_sig_tmp(golden_dir):
     assert int(np.argmax(peaks["snr"][:32])) == 7 and int(peaks["lo_shift"][7]) == 0
 
 
+def test_code_phase_follows_from_gps_sig_gen(golden_dir):
+    """A known answer that needs no reference run: README.md:57 ("C/A codes results are aligned with GPS signal we
+    generate") made exact.  gps_sig_gen.m starts chip 0 of PRN 8 at sample 0 of its impulse train and shapes it with
+    rcosine(1, 8) (delay 3 chips = 24 samples, :22,35): chip k peaks at sample 24 + 8 k, i.e. its leading edge -- what the
+    search's zero-order-hold replica aligns to -- is at 20 + 8 k.  SearchTask gives PRN index 7 the blocks 32 r + 7, which
+    start at sample 40960 (32 r + 7) (10 x 512 bytes per Sample() call, :129,135-136), so with 8184 samples per code
+    period Correlate must report ca_shift = (40960 (32 r + 7) - 20) mod 8184 and Doppler bin 0 (+-1: the 204.6 Hz bins
+    straddle zero).  That is 260, 1540, 2820, ... -- the sequence the survey's reference run printed."""
+    expect = [(40960 * (32 * r + 7) - 20) % 8184 for r in range(12)]
+    assert expect[:4] == [260, 1540, 2820, 4100]
+    buf = open(os.path.join(golden_dir, "gps_sig_tmp.bin"), "rb").read()
+    orc = Oracle(2.046e6, 8.184e6, 5000.0)
+    for r in (0, 5, 11):
+        b = 32 * r + 7
+        _, pk = orc.search_block(buf[b * 5120:(b + 1) * 5120], 7)
+        assert int(pk["ca_shift"]) == expect[r] and abs(int(pk["lo_shift"])) <= 1 and pk["snr"] > 500
+
+
 def test_quirk_only_touches_prn_index_0(golden_dir):
     buf = open(os.path.join(golden_dir, "gps_sig_tmp.bin"), "rb").read()[:32 * 5120]
     a = Oracle(2.046e6, 8.184e6, 5000.0, ref_quirks=True)
