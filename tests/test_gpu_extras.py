@@ -140,9 +140,10 @@ def test_config4_weak_signal_rtl_path(golden_dir):
 
 
 @pytest.mark.parametrize("fc,fs,max_fo", [(2.6e6, 10e6, 5000.0), (1.023e6, 4.092e6, 3000.0), (3.5e6, 9.9987e6, 5000.0),
-                                          (0.0, 1.1e6, 1000.0), (4.092e6, 16.368e6, 4000.0), (9.5e6, 38.192e6, 2000.0)])
+                                          (0.0, 1.1e6, 1000.0), (4.092e6, 16.368e6, 4000.0), (9.5e6, 38.192e6, 2000.0),
+                                          (1.7e6, 6.8e6, 5000.0)])
 def test_other_sampling_rates(fc, fs, max_fo):
-    """Every kernel instance (12/22/33/40 accumulator columns), lag counts that are not multiples of
+    """Every kernel instance (12/22/28/33/40 accumulator columns), lag counts that are not multiples of
     250 or of 8, a zero IF, and more than 10000 lags (fs > 10 MHz: 2 and 4 passes of 40 columns plus
     the merge kernel): cells against the oracle on a seeded noise + signal capture."""
     import gpsacq
@@ -340,3 +341,35 @@ def test_noncoherent_wide_instances(golden_dir, fc, fs, cols):
             np.testing.assert_allclose(cells["tot_pwr"][t], want["tot_pwr"], rtol=2e-5)
             assert (cells["max_i"][t] != want["max_i"]).sum() <= 1
         assert peaks["snr"][0] > 2 * peaks["snr"][2] and peaks["snr"][1] > 2 * peaks["snr"][2]
+
+
+@pytest.mark.parametrize("seed", [1, 2, 3, 4, 5, 6])
+def test_random_grid_configurations(seed):
+    """Seeded random (IF, sampling rate, Doppler range, Doppler step) combinations on random capture bits: ten random grid
+    points of two random (block, PRN) tasks against the oracle's restatement of the grid (Oracle.search_grid), and the peak
+    against the scan over all the engine's own cells."""
+    import gpsacq
+    from oracle_lib import Oracle
+    rng = np.random.default_rng(1000 + seed)
+    fs = float(rng.uniform(2.0e6, 10.0e6))
+    fc = float(rng.uniform(0.0, 0.45 * fs))
+    max_fo = float(rng.uniform(500.0, 20000.0))
+    bin_hz = fs / 40000.0
+    step = [0.0, bin_hz / 2, bin_hz / 3, 2.5 * bin_hz, bin_hz / 5, 4.2 * bin_hz][seed - 1]
+    bits = rng.integers(0, 256, size=3 * 5120, dtype=np.uint8).tobytes()
+    orc = Oracle(fc, fs, max_fo)
+    with gpsacq.Engine(fc, fs, max_fo) as eng:
+        eng.set_doppler_step(step)
+        sub, stride, kmax = eng.doppler_sub, eng.doppler_stride, eng.kmax
+        assert eng.num_doppler == 2 * kmax + 1 and kmax == int(max_fo / eng.doppler_step_hz)
+        tasks = [(int(rng.integers(0, 3)), int(rng.integers(0, 32))) for _ in range(2)]
+        cells, peaks = eng.search(bits, tasks=tasks)
+        for t, (b, sv) in enumerate(tasks):
+            pts = sorted(set([-kmax, kmax, 0] + [int(v) for v in rng.integers(-kmax, kmax + 1, 7)]))
+            oc, ks = orc.search_grid(bits[b * 5120:(b + 1) * 5120], sv, sub=sub, dstride=stride, points=pts)
+            got = cells[t][np.array(ks) + kmax]
+            np.testing.assert_allclose(got["max_pwr"], oc["max_pwr"], rtol=2e-5)
+            np.testing.assert_allclose(got["tot_pwr"], oc["tot_pwr"], rtol=2e-5)
+            assert np.array_equal(got["max_i"], oc["max_i"])
+            k = int(np.argmax(cells[t]["snr"]))  # first maximum == strict '>' scan over ascending frequency
+            assert peaks["lo_shift"][t] == k - kmax and peaks["ca_shift"][t] == cells[t]["max_i"][k]
