@@ -24,7 +24,7 @@ Fixtures:
                              7 blocks laid out every 5456 bytes (8 whole C/A periods), PRN 12 weak, PRN 3 stronger.
   synth_weak_rtl_fs2800.bin  BASELINE configs[3] shape: fs 2.8 MHz, IF 0.62 MHz, 6 blocks every 5250 bytes (15 C/A
                              periods), PRN 9 weak at +40 kHz (receiver LO offset, bin 571 of +-1428).
-  np64_cells_*.npz           per-cell {max_pwr, max_i, tot_pwr} from an INDEPENDENT float64
+  np64_cells_*.npz           per-cell {max_pwr, max_i, tot_pwr, second_pwr, second_i} from an INDEPENDENT float64
                              numpy restatement (np.fft / pocketfft) of
                              c/search_offline.cpp:121-201 for a few (block, sv) pairs.
 """
@@ -119,6 +119,8 @@ def np64_cells(fc, fs, max_fo, blocks, pairs, quirks=False):
         mp = np.empty(2 * dmax + 1, np.float64)
         mi = np.empty(2 * dmax + 1, np.int64)
         tp = np.empty(2 * dmax + 1, np.float64)
+        p2 = np.empty(2 * dmax + 1, np.float64)  # the runner-up lag and its power: what a rounding tie of the argmax
+        i2 = np.empty(2 * dmax + 1, np.int64)    # is proven against (tests/test_gpu_parity.py::test_cells_vs_numpy_golden)
         for d in range(-dmax, dmax + 1):
             prod = (np.conj(D) * np.roll(C, d)).astype(np.complex64).astype(np.complex128)
             y = np.fft.ifft(prod) * N
@@ -126,7 +128,11 @@ def np64_cells(fc, fs, max_fo, blocks, pairs, quirks=False):
             mp[d + dmax] = pwr.max()
             mi[d + dmax] = int(pwr.argmax())
             tp[d + dmax] = pwr.sum()
-        res[(b, sv)] = (mp, mi, tp)
+            rest = pwr.copy()
+            rest[mi[d + dmax]] = -1.0
+            i2[d + dmax] = int(rest.argmax())
+            p2[d + dmax] = rest.max()
+        res[(b, sv)] = (mp, mi, tp, p2, i2)
     return dmax, S, res
 
 
@@ -237,10 +243,12 @@ def main():
         dmax, S, res = np64_cells(fc, fs, mfo, blks, pairs, quirks)
         out = {"fc": fc, "fs": fs, "max_fo": mfo, "dmax": dmax, "S": S, "quirks": int(quirks),
                "pairs": np.array(pairs, dtype=np.int64)}
-        for (b, sv), (mp, mi, tp) in res.items():
+        for (b, sv), (mp, mi, tp, p2, i2) in res.items():
             out[f"max_pwr_{b}_{sv}"] = mp
             out[f"max_i_{b}_{sv}"] = mi
             out[f"tot_pwr_{b}_{sv}"] = tp
+            out[f"second_pwr_{b}_{sv}"] = p2
+            out[f"second_i_{b}_{sv}"] = i2
         np.savez_compressed(os.path.join(HERE, name), **out)
         print(name, "dmax", dmax, "S", S, "pairs", len(pairs))
 

@@ -30,7 +30,7 @@ def test_capture_mode_on_the_bundled_file(golden_dir):
     assert 8 in best and best[8]["lo_shift"] == 0 and best[8]["snr"] > 500
 
 
-def test_config4_line():
+def test_configs4_line():
     j = _bench("--config", "4", "--doppler-step", "50", "--grid-blocks", "1")
     assert "4399 Doppler points" in j["config"]["workload"] and j["config"]["cells_per_step_job"] == 32 * 4399
     assert j["value"] > 0 and j["roofline"]["kernel"] == "k_corr<22>"

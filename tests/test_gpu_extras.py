@@ -117,7 +117,7 @@ def test_forward_chunking_beyond_8192_blocks():
         assert np.array_equal(cells[nblk - 8180:], c3)
 
 
-def test_config4_weak_signal_rtl_path(golden_dir):
+def test_configs3_weak_signal_rtl_path(golden_dir):
     """BASELINE configs[3] ("weak-signal ... +-100 kHz ... rtl_sdr 2.8 Msps path") as built here:
     fs 2.8 MHz, IF 0.62 MHz, max_fo 100 kHz honoured (2857 bins of 70 Hz, N = 40000 = 14.3 ms
     coherent), 5 non-coherent sums over blocks 15 C/A periods apart."""

@@ -107,7 +107,7 @@ def _keys(gdist, torch, peaks, kmax):
 
 
 @pytest.mark.parametrize("step", [0.0, 50.0])
-def test_config4_grid_sharded_over_8_ranks(gpsacq_mod, golden_dir, step):
+def test_configs4_grid_sharded_over_8_ranks(gpsacq_mod, golden_dir, step):
     """BASELINE configs[4] on its exact grid: fs 5.456 MHz, +-100 kHz, 32 PRN -- 1467 bins of fs/N (step 0), or the
     50 Hz the config names (3 sub-bin spectra, 45.5 Hz, 4399 points).  The Doppler slabs of 8 emulated ranks, merged
     with the all-reduce's integer MAX over the packed keys, must equal the unsharded search bit for bit, and a

@@ -111,6 +111,17 @@ def test_code_phase_follows_from_gps_sig_gen(golden_dir):
         assert int(pk["ca_shift"]) == expect[r] and abs(int(pk["lo_shift"])) <= 1 and pk["snr"] > 500
 
 
+def test_every_block_of_gps_sig_tmp_has_prn8_where_gps_sig_gen_puts_it(golden_dir):
+    """The same derivation at EVERY block b of the file, searched for PRN 8 (384 integer pins instead of 12):
+    ca_shift = (40960 b - 20) mod 8184, Doppler bin 0 +- 1.  (The GPU counterpart is in tests/test_gpu_parity.py.)"""
+    buf = open(os.path.join(golden_dir, "gps_sig_tmp.bin"), "rb").read()
+    orc = Oracle(2.046e6, 8.184e6, 5000.0, kind="f32")
+    for b in range(384):
+        _, pk = orc.search_block(buf[b * 5120:(b + 1) * 5120], 7)
+        assert int(pk["ca_shift"]) == (40960 * b - 20) % 8184, b
+        assert abs(int(pk["lo_shift"])) <= 1 and pk["snr"] > 300, (b, pk)
+
+
 def test_quirk_only_touches_prn_index_0(golden_dir):
     buf = open(os.path.join(golden_dir, "gps_sig_tmp.bin"), "rb").read()[:32 * 5120]
     a = Oracle(2.046e6, 8.184e6, 5000.0, ref_quirks=True)
