@@ -21,8 +21,14 @@ Other configurations (the default line stays the one the driver records):
   --config 2   BASELINE configs[2]: fs 8.184 MHz / IF 2.046 MHz (gps_sig_gen.m's rates), 49 bins, 8184 lags
   --config 3   BASELINE configs[3]: rtl-sdr path, fs 2.8 MHz, +-100 kHz, 5 non-coherent sums
   --config 4   BASELINE configs[4]: one capture x 32 PRN x +-100 kHz fine grid, Doppler slabs over the ranks
+  --input iq8  the capture is an 8-bit IQ stream (rtl-sdr uint8, README.md:83-115) resident in HBM and searched directly:
+               mean removal, mixer, sign and bit transpose are fused into the forward transform (no 1-bit intermediate);
+               the line gains "ingest" = bytes moved by that stage / its time, against the 6.29 TB/s copy ceiling
   --capture F  search the 1-bit capture file F (e.g. gps.samples.1bit.I.fs5456.if4092.bin) instead of
                synthetic data: whole runs of the file, same schedule, and the SearchTask report's hit list
+
+`--gpus N` with N > 1 and no WORLD_SIZE in the environment re-launches itself under torch.distributed.run with N ranks
+(so a plain `python bench.py --gpus 8` cannot silently measure one GPU); fewer than N visible devices is an error.
 """
 import argparse
 import json
@@ -42,6 +48,10 @@ FP32_VALU_PEAK_TF = 157.3        # MI355X_MICROARCH.md: peak FP32 vector (= FP32
 HBM_PEAK_GBS = 8000.0            # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec (6.29 TB/s measured copy)
 L2_PEAK_GBS = 34500.0            # MI355X_MICROARCH.md: aggregate L2 bandwidth
 ALG_BYTES_PER_CELL = 32 * N_FFT  # read signal + code spectra, write + read one IFFT intermediate
+
+# PRN -> G2 tap pair (c/search_offline.cpp:20-53), for the synthetic IQ capture of --input iq8
+PRN_TAPS = [(2, 6), (3, 7), (4, 8), (5, 9), (1, 9), (2, 10), (1, 8), (2, 9), (3, 10), (2, 3), (3, 4), (5, 6), (6, 7), (7, 8), (8, 9), (9, 10),
+            (1, 4), (2, 5), (3, 6), (4, 7), (5, 8), (6, 9), (1, 3), (4, 6), (5, 7), (6, 8), (7, 9), (8, 10), (1, 6), (2, 7), (3, 8), (4, 9)]
 
 CONFIGS = {
     1: dict(fc=4.092e6, fs=5.456e6, max_fo=5000.0, name="BASELINE configs[1]"),
@@ -131,45 +141,80 @@ def cpu_baseline_reference(cfg, bits, ndop, target_s=15.0):
                       f"same capture, {dt:.1f} s incl. process start, on {os.cpu_count()} core host ({cpu_model()}), 1 thread"}
 
 
-def cpu_baseline_all_cores(cfg, bits, ndop, target_s=8.0):
-    """Same port on every core the process may use: one oracle instance per thread (ctypes releases the GIL), each
-    searching chunks of 4 blocks of the same host sample until `target_s` seconds have passed (time-bounded: the cores a
-    container really gets can be far fewer than it is shown)."""
-    from concurrent.futures import ThreadPoolExecutor
-    from oracle_lib import Oracle
-    ncpu = os.cpu_count() or 1
+def kernel_source_sha():
+    """sha256 over the sources of the timed kernels: profiles/traffic.json carries the value of the tree it was profiled
+    on (tools/summarize_prof.py), so counters from another kernel binary are flagged instead of shipped silently."""
+    import hashlib
+    h = hashlib.sha256()
+    for name in ("acq_kernels.hip", "acq_phases.hpp", "acq_math.hpp", "acq_launch.hpp", "iq_convert.hpp"):
+        with open(os.path.join(ROOT, "gnss-gps-sdr_amd", "csrc", name), "rb") as f:
+            h.update(f.read())
+    return h.hexdigest()[:16]
+
+
+def cpu_baseline_all_cores(cfg, bits, ndop, one_thread_rate, target_s=8.0):
+    """The same port on every core the process may use: an OpenMP loop inside liboracle_f32.so (oracle_bench_omp: one
+    oracle instance per thread, SearchInit untimed, blocks dealt round-robin for `target_s` seconds)."""
+    import ctypes
+    from oracle_lib import lib
+    L = lib("f32")
+    L.oracle_bench_omp.restype = ctypes.c_long
+    L.oracle_bench_omp.argtypes = [ctypes.c_double] * 3 + [ctypes.c_void_p, ctypes.c_long, ctypes.c_long, ctypes.c_int, ctypes.c_double,
+                                                            ctypes.POINTER(ctypes.c_double), ctypes.POINTER(ctypes.c_int)]
     try:
         ncpu = len(os.sched_getaffinity(0))
     except (AttributeError, OSError):
-        pass
-    nblk = len(bits) // 5120
-    chunk = 4
+        ncpu = os.cpu_count() or 1
+    buf = np.ascontiguousarray(bits)
+    nblk = buf.size // 5120
+    el, used = ctypes.c_double(), ctypes.c_int()
+    cells = L.oracle_bench_omp(cfg["fc"], cfg["fs"], cfg["max_fo"], buf.ctypes.data, nblk, 5120, ncpu, target_s, ctypes.byref(el), ctypes.byref(used))
+    rate = cells / el.value
+    return {"value": rate, "unit": "cells/s", "cores": used.value, "kind": "port",
+            "sched_getaffinity_cores": ncpu, "os_cpu_count": os.cpu_count(),
+            "speedup_over_1_thread": rate / one_thread_rate if one_thread_rate else None,
+            "sample": f"OpenMP, {used.value} threads (sched_getaffinity: {ncpu} cores), blocks of the same {nblk}-block sample dealt "
+                      f"round-robin x {ndop} bins for {el.value:.1f} s = {cells} cells"}
 
-    def make(_):
-        return Oracle(cfg["fc"], cfg["fs"], cfg["max_fo"], kind="f32")
 
-    def work(i):
-        cells, start = 0, (i * 7) % max(1, nblk - chunk + 1)
-        while time.perf_counter() < deadline:
-            cells += orcs[i].bench_blocks(bits[start * 5120:(start + chunk) * 5120], chunk)[0]
-            start = (start + chunk) % max(1, nblk - chunk + 1)
-        return cells
-
-    with ThreadPoolExecutor(ncpu) as ex:
-        orcs = list(ex.map(make, range(ncpu)))  # SearchInit() of every instance, untimed
-        t0 = time.perf_counter()
-        deadline = t0 + target_s
-        cells = sum(ex.map(work, range(ncpu)))
-        dt = time.perf_counter() - t0
-    return {"value": cells / dt, "unit": "cells/s", "cores": ncpu, "kind": "port",
-            "sample": f"{ncpu} threads (all cores the process may use) x chunks of {chunk} blocks x {ndop} bins for {target_s:.0f} s = {cells} cells, {dt:.1f} s"}
+def e2e_cli(cfg, d_bits, n_runs, ndop, reps=3):
+    """The drop-in a user runs: wall clock of gnss-gps-sdr_amd/bin/gps_test on a capture FILE of the bench's size (written
+    from the resident synthetic capture), process start to exit, with the front end's own split (GPSACQ_TRACE)."""
+    import re
+    import subprocess
+    import tempfile
+    exe = os.path.join(ROOT, "gnss-gps-sdr_amd", "bin", "gps_test")
+    if not os.path.exists(exe):
+        return {"error": "gps_test not built"}
+    host = d_bits[:n_runs * 32 * 5120].cpu().numpy()
+    tmpdir = "/dev/shm" if os.path.isdir("/dev/shm") else None
+    with tempfile.NamedTemporaryFile(suffix=".bin", dir=tmpdir) as f:
+        host.tofile(f)
+        f.flush()
+        walls, traces, runs = [], [], 0
+        for _ in range(reps):
+            t0 = time.perf_counter()
+            r = subprocess.run([exe, f.name, repr(cfg["fc"]), repr(cfg["fs"]), "5000"], capture_output=True, text=True,
+                               env=dict(os.environ, GPSACQ_TRACE="1"))
+            walls.append(time.perf_counter() - t0)
+            if r.returncode != 0:
+                return {"error": f"gps_test exit {r.returncode}: {r.stderr[-300:]}"}
+            runs = r.stdout.count("satellite:")
+            traces.append([ln for ln in r.stderr.splitlines() if ln.startswith("gpsacq trace")][-1])
+    best = int(np.argmin(walls))
+    nums = {k: float(v) for k, v in re.findall(r"(SearchInit|SearchTask|mean pass|read|submit|wait for GPU|report) ([0-9.]+)", traces[best])}
+    cells = runs * 32 * ndop
+    return {"wall_s": walls[best], "wall_s_all": walls, "runs_reported": runs, "cells": cells, "cells_per_s": cells / walls[best],
+            "file_bytes": int(host.size), "split_ms": nums,
+            "note": "process start + HIP runtime/module load + SearchInit + pipelined SearchTask (fread k+1 || search k || printf k-1)"}
 
 
 class Leg:
     """One timed workload: `n_tasks` tasks over `nblk` resident blocks on this rank."""
 
-    def __init__(self, torch, gpsacq, gdist, eng, dev, dist, backend, nblk, n_tasks, d_bits, d_tasks, stride, grid, n_keys=32):
+    def __init__(self, torch, gpsacq, gdist, eng, dev, dist, backend, nblk, n_tasks, d_bits, d_tasks, stride, grid, n_keys=32, iq=None):
         self.torch, self.gdist, self.eng, self.dev, self.dist, self.backend = torch, gdist, eng, dev, dist, backend
+        self.iq = iq  # gpsacq.Iq8Input: d_bits then holds interleaved 8-bit I,Q bytes, `stride` bytes per block
         self.nblk, self.n_tasks, self.d_bits, self.d_tasks, self.stride, self.grid, self.n_keys = nblk, n_tasks, d_bits, d_tasks, stride, grid, n_keys
         # The search runs on the engine's own HIP stream; the key packing and the collective run on torch's
         # stream, ordered after it by an event, so step i's reduction / all-reduce overlaps step i+1's search
@@ -187,9 +232,12 @@ class Leg:
         if self.n_tasks > 0:
             if self.reader_done[slot] is not None:
                 self.eng_stream.wait_event(self.reader_done[slot])
-            eng.search_device(self.d_bits.data_ptr(), self.nblk, buf.data_ptr(), stride=self.stride,
-                              d_tasks_ptr=self.d_tasks.data_ptr() if self.d_tasks is not None else None,
-                              n_tasks=self.n_tasks, sync=False)
+            if self.iq is not None:
+                eng.search_iq8_device(self.d_bits.data_ptr(), self.iq, self.nblk, buf.data_ptr(), stride=self.stride, sync=False)
+            else:
+                eng.search_device(self.d_bits.data_ptr(), self.nblk, buf.data_ptr(), stride=self.stride,
+                                  d_tasks_ptr=self.d_tasks.data_ptr() if self.d_tasks is not None else None,
+                                  n_tasks=self.n_tasks, sync=False)
             searched = torch.cuda.Event()
             searched.record(self.eng_stream)
             torch.cuda.current_stream().wait_event(searched)
@@ -227,14 +275,18 @@ class Leg:
         for _ in range(warmup):
             best = self.step()
         self.fence()
-        corr_ms = []
+        corr_ms, self.sample_ms = [], []
         t0 = time.perf_counter()
         for i in range(steps):
             best = self.step()
             if i > 0 and self.n_tasks > 0:  # the previous search's times: waits for that search only
-                corr_ms.append(self.eng.last_timing(1)["ms_correlate"])
+                tm = self.eng.last_timing(1)
+                corr_ms.append(tm["ms_correlate"])
+                self.sample_ms.append(tm["ms_sample"])
         if self.n_tasks > 0:
-            corr_ms.append(self.eng.last_timing(0)["ms_correlate"])
+            tm = self.eng.last_timing(0)
+            corr_ms.append(tm["ms_correlate"])
+            self.sample_ms.append(tm["ms_sample"])
         self.fence()
         elapsed = time.perf_counter() - t0
         t = torch.tensor([elapsed], dtype=torch.float64, device=self.dev if self.backend == "nccl" else "cpu")
@@ -257,26 +309,59 @@ def main():
                     help="--config 3/4: requested Doppler step in Hz (0: the FFT bin fs/N); the engine takes the finest grid "
                          "it has that is not coarser (sub-bin phase ramps) or the coarsest not finer (bin stride)")
     ap.add_argument("--capture", default=None, help="1-bit capture file to search instead of synthetic data (config 1/2 schedules)")
+    ap.add_argument("--input", choices=["bits", "iq8"], default="bits",
+                    help="iq8: an 8-bit IQ capture (uint8, offset 128) converted inside the forward transform (configs 1-3 schedules)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-e2e", action="store_true", help="skip the gps_test end-to-end leg")
+    ap.add_argument("--spawn-check", action="store_true",
+                    help="launcher check without a GPU: every rank joins a gloo group, rank 0 prints the ranks it saw, all exit")
     ap.add_argument("--data", choices=["signals", "noise"], default="signals",
                     help="signals (default): capture generated on the device, white noise + 8 PRNs at seeded Doppler / code "
                          "phase (SURVEY section 8d throughput set); noise: uniform random bits")
     args = ap.parse_args()
 
+    backend = os.environ.get("GPSACQ_DIST_BACKEND", "nccl")
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        # launched plainly: become N ranks (never report n_gpus = 1 for --gpus N)
+        import socket
+        import subprocess
+        import torch
+        ndev = torch.cuda.device_count()
+        if backend == "nccl" and ndev < args.gpus:
+            print(f"bench.py: --gpus {args.gpus} but {ndev} device(s) visible", file=sys.stderr)
+            raise SystemExit(2)
+        with socket.socket() as sk:
+            sk.bind(("127.0.0.1", 0))
+            port = sk.getsockname()[1]
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}", "--master-addr", "127.0.0.1",
+               "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+        raise SystemExit(subprocess.call(cmd))
+
     import torch
-    import gpsacq
-    from gpsacq import dist as gdist
 
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
-    if world != args.gpus and world > 1:
+    if world != args.gpus:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
+    if args.spawn_check:
+        import torch.distributed as dist
+        seen = 1
+        if world > 1:
+            dist.init_process_group(backend="gloo")
+            t = torch.ones(1, dtype=torch.int64)
+            dist.all_reduce(t)
+            seen = int(t.item())
+            dist.destroy_process_group()
+        if rank == 0:
+            print(json.dumps({"spawn_check": True, "n_gpus": args.gpus, "rccl_ranks_seen": seen, "world_size_env": world}), flush=True)
+        return
+    import gpsacq
+    from gpsacq import dist as gdist
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU (no CPU fallback)")
     # GPSACQ_DIST_BACKEND=gloo lets several ranks share one GPU to exercise the N > 1 code path on a 1-GPU box
     # (collectives then run on CPU copies); the driver's runs use nccl (= RCCL).
-    backend = os.environ.get("GPSACQ_DIST_BACKEND", "nccl")
     dev_index = local_rank % torch.cuda.device_count() if backend == "gloo" else local_rank
     torch.cuda.set_device(dev_index)
     dist = None
@@ -287,8 +372,15 @@ def main():
         else:
             dist.init_process_group(backend=backend)
 
+    ranks_seen = dist.get_world_size() if dist is not None else 1
+    if ranks_seen != args.gpus:
+        raise SystemExit(f"--gpus {args.gpus} but the process group has {ranks_seen} rank(s)")
+
     cfg = CONFIGS[args.config]
-    grid = args.config in (3, 4)
+    iq8 = args.input == "iq8"
+    grid = args.config in (3, 4) and not iq8  # an IQ capture is searched block by block (reference schedule) at the config's rates
+    if iq8 and args.capture:
+        raise SystemExit("--input iq8 works on the synthetic capture")
     eng = gpsacq.Engine(cfg["fc"], cfg["fs"], cfg["max_fo"], device=dev_index)
     dev = torch.device("cuda", dev_index)
     fs = cfg["fs"]
@@ -332,7 +424,7 @@ def main():
         d_tasks, n_tasks = None, nblk
         cells_rank = nblk * eng.num_doppler
         cells_job = total_runs * 32 * eng.num_doppler
-        workload = (f"{cfg['name']}: 32 PRN x {eng.num_doppler} Doppler bins (+-5 kHz, fs/N = {fs / N_FFT:.1f} Hz), N=40000, "
+        workload = (f"{cfg['name']}: 32 PRN x {eng.num_doppler} Doppler bins (+-{cfg['max_fo'] / 1e3:.0f} kHz, fs/N = {fs / N_FFT:.1f} Hz), N=40000, "
                     f"{eng.num_lags} lags, reference schedule block->PRN (block % 32); capture of {total_runs * 32} blocks "
                     f"({total_runs} runs)" + (f" = file {os.path.basename(args.capture)}" if args.capture else ""))
         parallelism = f"whole runs split over {world} GPU(s) (strong scaling), per-PRN peak all-reduce(MAX) of 256 bytes"
@@ -340,6 +432,45 @@ def main():
 
     # input resident in HBM before anything is timed
     injected, sats = synth_sats(data_seed, fs)
+
+    def make_iq_capture(n_blocks, seed):
+        """rtl-sdr style capture on the device (torch): uint8 offset-128 interleaved I,Q at BASEBAND -- complex noise of
+        sigma 30 + the seeded PRNs at their Doppler + a DC offset; the engine mixes it up to the config's IF
+        (proc_rtl_bin_for_gps.m:31-47) inside the forward transform.  Returns (bytes, (mean_i, mean_q))."""
+        g = torch.Generator(device=dev)
+        g.manual_seed(seed)
+        out = torch.empty(n_blocks * 81920, dtype=torch.uint8, device=dev)
+        chunk = 64
+        tables = list(synth_sats(seed, fs)[1])
+        chip_tab = {}
+        for prn, *_ in tables:  # the 1023 chips of each PRN (G1 = x^10+x^3+1, G2 = x^10+x^9+x^8+x^6+x^3+x^2+1, c/cacode.h:9-35)
+            g1, g2 = [1] * 10, [1] * 10
+            t1, t2 = PRN_TAPS[prn - 1]
+            c = []
+            for _ in range(1023):
+                c.append(g1[9] ^ g2[t1 - 1] ^ g2[t2 - 1])
+                f1 = g1[2] ^ g1[9]
+                f2 = g2[1] ^ g2[2] ^ g2[5] ^ g2[7] ^ g2[8] ^ g2[9]
+                g1 = [f1] + g1[:9]
+                g2 = [f2] + g2[:9]
+            chip_tab[prn] = torch.tensor([1.0 - 2.0 * v for v in c], dtype=torch.float64, device=dev)
+        for b0 in range(0, n_blocks, chunk):
+            nb = min(chunk, n_blocks - b0)
+            m = torch.arange(b0 * 40960, (b0 + nb) * 40960, dtype=torch.float64, device=dev)
+            zr = torch.randn(m.numel(), generator=g, device=dev, dtype=torch.float32).double() / math.sqrt(2)
+            zi = torch.randn(m.numel(), generator=g, device=dev, dtype=torch.float32).double() / math.sqrt(2)
+            for prn, amp, dop, ca, ph in tables:
+                idx = torch.floor((m + ca) * (1.023e6 * (1 + dop / 1575.42e6) / fs)).long() % 1023
+                th = 2 * math.pi * ((dop / fs * m + ph) % 1.0)
+                a = amp * chip_tab[prn][idx]  # rails of sigma 1/sqrt 2 and envelope amp/sqrt 2: amp over a unit-sigma real IF after the mixer
+                zr += a * torch.cos(th) / math.sqrt(2)
+                zi += a * torch.sin(th) / math.sqrt(2)
+            seg = out[b0 * 81920:(b0 + nb) * 81920].view(-1, 2)
+            seg[:, 0] = torch.clamp(torch.round(30.0 * zr + 3.7) + 128, 0, 255).to(torch.uint8)
+            seg[:, 1] = torch.clamp(torch.round(30.0 * zi + 1.2) + 128, 0, 255).to(torch.uint8)
+        sums = out.view(-1, 2).sum(dim=0, dtype=torch.int64).cpu()
+        n = out.numel() // 2
+        return out, (float(sums[0]) / n - 128.0, float(sums[1]) / n - 128.0)
 
     def make_capture(n_blocks, seed, blk_stride):
         if n_blocks == 0:
@@ -351,7 +482,12 @@ def main():
             return d
         return torch.from_numpy(np.random.default_rng(seed).integers(0, 256, size=nbytes, dtype=np.uint8)).to(dev)
 
-    if args.capture and not grid:
+    iq_in = None
+    if iq8:
+        stride = 81920
+        d_bits, iq_mean = make_iq_capture(max(nblk, 1), data_seed)
+        iq_in = eng.iq8_input(signed=False, remove_dc=True, mean=iq_mean, mix_hz=cfg["fc"], fs=fs, first_sample=0, total_samples=max(nblk, 1) * 40960)
+    elif args.capture and not grid:
         with open(args.capture, "rb") as f:
             f.seek(first_run * 32 * 5120)
             host = np.frombuffer(f.read(nblk * 5120), dtype=np.uint8)
@@ -359,12 +495,22 @@ def main():
     else:
         d_bits = make_capture(nblk, data_seed, stride)
 
+    # every rank's share of the work, gathered before anything is timed (what SCALE lines are checked against)
+    blocks_per_rank = [nblk]
+    if dist is not None:
+        t = torch.zeros(world, dtype=torch.int64, device=dev if backend == "nccl" else "cpu")
+        t[rank] = n_tasks if grid else nblk
+        dist.all_reduce(t, op=dist.ReduceOp.SUM)
+        blocks_per_rank = [int(v) for v in t.tolist()]
+
     leg = Leg(torch, gpsacq, gdist, eng, dev, dist, backend, nblk, n_tasks, d_bits, d_tasks, stride, grid,
-              n_keys=(tasks.shape[0] if grid else 32))
+              n_keys=(tasks.shape[0] if grid else 32), iq=iq_in)
     elapsed, kern_ms, best = leg.run(args.steps, args.warmup)
     timing = eng.last_timing() if n_tasks > 0 else None
 
     weak = None
+    if iq8:
+        weak_blocks = 0
     if weak_blocks > 0:
         wleg = Leg(torch, gpsacq, gdist, eng, dev, dist, backend, weak_blocks, weak_blocks, make_capture(weak_blocks, 2000 + rank, 5120),
                    None, 5120, False)
@@ -378,15 +524,20 @@ def main():
         value = cells_job * args.steps / elapsed
         fl = flops_per_cell(eng.num_lags)
         achieved_tf = cells_rank * fl / (kern_ms * 1e-3) / 1e12 if kern_ms else 0.0
-        traffic, traffic_src, onchip = None, None, None
+        traffic, traffic_src, onchip, traffic_sha = None, None, None, None
         try:  # HBM bytes per launch and pipe utilisation from the committed PMC passes (profiles/traffic.json)
             tj = json.load(open(os.path.join(ROOT, "profiles", "traffic.json")))
             traffic = (tj["hbm_read_bytes_per_cell"] + tj["hbm_write_bytes_per_cell"]) * cells_rank
             traffic_src = (f"profiles/{tj['tag']}_summary.md (rocprofv3 --pmc FETCH_SIZE, WRITE_SIZE in separate passes; "
                            "bytes per cell x cells per launch)")
             onchip = tj.get("onchip_counters")
+            traffic_sha = tj.get("kernel_source_sha")
         except Exception:
             pass
+        sha_now = kernel_source_sha()
+        # counters belong to the kernel binary they were collected on: flagged when the sources changed since (or the
+        # profile predates the hash), or when this run's kernel instance is not the profiled one
+        traffic_stale = (traffic is not None) and (traffic_sha != sha_now or args.config not in (1, 4) or iq8)
         alg_gbs = cells_rank * ALG_BYTES_PER_CELL / (kern_ms * 1e-3) / 1e9 if kern_ms else 0.0
         out = {
             "metric": "(PRN,Doppler) correlation cells/s, 32 PRN @ fs=5.456 MHz" if args.config in (1, 4) else
@@ -406,7 +557,10 @@ def main():
                             ("device-generated 1-bit real-IF capture: white noise + PRNs %s at 45 dB-Hz, seeded Doppler/code phase" % injected)
                             if args.data == "signals" else "uniform random bits (sign of white noise)"),
             "config": {"workload": workload, "fs_hz": fs, "if_hz": cfg["fc"], "blocks_rank0": nblk,
-                       "cells_per_step_rank0": cells_rank, "cells_per_step_job": cells_job, "parallelism": parallelism},
+                       "cells_per_step_rank0": cells_rank, "cells_per_step_job": cells_job, "parallelism": parallelism,
+                       "input": "8-bit IQ (uint8 offset 128), converted inside the forward transform" if iq8 else "1-bit real IF"},
+            "rccl_ranks_seen": ranks_seen, "dist_backend": (backend if world > 1 else None),
+            ("tasks_per_rank" if grid else "blocks_per_rank"): blocks_per_rank,
             # What binds k_corr is the fp32 vector pipe, not HBM: the fused kernel keeps the IFFT intermediate in LDS
             # and reads both spectra from L2, so the algorithmic bytes of SURVEY 8(d) never reach HBM.
             "roofline": {"bound": "valu_fp32", "kernel": f"k_corr<{eng.acc_columns}>", "achieved": achieved_tf,
@@ -414,7 +568,8 @@ def main():
                          "flops_per_cell": fl, "flops_definition": "SURVEY.md 8(d): 6N + 5N log2 N + 5S",
                          "kernel_ms": kern_ms, "cells_per_launch": cells_rank,
                          "kernel_cells_per_s": cells_rank / (kern_ms * 1e-3) if kern_ms else None,
-                         "traffic": traffic, "traffic_source": traffic_src,
+                         "traffic": traffic, "traffic_source": traffic_src, "traffic_stale": traffic_stale,
+                         "kernel_source_sha": sha_now, "traffic_kernel_source_sha": traffic_sha,
                          "hbm_secondary": {"algorithmic_bytes_per_cell": ALG_BYTES_PER_CELL, "algorithmic_GBs": alg_gbs,
                                            "hbm_peak_GBs": HBM_PEAK_GBS, "algorithmic_over_hbm_peak": alg_gbs / HBM_PEAK_GBS,
                                            "measured_hbm_GBs": (traffic / (kern_ms * 1e-3) / 1e9) if (traffic and kern_ms) else None,
@@ -426,6 +581,14 @@ def main():
         }
         if weak is not None:
             out["weak_scaling"] = weak
+        if iq8 and leg.sample_ms:
+            ms = float(np.mean(leg.sample_ms))
+            b_in, b_out = nblk * 80000, nblk * eng.doppler_sub * 8 * 5000 * 8
+            out["ingest"] = {"kernel": "k_fwd<iq8>", "ms": ms, "bytes_read": b_in, "bytes_written": b_out,
+                             "GBs": (b_in + b_out) / (ms * 1e-3) / 1e9, "copy_ceiling_GBs": 6290.0,
+                             "frac_of_copy_ceiling": (b_in + b_out) / (ms * 1e-3) / 1e9 / 6290.0,
+                             "note": "8-bit IQ read (80 000 B per block) + polyphase spectrum written (320 KB per block) over the "
+                                     "stage's HIP-event time; the stage also does 40 000 double-precision sincos per block (the mixer)"}
         if not grid:
             snr, lo, ca = gdist.unpack_keys(best.cpu(), eng.kmax)
             hits = torch.nonzero(snr >= 25).flatten().tolist()
@@ -437,18 +600,23 @@ def main():
                 out["injected_prns_all_ranks"] = sorted(set().union(*[synth_sats(1000 + r, fs)[0] for r in range(world)]))
         if world == 1 and not args.no_cpu_baseline:
             out["roofline"]["hbm_secondary"]["hbm_copy_measured_GBs"] = hbm_copy_gbs(torch, dev)
-            host_bits = d_bits[:min(nblk, 1024) * 5120 if not grid else d_bits.numel()].cpu().numpy()
+            host_bits = d_bits[:min(nblk, 1024) * 5120 if not grid else d_bits.numel()].cpu().numpy() if not iq8 else None
             ndop = eng.num_doppler_total if grid else eng.num_doppler
-            if args.config in (1, 2):
+            if args.config in (1, 2) and not iq8:
                 port = cpu_baseline(cfg, host_bits, ndop)
                 ref = cpu_baseline_reference(cfg, host_bits, ndop)
                 out["cpu_baseline"] = ref or port
                 if ref:
                     out["cpu_baseline_port"] = port
                 try:
-                    out["cpu_baseline_all_cores"] = cpu_baseline_all_cores(cfg, host_bits, ndop)
+                    out["cpu_baseline_all_cores"] = cpu_baseline_all_cores(cfg, host_bits, ndop, port["value"])
                 except Exception as ex:  # the 1-thread figure is the contract; this one is informative
                     out["cpu_baseline_all_cores"] = {"error": str(ex)}
+        if world == 1 and not args.no_e2e and not grid and not iq8 and not args.capture and args.config in (1, 2):
+            try:
+                out["e2e_cli"] = e2e_cli(cfg, d_bits, nblk // 32, eng.num_doppler)
+            except Exception as ex:
+                out["e2e_cli"] = {"error": str(ex)}
         out.update(extra)
         print(json.dumps(out), flush=True)
     if dist is not None:

@@ -29,15 +29,52 @@ hipError_t upload_wq(const cf* host) { return hipMemcpyToSymbol(HIP_SYMBOL(c_wq)
 // ---------------------------------------------------------------------------------------
 // Forward transform (Sample() :141-161 / SearchInit() :101-106): grid (n_items), one workgroup per item computes the
 // eight rows of its polyphase spectrum one after the other and writes each once, coalesced.
-template <bool BITS>
+// SRC_REAL: float code replicas (SearchInit).  SRC_BITS: the 1-bit capture gps_test reads.  SRC_IQ8: an 8-bit IQ capture
+// (rtl-sdr / HackRF) -- mean removal, mixer, sign and the bit transpose happen while the block is staged, so the 1-bit
+// stream the reference's MATLAB scripts write to disk (proc_rtl_bin_for_gps.m:22-26,43-47) is never materialised.
+enum { SRC_REAL = 0, SRC_BITS = 1, SRC_IQ8 = 2 };
+
+// iq8 staging, step 1: the block's first 5000 bytes of the 1-bit stream, made from the IQ bytes (one aligned 16-byte group
+// of 8 samples -> one byte; iq_convert.hpp) into a workgroup-local buffer -- the transform buffer, not yet in use.
+// Step 2 is fwd_stage_bits on that buffer.  One byte per loop trip keeps the eight double-precision sincos of a byte
+// the only live state (the whole staging unrolled needs 256 VGPRs).
+__device__ __forceinline__ void fwd_convert_iq8(int tid, const uint8_t* __restrict__ iq, size_t n0, size_t n_total, const IqConv& c,
+                                                uint8_t* stage) {
+    const uint4* p = reinterpret_cast<const uint4*>(iq);
+#pragma unroll 1
+    for (int by = tid; by < USED_BYTES; by += WG) {
+        const size_t s0 = n0 + (size_t)by * 8;
+        unsigned raw[4] = {0, 0, 0, 0};
+        if (s0 + 8 <= n_total) {
+            const uint4 v = p[by];
+            raw[0] = v.x; raw[1] = v.y; raw[2] = v.z; raw[3] = v.w;
+        } else {
+            for (size_t sidx = s0; sidx < n_total; ++sidx) {
+                const size_t o = 2 * (sidx - n0);
+                const unsigned pair = iq[o] | ((unsigned)iq[o + 1] << 8);
+                raw[(sidx - s0) >> 1] |= pair << (16 * ((sidx - s0) & 1));
+            }
+        }
+        stage[by] = (uint8_t)iq8_byte(raw, s0, n_total, c);
+    }
+}
+
+template <int SRC>
 __global__ __launch_bounds__(WG) void k_fwd(FwdArgs a) {
+    constexpr bool BITS = SRC != SRC_REAL;
     __shared__ cf lds[M_SUB];
     __shared__ uint64_t ib[BITS ? USED_BYTES / NPOLY : 1], qb[BITS ? USED_BYTES / NPOLY : 1];
     __shared__ cf lut[BITS ? 256 : 1];
     const int tid = threadIdx.x, item = blockIdx.x;
     const int srci = item / a.sub, r = item - srci * a.sub;
     // once per workgroup: the bit-transposed block and the row-independent pass-1 twiddles
-    if (BITS) fwd_stage_bits(tid, (const uint8_t*)a.src + (size_t)srci * a.src_stride, a.cos_t, a.sin_t, ib, qb);
+    if (SRC == SRC_BITS) fwd_stage_bits(tid, (const uint8_t*)a.src + (size_t)srci * a.src_stride, a.cos_t, a.sin_t, ib, qb);
+    if (SRC == SRC_IQ8) {
+        uint8_t* stage = reinterpret_cast<uint8_t*>(lds);
+        fwd_convert_iq8(tid, (const uint8_t*)a.src + (size_t)srci * a.src_stride, a.iq_first + (size_t)srci * (a.src_stride / 2), a.iq_total, a.iq, stage);
+        __syncthreads();
+        fwd_stage_bits(tid, stage, a.cos_t, a.sin_t, ib, qb);
+    }
     cf w[2][RA - 1];
     load_tw1(tid, a.t1, w);
     for (int kappa = 0; kappa < NPOLY; ++kappa) {
@@ -304,13 +341,31 @@ __global__ void k_pack_keys(const Peak* peaks, unsigned long long* keys, int n, 
     keys[i] = (snr << 32) | (lo << 16) | ((unsigned long long)p.ca_shift & 0xFFFFull);
 }
 
+// Reference schedule (task t <-> PRN t % 32): the best key of each PRN over all runs of this device -- what the one
+// all-reduce of the block decomposition carries (32 keys).  One workgroup, thread (r, sv) strides over the runs.
+__global__ __launch_bounds__(WG) void k_prn_best(const unsigned long long* keys, int n_tasks, unsigned long long* best) {
+    __shared__ unsigned long long part[WG];
+    const int sv = threadIdx.x & 31, lane_run = threadIdx.x >> 5;  // 8 runs in flight per pass
+    unsigned long long k = 0;
+    for (int t = lane_run * 32 + sv; t < n_tasks; t += WG) k = keys[t] > k ? keys[t] : k;
+    part[threadIdx.x] = k;
+    __syncthreads();
+    if (threadIdx.x < 32) {
+        for (int r = 1; r < WG / 32; ++r) k = part[r * 32 + sv] > k ? part[r * 32 + sv] : k;
+        best[sv] = k;
+    }
+}
+
 // ---------------------------------------------------------------------------------------
 // launchers (host)
 void launch_fwd_bits(const FwdArgs& a, int n_items, hipStream_t s) {
-    hipLaunchKernelGGL(k_fwd<true>, dim3(n_items), dim3(WG), 0, s, a);
+    hipLaunchKernelGGL(k_fwd<SRC_BITS>, dim3(n_items), dim3(WG), 0, s, a);
+}
+void launch_fwd_iq8(const FwdArgs& a, int n_items, hipStream_t s) {
+    hipLaunchKernelGGL(k_fwd<SRC_IQ8>, dim3(n_items), dim3(WG), 0, s, a);
 }
 void launch_fwd_real(const FwdArgs& a, int n_items, hipStream_t s) {
-    hipLaunchKernelGGL(k_fwd<false>, dim3(n_items), dim3(WG), 0, s, a);
+    hipLaunchKernelGGL(k_fwd<SRC_REAL>, dim3(n_items), dim3(WG), 0, s, a);
 }
 void launch_code_halo(cf* cpp, int n_rows, int crow, int halo, hipStream_t s) {
     hipLaunchKernelGGL(k_code_halo, dim3(n_rows), dim3(WG), 0, s, cpp, crow, halo);
@@ -363,6 +418,9 @@ void launch_merge_cells(const Cell* parts, Cell* cells, size_t n_cells, int n_pa
 }
 void launch_pack_keys(const Peak* peaks, unsigned long long* keys, int n, int kmax, hipStream_t s) {
     hipLaunchKernelGGL(k_pack_keys, dim3((n + 255) / 256), dim3(256), 0, s, peaks, keys, n, kmax);
+}
+void launch_prn_best(const unsigned long long* keys, int n_tasks, unsigned long long* best, hipStream_t s) {
+    hipLaunchKernelGGL(k_prn_best, dim3(1), dim3(WG), 0, s, keys, n_tasks, best);
 }
 void launch_peaks(const Cell* cells, Peak* peaks, int n_tasks, int ndop, int dop_first, hipStream_t s) {
     const int per_wg = WG / 64;

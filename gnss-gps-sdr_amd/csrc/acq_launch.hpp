@@ -4,12 +4,16 @@
 #include <stdint.h>
 
 #include "acq_phases.hpp"
+#include "iq_convert.hpp"
 
 namespace acq {
 
 struct FwdArgs {
-    const void* src;     // bits: packed capture bytes; real: float replicas
-    size_t src_stride;   // per item: bytes (bits) or floats (real)
+    const void* src;     // bits: packed capture bytes; iq8: interleaved 8-bit I,Q bytes (16-byte aligned); real: float replicas
+    size_t src_stride;   // per item: bytes (bits, iq8) or floats (real)
+    IqConv iq;           // iq8 source: format, mean, mixer
+    size_t iq_first;     // iq8 source: capture sample index of src's first sample (the mixer's n, proc_rtl_bin_for_gps.m:41)
+    size_t iq_total;     // iq8 source: samples of the whole capture (samples beyond it read as bit 0, like the converter's tail)
     const uint64_t* cos_t;  // [625] bit-transposed LO masks (bits source only)
     const uint64_t* sin_t;
     const cf* t1;
@@ -54,6 +58,7 @@ struct CorrArgs {
 __attribute__((visibility("hidden"))) int set_last_error(int code, const char* msg);
 
 void launch_fwd_bits(const FwdArgs& a, int n_items, hipStream_t s);
+void launch_fwd_iq8(const FwdArgs& a, int n_items, hipStream_t s);
 void launch_fwd_real(const FwdArgs& a, int n_items, hipStream_t s);
 void launch_code_halo(cf* cpp, int n_rows, int crow, int halo, hipStream_t s);
 void launch_quirk_patch(const QuirkArgs& a, int n_patch, hipStream_t s);
@@ -62,6 +67,7 @@ hipError_t upload_wq(const cf* host);  // fills the __constant__ copy of wq on t
 int launch_corr(const CorrArgs& a, int mc, hipStream_t s);
 void launch_merge_cells(const Cell* parts, Cell* cells, size_t n_cells, int n_parts, int nlags, hipStream_t s);
 void launch_pack_keys(const Peak* peaks, unsigned long long* keys, int n, int kmax, hipStream_t s);
+void launch_prn_best(const unsigned long long* keys, int n_tasks, unsigned long long* best, hipStream_t s);
 void launch_peaks(const Cell* cells, Peak* peaks, int n_tasks, int ndop, int dop_first, hipStream_t s);
 
 }  // namespace acq

@@ -93,9 +93,33 @@ struct gpsacq_engine {
     uint8_t* d_gen = nullptr;
     size_t gen_cap = 0;
     unsigned long long* d_prof = nullptr;  // GPSACQ_PROF=1: s_memtime phase profile of k_corr (diagnostic; 22-column coherent instance)
-    // cached default schedule
+    bool prof = false;                     // GPSACQ_PROF read once, at gpsacq_create
+    // cached default schedule (task t = block t, PRN t % 32; with ref_quirks also its patch list: blocks 0, 32, 64, ...)
     size_t sched_tasks = 0;
     bool sched_valid = false;
+    // pipelined host-buffer searches (gpsacq_pipe_*): a second stream for the uploads, per-slot pinned staging and device buffers
+    hipStream_t copy_stream = nullptr;
+    struct PipeSlot {
+        uint8_t* h_in = nullptr;   // pinned
+        size_t h_cap = 0;
+        uint8_t* d_in = nullptr;
+        size_t d_cap = 0;
+        Peak* d_peaks = nullptr;
+        Peak* h_peaks = nullptr;   // pinned
+        size_t peak_cap = 0;
+        hipEvent_t uploaded = nullptr, done = nullptr;
+        bool busy = false;
+        size_t n_tasks = 0;
+    } pipe[GPSACQ_PIPE_SLOTS];
+};
+
+// what a search transforms: the 1-bit stream gps_test reads, or an 8-bit IQ capture converted while it is staged
+struct Capture {
+    bool iq8 = false;
+    const uint8_t* d_src = nullptr;  // device pointer
+    size_t stride = 0;               // bytes per block in d_src
+    IqConv iq{};
+    size_t iq_first = 0, iq_total = ~(size_t)0;
 };
 
 static const size_t kFwdChunk = 32768;  // blocks per forward-transform launch (grid.y bound)
@@ -132,16 +156,23 @@ static int ensure_code_slots(gpsacq_engine* e, size_t n_patch) {
 }
 
 // forward transforms of n items into out (polyphase layout)
-// (sub spectra per source item when bits: item i of the grid -> source i / sub, sub-bin offset i % sub)
-static int run_forward(gpsacq_engine* e, bool bits, const void* src, size_t src_stride, size_t n_src, cf* out,
-                       size_t item_stride, long row, int off, bool conj_out) {
-    const int sub = bits ? e->sub : 1;
+// (sub spectra per source item when bits / iq8: item i of the grid -> source i / sub, sub-bin offset i % sub;
+//  sub_override > 0: that many instead of the engine's -- the parity probe wants exactly one)
+enum FwdKind { FWD_REAL, FWD_BITS, FWD_IQ8 };
+static int run_forward(gpsacq_engine* e, FwdKind kind, const void* src, size_t src_stride, size_t n_src, cf* out,
+                       size_t item_stride, long row, int off, bool conj_out, int sub_override = 0, const Capture* cap = nullptr) {
+    const int sub = kind == FWD_REAL ? 1 : (sub_override > 0 ? sub_override : e->sub);
     const size_t chunk = kFwdChunk / (size_t)sub;  // sources per launch
     for (size_t base = 0; base < n_src; base += chunk) {  // grid.y bound
         const size_t cnt = std::min(chunk, n_src - base) * (size_t)sub;
         FwdArgs fa{};
-        fa.src = bits ? (const void*)((const uint8_t*)src + base * src_stride) : (const void*)((const float*)src + base * src_stride);
+        fa.src = kind == FWD_REAL ? (const void*)((const float*)src + base * src_stride) : (const void*)((const uint8_t*)src + base * src_stride);
         fa.src_stride = src_stride;
+        if (kind == FWD_IQ8) {
+            fa.iq = cap->iq;
+            fa.iq_first = cap->iq_first + base * (src_stride / 2);
+            fa.iq_total = cap->iq_total;
+        }
         fa.sub = sub;
         fa.rot8 = e->d_rot8;
         fa.cos_t = e->d_cos_t;
@@ -154,7 +185,8 @@ static int run_forward(gpsacq_engine* e, bool bits, const void* src, size_t src_
         fa.row = row;
         fa.off = off;
         fa.conj_out = conj_out ? 1 : 0;
-        if (bits) launch_fwd_bits(fa, (int)cnt, e->stream);
+        if (kind == FWD_BITS) launch_fwd_bits(fa, (int)cnt, e->stream);
+        else if (kind == FWD_IQ8) launch_fwd_iq8(fa, (int)cnt, e->stream);
         else launch_fwd_real(fa, (int)cnt, e->stream);
     }
     HIPCHK(hipGetLastError());
@@ -174,6 +206,16 @@ extern "C" void gpsacq_destroy(gpsacq_engine* e) {
     for (auto& set : e->ev)
         for (auto& ev : set)
             if (ev) (void)hipEventDestroy(ev);
+    if (e->copy_stream) (void)hipStreamSynchronize(e->copy_stream);
+    for (auto& sl : e->pipe) {
+        if (sl.h_in) (void)hipHostFree(sl.h_in);
+        if (sl.h_peaks) (void)hipHostFree(sl.h_peaks);
+        if (sl.d_in) (void)hipFree(sl.d_in);
+        if (sl.d_peaks) (void)hipFree(sl.d_peaks);
+        if (sl.uploaded) (void)hipEventDestroy(sl.uploaded);
+        if (sl.done) (void)hipEventDestroy(sl.done);
+    }
+    if (e->copy_stream) (void)hipStreamDestroy(e->copy_stream);
     if (e->stream) (void)hipStreamDestroy(e->stream);
     delete e;
 }
@@ -215,6 +257,10 @@ extern "C" int gpsacq_create(const gpsacq_params* params, gpsacq_engine** out) {
     e->crow = M_SUB + 2 * e->halo;
     e->cus = prop.multiProcessorCount;
     snprintf(e->name, sizeof e->name, "%s", prop.name);
+    {
+        const char* pv = getenv("GPSACQ_PROF");  // diagnostic (k_corr phase profile); read once, here
+        e->prof = pv && *pv && atoi(pv) != 0;
+    }
 #define HCK(expr)                                                                     \
     do {                                                                              \
         hipError_t e_ = (expr);                                                       \
@@ -280,7 +326,7 @@ extern "C" int gpsacq_create(const gpsacq_params* params, gpsacq_engine** out) {
     HCK(hipMalloc((void**)&e->d_code, GPSACQ_NUM_SATS * slot * sizeof(cf)));
     HCK(hipMemsetAsync(e->d_code, 0, GPSACQ_NUM_SATS * slot * sizeof(cf), e->stream));
     {
-        int rc = run_forward(e, false, d_rep, N_FFT, GPSACQ_NUM_SATS, e->d_code, slot, e->crow, e->halo, false);
+        int rc = run_forward(e, FWD_REAL, d_rep, N_FFT, GPSACQ_NUM_SATS, e->d_code, slot, e->crow, e->halo, false);
         if (rc != GPSACQ_OK) {
             (void)hipFree(d_rep);
             gpsacq_destroy(e);
@@ -317,12 +363,29 @@ extern "C" int gpsacq_get_info(const gpsacq_engine* e, gpsacq_info* info) {
 }
 
 // Builds the device task list.  h_tasks (host copy of the user's tasks) may be NULL for the
-// reference schedule.  Returns the number of quirk patches needed through n_patch.
+// reference schedule (task t = block t against PRN t % 32), whose list -- and, with ref_quirks, whose patch list
+// (PRN index 0 <-> blocks 0, 32, 64, ...) -- is cached on the device: later batches of the same schedule enqueue
+// nothing but the patch kernel and never wait for the stream (the pipelined front end depends on that).
+static void launch_patches(gpsacq_engine* e, size_t n_patch, const uint8_t* d_bits, size_t stride) {
+    QuirkArgs qa{};
+    qa.code0 = e->d_code;
+    qa.patched = e->d_code + (size_t)GPSACQ_NUM_SATS * NPOLY * e->crow;
+    qa.bits = d_bits;
+    qa.stride = stride;
+    qa.block_of_patch = e->d_patch_blocks;
+    qa.cos_mask = e->d_cos;
+    qa.sin_mask = e->d_sin;
+    qa.crow = e->crow;
+    qa.halo = e->halo;
+    launch_quirk_patch(qa, (int)n_patch, e->stream);
+}
 static int prepare_tasks(gpsacq_engine* e, const gpsacq_task* h_tasks, const void* d_user_tasks, size_t n_blocks,
                          size_t n_tasks, const uint8_t* d_bits, size_t stride) {
     const bool quirks = e->p.ref_quirks != 0;
-    if (!h_tasks && !d_user_tasks) {
-        if (e->sched_valid && n_tasks <= e->sched_tasks && !quirks && e->n_acc == 1) return GPSACQ_OK;  // cached (a prefix is the same schedule)
+    const bool deflt = !h_tasks && !d_user_tasks;
+    if (deflt && e->sched_valid && n_tasks <= e->sched_tasks && e->n_acc == 1) {  // cached (a prefix is the same schedule)
+        if (quirks) launch_patches(e, (n_tasks + GPSACQ_NUM_SATS - 1) / GPSACQ_NUM_SATS, d_bits, stride);
+        return GPSACQ_OK;
     }
     if (int rc = grow(e->d_tasks, e->task_cap, n_tasks, e->stream)) return rc;
     e->sched_valid = false;
@@ -356,32 +419,44 @@ static int prepare_tasks(gpsacq_engine* e, const gpsacq_task* h_tasks, const voi
     if (!patch_blocks.empty()) {
         if (int rc = ensure_code_slots(e, patch_blocks.size())) return rc;
         HIPCHK(hipMemcpyAsync(e->d_patch_blocks, patch_blocks.data(), patch_blocks.size() * sizeof(int32_t), hipMemcpyHostToDevice, e->stream));
-        QuirkArgs qa{};
-        qa.code0 = e->d_code;
-        qa.patched = e->d_code + (size_t)GPSACQ_NUM_SATS * NPOLY * e->crow;
-        qa.bits = d_bits;
-        qa.stride = stride;
-        qa.block_of_patch = e->d_patch_blocks;
-        qa.cos_mask = e->d_cos;
-        qa.sin_mask = e->d_sin;
-        qa.crow = e->crow;
-        qa.halo = e->halo;
-        launch_quirk_patch(qa, (int)patch_blocks.size(), e->stream);
+        launch_patches(e, patch_blocks.size(), d_bits, stride);
     }
     HIPCHK(hipMemcpyAsync(e->d_tasks, tk.data(), n_tasks * sizeof(Task), hipMemcpyHostToDevice, e->stream));
     HIPCHK(hipStreamSynchronize(e->stream));  // tk / patch_blocks go out of scope
-    if (!h_tasks && !quirks && e->n_acc == 1) {
+    if (deflt && e->n_acc == 1) {
         e->sched_valid = true;
         e->sched_tasks = n_tasks;
     }
     return GPSACQ_OK;
 }
 
-static int search_core(gpsacq_engine* e, const uint8_t* d_bits, size_t n_blocks, size_t stride, const gpsacq_task* h_tasks,
+static int iq8_to_bits_enqueue(gpsacq_engine* e, const uint8_t* d_iq, size_t n_samples, const IqConv& conv, size_t first_sample, uint8_t* d_bits);
+
+static int search_core(gpsacq_engine* e, const Capture& cap_in, size_t n_blocks, const gpsacq_task* h_tasks,
                        const void* d_user_tasks, size_t n_tasks, Cell* d_cells, Peak* d_peaks) {
+    Capture cap = cap_in;
     if (n_blocks == 0 || n_tasks == 0) return fail(GPSACQ_ERR_ARG, "empty batch");
-    if (stride < (size_t)BLOCK_BYTES && e->p.ref_quirks) return fail(GPSACQ_ERR_ARG, "ref_quirks needs all 5120 bytes of a block (stride >= 5120)");
-    if (stride < (size_t)USED_BYTES) return fail(GPSACQ_ERR_ARG, "stride %zu < 5000 bytes", stride);
+    if (cap.iq8) {
+        if (cap.stride % 16 != 0 || cap.stride < (size_t)USED_BYTES * 16) return fail(GPSACQ_ERR_ARG, "8-bit IQ blocks: stride %zu must be a multiple of 16 and >= 80000 bytes", cap.stride);
+        if (((uintptr_t)cap.d_src & 15) != 0) return fail(GPSACQ_ERR_ARG, "IQ buffer must be 16-byte aligned");
+        if (e->p.ref_quirks) {
+            // the quirk patch reads the 960 samples past each block from a 1-bit stream: convert first (same arithmetic,
+            // iq_convert.hpp), then search the bits -- the un-fused route, kept for this one mode
+            const size_t n_samples = (n_blocks - 1) * (cap.stride / 2) + (size_t)BLOCK_BYTES * 8;
+            if (int rc = grow(e->d_iqbits, e->iqbits_cap, (n_samples + 7) / 8, e->stream)) return rc;
+            IqConv cv = cap.iq;
+            const size_t avail = cap.iq_total > cap.iq_first ? cap.iq_total - cap.iq_first : 0;
+            if (int rc = iq8_to_bits_enqueue(e, cap.d_src, std::min(n_samples, avail), cv, cap.iq_first, e->d_iqbits)) return rc;
+            cap.iq8 = false;
+            cap.d_src = e->d_iqbits;
+            cap.stride = cap.stride / 16;
+        }
+    }
+    const size_t stride = cap.stride;
+    if (!cap.iq8) {
+        if (stride < (size_t)BLOCK_BYTES && e->p.ref_quirks) return fail(GPSACQ_ERR_ARG, "ref_quirks needs all 5120 bytes of a block (stride >= 5120)");
+        if (stride < (size_t)USED_BYTES) return fail(GPSACQ_ERR_ARG, "stride %zu < 5000 bytes", stride);
+    }
     if (n_blocks > 0x7fffffffu) return fail(GPSACQ_ERR_ARG, "batch too large: %zu blocks", n_blocks);
     if (n_tasks * (size_t)e->ndop > 0x7fffff00u) return fail(GPSACQ_ERR_ARG, "batch too large: %zu tasks x %d bins", n_tasks, e->ndop);
     if (n_blocks * (size_t)e->sub > 0x7fffffffu) return fail(GPSACQ_ERR_ARG, "batch too large: %zu blocks x %d sub-bin spectra", n_blocks, e->sub);
@@ -390,12 +465,14 @@ static int search_core(gpsacq_engine* e, const uint8_t* d_bits, size_t n_blocks,
         if (int rc = grow(e->d_cells, e->cell_cap, n_tasks * (size_t)e->ndop, e->stream)) return rc;
         d_cells = e->d_cells;
     }
-    if (int rc = prepare_tasks(e, h_tasks, d_user_tasks, n_blocks, n_tasks, d_bits, stride)) return rc;
+    if (int rc = prepare_tasks(e, h_tasks, d_user_tasks, n_blocks, n_tasks, cap.d_src, stride)) return rc;
 
     hipEvent_t* ev = e->ev[e->searches % gpsacq_engine::kTimingRing];
     HIPCHK(hipEventRecord(ev[0], e->stream));
-    if (int rc = run_forward(e, true, d_bits, stride, n_blocks, e->d_dpp, (size_t)NPOLY * M_SUB, M_SUB, 0, true)) return rc;
+    if (int rc = run_forward(e, cap.iq8 ? FWD_IQ8 : FWD_BITS, cap.d_src, stride, n_blocks, e->d_dpp, (size_t)NPOLY * M_SUB, M_SUB, 0, true, 0, &cap)) return rc;
     HIPCHK(hipEventRecord(ev[1], e->stream));
+    // the block period in samples: what the code creeps over between accumulated blocks
+    const double block_samples = cap.iq8 ? (double)stride / 2.0 : (double)stride * 8.0;
     CorrArgs ca{};
     ca.dpp = e->d_dpp;
     ca.cpp = e->d_code;
@@ -417,7 +494,7 @@ static int search_core(gpsacq_engine* e, const uint8_t* d_bits, size_t n_blocks,
     ca.n_code = GPSACQ_NUM_SATS + (int)e->patch_cap;
     ca.sub = e->sub;
     ca.dstride = e->dstride;
-    if (getenv("GPSACQ_PROF")) {
+    if (e->prof && e->mc == 22 && e->n_acc == 1) {  // the profiled instance exists for the 22-column coherent kernel only
         if (!e->d_prof) HIPCHK(hipMalloc((void**)&e->d_prof, 1024 * 16 * sizeof(unsigned long long)));
         HIPCHK(hipMemsetAsync(e->d_prof, 0, 1024 * 16 * sizeof(unsigned long long), e->stream));
         ca.prof = e->d_prof;
@@ -428,7 +505,7 @@ static int search_core(gpsacq_engine* e, const uint8_t* d_bits, size_t n_blocks,
         ca.m0 = 0;
         // samples the code advances per accumulated block per Doppler bin: elapsed samples x (bin Hz / L1)
         if (e->creep_comp && e->n_acc > 1)
-            ca.creep = (float)((double)e->acc_step * (double)stride * 8.0 * (e->p.fs / N_FFT * e->dstride / e->sub) / 1575.42e6);
+            ca.creep = (float)((double)e->acc_step * block_samples * (e->p.fs / N_FFT * e->dstride / e->sub) / 1575.42e6);
         if (launch_corr(ca, e->mc, e->stream) != 0) return fail(GPSACQ_ERR_UNSUPPORTED, "no correlate kernel for %d columns", e->mc);
     } else {
         const size_t n_cells = n_tasks * (size_t)e->ndop;
@@ -466,13 +543,70 @@ static int search_core(gpsacq_engine* e, const uint8_t* d_bits, size_t n_blocks,
     return GPSACQ_OK;
 }
 
+static Capture bits_capture(const void* d_bits, size_t stride) {
+    Capture c;
+    c.d_src = (const uint8_t*)d_bits;
+    c.stride = stride;
+    return c;
+}
+// validates a gpsacq_iq8_input and turns it into the kernels' argument form
+static int iq8_capture(const gpsacq_engine* e, const gpsacq_iq8_input* in, const void* d_iq, size_t stride, Capture* out) {
+    if (!in) return fail(GPSACQ_ERR_ARG, "8-bit IQ search: null gpsacq_iq8_input");
+    if (in->format != GPSACQ_IQ_U8 && in->format != GPSACQ_IQ_S8) return fail(GPSACQ_ERR_ARG, "unknown IQ format %d", in->format);
+    const double fs = in->fs > 0 ? in->fs : e->p.fs;
+    Capture c;
+    c.iq8 = true;
+    c.d_src = (const uint8_t*)d_iq;
+    c.stride = stride;
+    c.iq.is_signed = in->format == GPSACQ_IQ_S8;
+    c.iq.mix = in->mix_hz != 0.0;
+    c.iq.mean_i = in->remove_dc ? in->mean_i : 0.0;
+    c.iq.mean_q = in->remove_dc ? in->mean_q : 0.0;
+    c.iq.two_pi_fc = (2.0 * 3.141592653589793) * in->mix_hz;  // ((1i*2)*pi)*fc, left to right
+    c.iq.inv_fs = 1.0 / fs;
+    c.iq_first = (size_t)in->first_sample;
+    c.iq_total = in->total_samples ? (size_t)in->total_samples : ~(size_t)0;
+    *out = c;
+    return GPSACQ_OK;
+}
+
 extern "C" int gpsacq_search_device(gpsacq_engine* e, const void* d_bits, size_t n_blocks, size_t stride, const void* d_tasks,
                                     size_t n_tasks, void* d_cells, void* d_peaks, int sync) {
     if (!e || !d_bits || !d_peaks) return fail(GPSACQ_ERR_ARG, "gpsacq_search_device: null argument");
     if (!d_tasks && n_tasks != n_blocks && e->n_acc == 1) return fail(GPSACQ_ERR_ARG, "tasks == NULL needs n_tasks == n_blocks");
     HIPCHK(hipSetDevice(e->p.device));
-    if (int rc = search_core(e, (const uint8_t*)d_bits, n_blocks, stride, nullptr, d_tasks, n_tasks, (Cell*)d_cells, (Peak*)d_peaks)) return rc;
+    if (int rc = search_core(e, bits_capture(d_bits, stride), n_blocks, nullptr, d_tasks, n_tasks, (Cell*)d_cells, (Peak*)d_peaks)) return rc;
     if (sync) HIPCHK(hipStreamSynchronize(e->stream));
+    return GPSACQ_OK;
+}
+
+extern "C" int gpsacq_search_iq8_device(gpsacq_engine* e, const gpsacq_iq8_input* in, const void* d_iq, size_t n_blocks, size_t stride,
+                                        const void* d_tasks, size_t n_tasks, void* d_cells, void* d_peaks, int sync) {
+    if (!e || !d_iq || !d_peaks) return fail(GPSACQ_ERR_ARG, "gpsacq_search_iq8_device: null argument");
+    if (!d_tasks && n_tasks != n_blocks && e->n_acc == 1) return fail(GPSACQ_ERR_ARG, "tasks == NULL needs n_tasks == n_blocks");
+    Capture cap;
+    if (int rc = iq8_capture(e, in, d_iq, stride, &cap)) return rc;
+    HIPCHK(hipSetDevice(e->p.device));
+    if (int rc = search_core(e, cap, n_blocks, nullptr, d_tasks, n_tasks, (Cell*)d_cells, (Peak*)d_peaks)) return rc;
+    if (sync) HIPCHK(hipStreamSynchronize(e->stream));
+    return GPSACQ_OK;
+}
+
+// host-buffer searches: upload, search, download, wait
+static int search_host(gpsacq_engine* e, Capture cap, const void* host, size_t nbytes, size_t n_blocks, const gpsacq_task* tasks,
+                       size_t n_tasks, gpsacq_cell* cells, gpsacq_peak* peaks) {
+    HIPCHK(hipSetDevice(e->p.device));
+    uint8_t*& dbuf = cap.iq8 ? e->d_iq : e->d_bits;
+    size_t& dcap = cap.iq8 ? e->iq_cap : e->bits_cap;
+    if (int rc = grow(dbuf, dcap, nbytes + 16, e->stream)) return rc;
+    HIPCHK(hipMemcpyAsync(dbuf, host, nbytes, hipMemcpyHostToDevice, e->stream));
+    cap.d_src = dbuf;
+    if (int rc = grow(e->d_cells, e->cell_cap, n_tasks * (size_t)e->ndop, e->stream)) return rc;
+    if (int rc = grow(e->d_peaks, e->peak_cap, n_tasks, e->stream)) return rc;
+    if (int rc = search_core(e, cap, n_blocks, tasks, nullptr, n_tasks, e->d_cells, e->d_peaks)) return rc;
+    if (cells) HIPCHK(hipMemcpyAsync(cells, e->d_cells, n_tasks * (size_t)e->ndop * sizeof(Cell), hipMemcpyDeviceToHost, e->stream));
+    if (peaks) HIPCHK(hipMemcpyAsync(peaks, e->d_peaks, n_tasks * sizeof(Peak), hipMemcpyDeviceToHost, e->stream));
+    HIPCHK(hipStreamSynchronize(e->stream));
     return GPSACQ_OK;
 }
 
@@ -481,16 +615,122 @@ extern "C" int gpsacq_search(gpsacq_engine* e, const uint8_t* bits, size_t n_blo
     if (!e || !bits) return fail(GPSACQ_ERR_ARG, "gpsacq_search: null argument");
     if (!tasks && n_tasks != n_blocks && e->n_acc == 1) return fail(GPSACQ_ERR_ARG, "tasks == NULL needs n_tasks == n_blocks");
     if (n_blocks == 0 || n_tasks == 0) return fail(GPSACQ_ERR_ARG, "empty batch");
-    HIPCHK(hipSetDevice(e->p.device));
     const size_t nbytes = (n_blocks - 1) * stride + (stride < (size_t)BLOCK_BYTES ? stride : (size_t)BLOCK_BYTES);
-    if (int rc = grow(e->d_bits, e->bits_cap, nbytes, e->stream)) return rc;
-    HIPCHK(hipMemcpyAsync(e->d_bits, bits, nbytes, hipMemcpyHostToDevice, e->stream));
-    if (int rc = grow(e->d_cells, e->cell_cap, n_tasks * (size_t)e->ndop, e->stream)) return rc;
-    if (int rc = grow(e->d_peaks, e->peak_cap, n_tasks, e->stream)) return rc;
-    if (int rc = search_core(e, e->d_bits, n_blocks, stride, tasks, nullptr, n_tasks, e->d_cells, e->d_peaks)) return rc;
-    if (cells) HIPCHK(hipMemcpyAsync(cells, e->d_cells, n_tasks * (size_t)e->ndop * sizeof(Cell), hipMemcpyDeviceToHost, e->stream));
-    if (peaks) HIPCHK(hipMemcpyAsync(peaks, e->d_peaks, n_tasks * sizeof(Peak), hipMemcpyDeviceToHost, e->stream));
-    HIPCHK(hipStreamSynchronize(e->stream));
+    return search_host(e, bits_capture(nullptr, stride), bits, nbytes, n_blocks, tasks, n_tasks, cells, peaks);
+}
+
+// bytes of an 8-bit IQ buffer that hold what n_blocks blocks `stride` bytes apart read: 80000 per block, the whole 81920
+// (40960 samples, one Sample() call) with ref_quirks; never beyond the end of the capture
+static size_t iq8_span(const gpsacq_engine* e, const Capture& cap, size_t n_blocks) {
+    const size_t per = (size_t)(e->p.ref_quirks ? BLOCK_BYTES : USED_BYTES) * 16;
+    size_t nbytes = (n_blocks - 1) * cap.stride + std::min(per, cap.stride);
+    if (cap.iq_total != ~(size_t)0) {
+        const size_t avail = cap.iq_total > cap.iq_first ? (cap.iq_total - cap.iq_first) * 2 : 0;
+        nbytes = std::min(nbytes, avail);
+    }
+    return nbytes;
+}
+
+extern "C" int gpsacq_search_iq8(gpsacq_engine* e, const gpsacq_iq8_input* in, const void* iq, size_t n_blocks, size_t stride,
+                                 const gpsacq_task* tasks, size_t n_tasks, gpsacq_cell* cells, gpsacq_peak* peaks) {
+    if (!e || !iq) return fail(GPSACQ_ERR_ARG, "gpsacq_search_iq8: null argument");
+    if (!tasks && n_tasks != n_blocks && e->n_acc == 1) return fail(GPSACQ_ERR_ARG, "tasks == NULL needs n_tasks == n_blocks");
+    if (n_blocks == 0 || n_tasks == 0) return fail(GPSACQ_ERR_ARG, "empty batch");
+    Capture cap;
+    if (int rc = iq8_capture(e, in, nullptr, stride, &cap)) return rc;
+    return search_host(e, cap, iq, iq8_span(e, cap, n_blocks), n_blocks, tasks, n_tasks, cells, peaks);
+}
+
+// ---- pipelined host-buffer searches (reference schedule) -----------------------------------------------------------
+// Slot life cycle: gpsacq_pipe_buffer (fill it) -> gpsacq_pipe_submit (upload on the copy stream, search on the engine's
+// stream after it, peaks into pinned memory; returns at once) -> gpsacq_pipe_collect (waits for THIS slot only).  With two
+// or three slots the caller's file read of batch k+1 and its report of batch k-1 overlap the search of batch k.
+static int pipe_slot(gpsacq_engine* e, int slot, gpsacq_engine::PipeSlot** out) {
+    if (!e) return fail(GPSACQ_ERR_ARG, "gpsacq_pipe: null engine");
+    if (slot < 0 || slot >= GPSACQ_PIPE_SLOTS) return fail(GPSACQ_ERR_ARG, "gpsacq_pipe: slot %d outside 0..%d", slot, GPSACQ_PIPE_SLOTS - 1);
+    HIPCHK(hipSetDevice(e->p.device));
+    gpsacq_engine::PipeSlot& sl = e->pipe[slot];
+    if (!e->copy_stream) HIPCHK(hipStreamCreateWithFlags(&e->copy_stream, hipStreamNonBlocking));
+    if (!sl.uploaded) HIPCHK(hipEventCreateWithFlags(&sl.uploaded, hipEventDisableTiming));
+    if (!sl.done) HIPCHK(hipEventCreateWithFlags(&sl.done, hipEventDisableTiming));
+    *out = &sl;
+    return GPSACQ_OK;
+}
+
+extern "C" uint8_t* gpsacq_pipe_buffer(gpsacq_engine* e, int slot, size_t nbytes) {
+    gpsacq_engine::PipeSlot* sl = nullptr;
+    if (pipe_slot(e, slot, &sl) != GPSACQ_OK) return nullptr;
+    if (sl->busy) {
+        fail(GPSACQ_ERR_ARG, "gpsacq_pipe_buffer: slot %d has a search in flight (collect it first)", slot);
+        return nullptr;
+    }
+    if (nbytes > sl->h_cap) {
+        if (sl->h_in) (void)hipHostFree(sl->h_in);
+        sl->h_in = nullptr;
+        sl->h_cap = 0;
+        hipError_t he = hipHostMalloc((void**)&sl->h_in, nbytes, hipHostMallocDefault);
+        if (he != hipSuccess) {
+            fail(he == hipErrorOutOfMemory ? GPSACQ_ERR_NOMEM : GPSACQ_ERR_DEVICE, "hipHostMalloc(%zu): %s", nbytes, hipGetErrorString(he));
+            return nullptr;
+        }
+        sl->h_cap = nbytes;
+    }
+    return sl->h_in;
+}
+
+extern "C" int gpsacq_pipe_submit(gpsacq_engine* e, int slot, size_t n_blocks, size_t stride, const gpsacq_iq8_input* iq) {
+    gpsacq_engine::PipeSlot* sl = nullptr;
+    if (int rc = pipe_slot(e, slot, &sl)) return rc;
+    if (sl->busy) return fail(GPSACQ_ERR_ARG, "gpsacq_pipe_submit: slot %d already has a search in flight", slot);
+    if (n_blocks == 0) return fail(GPSACQ_ERR_ARG, "empty batch");
+    if (e->n_acc != 1) return fail(GPSACQ_ERR_UNSUPPORTED, "gpsacq_pipe_submit runs the reference schedule (coherent, task t = block t)");
+    Capture cap = bits_capture(nullptr, stride);
+    size_t nbytes;
+    if (iq) {
+        if (int rc = iq8_capture(e, iq, nullptr, stride, &cap)) return rc;
+        nbytes = iq8_span(e, cap, n_blocks);
+    } else {
+        nbytes = (n_blocks - 1) * stride + (stride < (size_t)BLOCK_BYTES ? stride : (size_t)BLOCK_BYTES);
+    }
+    if (!sl->h_in || nbytes > sl->h_cap) return fail(GPSACQ_ERR_ARG, "gpsacq_pipe_submit: slot %d holds %zu bytes, the batch needs %zu", slot, sl->h_cap, nbytes);
+    if (nbytes + 16 > sl->d_cap) {  // (the previous search of this slot was collected: nothing reads the old buffer)
+        if (sl->d_in) HIPCHK(hipFree(sl->d_in));
+        sl->d_in = nullptr;
+        sl->d_cap = 0;
+        const size_t want = std::max(nbytes + 16, sl->h_cap + 16);
+        HIPCHK(hipMalloc((void**)&sl->d_in, want));
+        sl->d_cap = want;
+    }
+    if (n_blocks > sl->peak_cap) {
+        if (sl->d_peaks) HIPCHK(hipFree(sl->d_peaks));
+        if (sl->h_peaks) HIPCHK(hipHostFree(sl->h_peaks));
+        sl->d_peaks = nullptr;
+        sl->h_peaks = nullptr;
+        sl->peak_cap = 0;
+        HIPCHK(hipMalloc((void**)&sl->d_peaks, n_blocks * sizeof(Peak)));
+        HIPCHK(hipHostMalloc((void**)&sl->h_peaks, n_blocks * sizeof(Peak), hipHostMallocDefault));
+        sl->peak_cap = n_blocks;
+    }
+    HIPCHK(hipMemcpyAsync(sl->d_in, sl->h_in, nbytes, hipMemcpyHostToDevice, e->copy_stream));
+    HIPCHK(hipEventRecord(sl->uploaded, e->copy_stream));
+    HIPCHK(hipStreamWaitEvent(e->stream, sl->uploaded, 0));
+    cap.d_src = sl->d_in;
+    if (int rc = search_core(e, cap, n_blocks, nullptr, nullptr, n_blocks, nullptr, sl->d_peaks)) return rc;
+    HIPCHK(hipMemcpyAsync(sl->h_peaks, sl->d_peaks, n_blocks * sizeof(Peak), hipMemcpyDeviceToHost, e->stream));
+    HIPCHK(hipEventRecord(sl->done, e->stream));
+    sl->busy = true;
+    sl->n_tasks = n_blocks;
+    return GPSACQ_OK;
+}
+
+extern "C" int gpsacq_pipe_collect(gpsacq_engine* e, int slot, const gpsacq_peak** peaks, size_t* n_peaks) {
+    gpsacq_engine::PipeSlot* sl = nullptr;
+    if (int rc = pipe_slot(e, slot, &sl)) return rc;
+    if (!sl->busy) return fail(GPSACQ_ERR_ARG, "gpsacq_pipe_collect: slot %d has nothing in flight", slot);
+    HIPCHK(hipEventSynchronize(sl->done));
+    sl->busy = false;
+    if (peaks) *peaks = reinterpret_cast<const gpsacq_peak*>(sl->h_peaks);
+    if (n_peaks) *n_peaks = sl->n_tasks;
     return GPSACQ_OK;
 }
 
@@ -535,8 +775,10 @@ extern "C" int gpsacq_set_doppler_step(gpsacq_engine* e, double step_hz) {
     else if (step_hz >= 2 * bin * (1 - 1e-9)) dstride = (int)std::floor(step_hz / bin + 1e-9);
     if (sub > GPSACQ_MAX_DOPPLER_SUB) return fail(GPSACQ_ERR_UNSUPPORTED, "Doppler step %g Hz needs %d sub-bin spectra per block (limit %d)", step_hz, sub, GPSACQ_MAX_DOPPLER_SUB);
     if (sub > 1 && e->p.ref_quirks) return fail(GPSACQ_ERR_UNSUPPORTED, "ref_quirks is defined for the reference's Doppler grid only");
-    const double step = bin * dstride / sub;
-    const int kmax = (int)(e->p.max_fo / step);  // same truncation as :176
+    // same truncation and operation order as :176, (int)(max_fo * N / fs), with the step folded in; sub = dstride = 1
+    // (step_hz = 0 restores the reference grid) gives exactly the dmax of gpsacq_create
+    const int kmax = (sub == 1 && dstride == 1) ? doppler_half_range(e->p.fs, e->p.max_fo)
+                                                : (int)(e->p.max_fo * (double)N_FFT * (double)sub / (e->p.fs * (double)dstride));
     if (2 * kmax + 1 > 0xFFFF) return fail(GPSACQ_ERR_UNSUPPORTED, "%d Doppler points exceed the 65535 the peak keys can carry", 2 * kmax + 1);
     if (sub != e->sub) {  // forward-transform tables of the sub-bin offsets
         HIPCHK(hipStreamSynchronize(e->stream));
@@ -668,6 +910,33 @@ extern "C" int gpsacq_generate_sig(gpsacq_engine* e, int prn, const int8_t* data
 }
 
 // 8-bit IQ -> 1-bit real IF (proc_rtl_bin_for_gps.m / proc_hackrf_bin_for_gps.m), device buffers
+static int iq8_to_bits_enqueue(gpsacq_engine* e, const uint8_t* d_iq, size_t n_samples, const IqConv& conv, size_t first_sample, uint8_t* d_bits) {
+    if (n_samples == 0) return GPSACQ_OK;
+    IqArgs a{};
+    a.iq = d_iq;
+    a.bits = d_bits;
+    a.n_samples = n_samples;
+    a.first_sample = first_sample;
+    a.conv = conv;
+    launch_iq_to_bits(a, e->stream);
+    HIPCHK(hipGetLastError());
+    return GPSACQ_OK;
+}
+
+// exact integer sums of I and Q over n_samples of a device buffer, added to sums[0..1]
+static int iq8_sums_device(gpsacq_engine* e, const uint8_t* d_iq, size_t n_samples, bool is_signed, long long sums[2]) {
+    if (!e->d_sums) HIPCHK(hipMalloc((void**)&e->d_sums, 2 * sizeof(unsigned long long)));
+    HIPCHK(hipMemsetAsync(e->d_sums, 0, 2 * sizeof(unsigned long long), e->stream));
+    launch_iq_sums(d_iq, n_samples, is_signed, e->d_sums, e->stream);
+    HIPCHK(hipGetLastError());
+    long long h[2];
+    HIPCHK(hipMemcpyAsync(h, e->d_sums, sizeof h, hipMemcpyDeviceToHost, e->stream));
+    HIPCHK(hipStreamSynchronize(e->stream));
+    sums[0] += h[0];
+    sums[1] += h[1];
+    return GPSACQ_OK;
+}
+
 extern "C" int gpsacq_iq8_to_bits_device(gpsacq_engine* e, const void* d_iq, size_t n_samples, int format, int remove_dc,
                                          double mix_hz, double fs, void* d_bits, int sync) {
     if (!e || !d_iq || !d_bits || n_samples == 0) return fail(GPSACQ_ERR_ARG, "gpsacq_iq8_to_bits_device: bad argument");
@@ -675,28 +944,33 @@ extern "C" int gpsacq_iq8_to_bits_device(gpsacq_engine* e, const void* d_iq, siz
     if (((uintptr_t)d_iq & 15) != 0) return fail(GPSACQ_ERR_ARG, "IQ buffer must be 16-byte aligned");
     if (!(fs > 0)) fs = e->p.fs;
     HIPCHK(hipSetDevice(e->p.device));
-    IqArgs a{};
-    a.iq = (const uint8_t*)d_iq;
-    a.bits = (uint8_t*)d_bits;
-    a.n_samples = n_samples;
-    a.is_signed = format == GPSACQ_IQ_S8;
-    a.mix = mix_hz != 0.0;
-    a.two_pi_fc = (2.0 * 3.141592653589793) * mix_hz;  // ((1i*2)*pi)*fc, left to right
-    a.inv_fs = 1.0 / fs;
+    IqConv c{};
+    c.is_signed = format == GPSACQ_IQ_S8;
+    c.mix = mix_hz != 0.0;
+    c.two_pi_fc = (2.0 * 3.141592653589793) * mix_hz;  // ((1i*2)*pi)*fc, left to right
+    c.inv_fs = 1.0 / fs;
     if (remove_dc) {
-        if (!e->d_sums) HIPCHK(hipMalloc((void**)&e->d_sums, 2 * sizeof(unsigned long long)));
-        HIPCHK(hipMemsetAsync(e->d_sums, 0, 2 * sizeof(unsigned long long), e->stream));
-        launch_iq_sums(a.iq, n_samples, a.is_signed, e->d_sums, e->stream);
-        HIPCHK(hipGetLastError());
-        long long h[2];
-        HIPCHK(hipMemcpyAsync(h, e->d_sums, sizeof h, hipMemcpyDeviceToHost, e->stream));
-        HIPCHK(hipStreamSynchronize(e->stream));
-        a.mean_i = (double)h[0] / (double)n_samples;  // mean() of integer-valued doubles: exact sums
-        a.mean_q = (double)h[1] / (double)n_samples;
+        long long h[2] = {0, 0};
+        if (int rc = iq8_sums_device(e, (const uint8_t*)d_iq, n_samples, c.is_signed != 0, h)) return rc;
+        c.mean_i = (double)h[0] / (double)n_samples;  // mean() of integer-valued doubles: exact sums
+        c.mean_q = (double)h[1] / (double)n_samples;
     }
-    launch_iq_to_bits(a, e->stream);
-    HIPCHK(hipGetLastError());
+    if (int rc = iq8_to_bits_enqueue(e, (const uint8_t*)d_iq, n_samples, c, 0, (uint8_t*)d_bits)) return rc;
     if (sync) HIPCHK(hipStreamSynchronize(e->stream));
+    return GPSACQ_OK;
+}
+
+// `y - mean(y)` is over the WHOLE capture (proc_rtl_bin_for_gps.m:17): a caller that streams a file in pieces sums first
+extern "C" int gpsacq_iq8_accumulate_sums(gpsacq_engine* e, const void* iq, size_t n_samples, int format, int64_t sums[2]) {
+    if (!e || !iq || !sums || n_samples == 0) return fail(GPSACQ_ERR_ARG, "gpsacq_iq8_accumulate_sums: bad argument");
+    if (format != GPSACQ_IQ_U8 && format != GPSACQ_IQ_S8) return fail(GPSACQ_ERR_ARG, "unknown IQ format %d", format);
+    HIPCHK(hipSetDevice(e->p.device));
+    if (int rc = grow(e->d_iq, e->iq_cap, 2 * n_samples + 16, e->stream)) return rc;
+    HIPCHK(hipMemcpyAsync(e->d_iq, iq, 2 * n_samples, hipMemcpyHostToDevice, e->stream));
+    long long h[2] = {0, 0};
+    if (int rc = iq8_sums_device(e, e->d_iq, n_samples, format == GPSACQ_IQ_S8, h)) return rc;
+    sums[0] += h[0];
+    sums[1] += h[1];
     return GPSACQ_OK;
 }
 
@@ -714,10 +988,12 @@ extern "C" int gpsacq_iq8_to_bits(gpsacq_engine* e, const void* iq, size_t n_sam
     return GPSACQ_OK;
 }
 
-extern "C" int gpsacq_handoff(const gpsacq_peak* peak, double fc, double fs, double secs, gpsacq_handoff_t* out) {
+extern "C" int gpsacq_handoff_step(const gpsacq_peak* peak, double fc, double fs, double step_hz, double secs, gpsacq_handoff_t* out) {
     if (!peak || !out || !(fs > 0)) return fail(GPSACQ_ERR_ARG, "gpsacq_handoff: bad argument");
     const double L1 = 1575.42e6, CPS = 1.023e6;  // c/gps_offline.h:22,30
-    const double lo_dop = peak->lo_shift * fs / N_FFT;
+    // lo_shift counts Doppler grid points: FFT bins of fs / 40000 Hz on the reference grid (:145), gpsacq_info.doppler_step_hz
+    // after gpsacq_set_doppler_step and for gpsacq_multi_search_grid peaks
+    const double lo_dop = step_hz > 0 ? peak->lo_shift * step_hz : peak->lo_shift * fs / N_FFT;
     const double ca_dop = lo_dop / L1 * CPS;
     // the NCO words are fractions of 2^32: frequencies outside [0, fs) do not fit (the reference would wrap silently)
     if (!(fc + lo_dop >= 0 && fc + lo_dop < fs) || !(CPS + ca_dop >= 0 && CPS + ca_dop < fs))
@@ -733,6 +1009,16 @@ extern "C" int gpsacq_handoff(const gpsacq_peak* peak, double fc, double fs, dou
     if (pause < 0) pause += spm;
     out->ca_pause = (uint32_t)pause;
     return GPSACQ_OK;
+}
+
+extern "C" int gpsacq_handoff(const gpsacq_peak* peak, double fc, double fs, double secs, gpsacq_handoff_t* out) {
+    return gpsacq_handoff_step(peak, fc, fs, 0.0, secs, out);  // the reference grid: lo_shift in FFT bins
+}
+
+extern "C" int gpsacq_handoff_engine(const gpsacq_engine* e, const gpsacq_peak* peak, double secs, gpsacq_handoff_t* out) {
+    if (!e) return fail(GPSACQ_ERR_ARG, "gpsacq_handoff_engine: null engine");
+    const bool ref_grid = e->sub == 1 && e->dstride == 1;
+    return gpsacq_handoff_step(peak, e->p.fc, e->p.fs, ref_grid ? 0.0 : e->p.fs / N_FFT * e->dstride / e->sub, secs, out);
 }
 
 extern "C" int gpsacq_search_code(int sv, int g1) {
@@ -754,7 +1040,8 @@ extern "C" int gpsacq_sample_spectrum(gpsacq_engine* e, const uint8_t* block, fl
     if (int rc = grow(e->d_bits, e->bits_cap, (size_t)BLOCK_BYTES, e->stream)) return rc;
     if (int rc = grow(e->d_dpp, e->dpp_cap, (size_t)1, e->stream, (size_t)NPOLY * M_SUB * sizeof(cf))) return rc;
     HIPCHK(hipMemcpyAsync(e->d_bits, block, BLOCK_BYTES, hipMemcpyHostToDevice, e->stream));
-    if (int rc = run_forward(e, true, e->d_bits, BLOCK_BYTES, 1, e->d_dpp, (size_t)NPOLY * M_SUB, M_SUB, 0, true)) return rc;
+    // one spectrum (sub-bin offset 0) even when a finer Doppler grid is active: d_dpp is grown for exactly that
+    if (int rc = run_forward(e, FWD_BITS, e->d_bits, BLOCK_BYTES, 1, e->d_dpp, (size_t)NPOLY * M_SUB, M_SUB, 0, true, 1)) return rc;
     std::vector<cf> pp((size_t)NPOLY * M_SUB);
     HIPCHK(hipMemcpyAsync(pp.data(), e->d_dpp, pp.size() * sizeof(cf), hipMemcpyDeviceToHost, e->stream));
     HIPCHK(hipStreamSynchronize(e->stream));

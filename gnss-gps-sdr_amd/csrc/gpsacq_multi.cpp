@@ -12,7 +12,9 @@
 
 #include <cstdarg>
 #include <cstdio>
+#include <algorithm>
 #include <cstring>
+#include <mutex>
 #include <string>
 #include <vector>
 
@@ -31,17 +33,23 @@ struct Rccl {
     ncclResult_t (*GroupEnd)() = nullptr;
     const char* (*GetErrorString)(ncclResult_t) = nullptr;
 };
-Rccl g_rccl;
+Rccl g_rccl;             // published only when every symbol resolved
+std::mutex g_rccl_lock;  // gpsacq_multi_create may be called from several threads
 const char* load_rccl() {
+    std::lock_guard<std::mutex> guard(g_rccl_lock);
     if (g_rccl.so) return nullptr;
+    Rccl r;
     for (const char* name : {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"}) {
-        g_rccl.so = dlopen(name, RTLD_NOW | RTLD_GLOBAL);
-        if (g_rccl.so) break;
+        r.so = dlopen(name, RTLD_NOW | RTLD_GLOBAL);
+        if (r.so) break;
     }
-    if (!g_rccl.so) return "librccl.so.1 not found (dlopen)";
-#define SYM(field, name)                                                       \
-    g_rccl.field = reinterpret_cast<decltype(g_rccl.field)>(dlsym(g_rccl.so, name)); \
-    if (!g_rccl.field) return "RCCL symbol " name " missing";
+    if (!r.so) return "librccl.so.1 not found (dlopen)";
+#define SYM(field, name)                                                 \
+    r.field = reinterpret_cast<decltype(r.field)>(dlsym(r.so, name));   \
+    if (!r.field) {                                                      \
+        dlclose(r.so);                                                   \
+        return "RCCL symbol " name " missing";                           \
+    }
     SYM(CommInitAll, "ncclCommInitAll")
     SYM(CommDestroy, "ncclCommDestroy")
     SYM(AllReduce, "ncclAllReduce")
@@ -49,6 +57,7 @@ const char* load_rccl() {
     SYM(GroupEnd, "ncclGroupEnd")
     SYM(GetErrorString, "ncclGetErrorString")
 #undef SYM
+    g_rccl = r;
     return nullptr;
 }
 int failf(int code, const char* fmt, ...) {
@@ -59,6 +68,12 @@ int failf(int code, const char* fmt, ...) {
     va_end(ap);
     return acq::set_last_error(code, buf);
 }
+// the caller's current HIP device is the caller's business: put it back on every way out
+struct DeviceGuard {
+    int dev = -1;
+    DeviceGuard() { if (hipGetDevice(&dev) != hipSuccess) dev = -1; }
+    ~DeviceGuard() { if (dev >= 0) (void)hipSetDevice(dev); }
+};
 }  // namespace
 
 struct gpsacq_multi {
@@ -79,14 +94,10 @@ struct gpsacq_multi {
         hipError_t e_ = (expr);                                                                           \
         if (e_ != hipSuccess) return failf(e_ == hipErrorOutOfMemory ? GPSACQ_ERR_NOMEM : GPSACQ_ERR_DEVICE, "%s: %s", #expr, hipGetErrorString(e_)); \
     } while (0)
-#define NCCLM(expr)                                                                                \
-    do {                                                                                           \
-        ncclResult_t r_ = (expr);                                                                  \
-        if (r_ != ncclSuccess) return failf(GPSACQ_ERR_DEVICE, "%s: %s", #expr, g_rccl.GetErrorString(r_)); \
-    } while (0)
 
 extern "C" void gpsacq_multi_destroy(gpsacq_multi* m) {
     if (!m) return;
+    DeviceGuard guard;
     for (size_t i = 0; i < m->eng.size(); ++i) {
         if (!m->eng[i]) continue;  // creation stopped before this device
         (void)hipSetDevice(m->dev[i]);
@@ -102,8 +113,8 @@ extern "C" void gpsacq_multi_destroy(gpsacq_multi* m) {
 extern "C" int gpsacq_multi_create(const gpsacq_params* params, const int32_t* devices, int n_devices, gpsacq_multi** out) {
     if (!params || !out || n_devices < 1 || n_devices > 64) return failf(GPSACQ_ERR_ARG, "gpsacq_multi_create: bad argument");
     *out = nullptr;
-    if (params->ref_quirks) return failf(GPSACQ_ERR_UNSUPPORTED, "ref_quirks belongs to the reference's one-block-per-PRN schedule, not to the grid search");
     if (const char* why = load_rccl()) return failf(GPSACQ_ERR_DEVICE, "RCCL unavailable: %s", why);
+    DeviceGuard guard;
     gpsacq_multi* m = new gpsacq_multi();
     const size_t n = (size_t)n_devices;
     m->eng.assign(n, nullptr);
@@ -138,6 +149,7 @@ extern "C" int gpsacq_multi_create(const gpsacq_params* params, const int32_t* d
 
 extern "C" int gpsacq_multi_set_doppler_step(gpsacq_multi* m, double step_hz) {
     if (!m) return failf(GPSACQ_ERR_ARG, "gpsacq_multi_set_doppler_step: null handle");
+    DeviceGuard guard;
     for (gpsacq_engine* e : m->eng)
         if (int rc = gpsacq_set_doppler_step(e, step_hz)) return rc;
     (void)gpsacq_get_info(m->eng[0], &m->info);
@@ -151,38 +163,80 @@ extern "C" int gpsacq_multi_get_info(const gpsacq_multi* m, gpsacq_info* info, i
     return GPSACQ_OK;
 }
 
-extern "C" int gpsacq_multi_search_grid(gpsacq_multi* m, const uint8_t* bits, size_t n_blocks, size_t stride, const gpsacq_task* tasks,
-                                        size_t n_tasks, gpsacq_peak* peaks) {
-    if (!m || !bits || !tasks || !peaks || n_blocks == 0 || n_tasks == 0 || stride < 5000) return failf(GPSACQ_ERR_ARG, "gpsacq_multi_search_grid: bad argument");
-    for (size_t t = 0; t < n_tasks; ++t)
-        if (tasks[t].block < 0 || (size_t)tasks[t].block >= n_blocks || tasks[t].prn < 0 || tasks[t].prn >= GPSACQ_NUM_SATS)
-            return failf(GPSACQ_ERR_ARG, "task %zu = (block %d, prn %d) out of range", t, tasks[t].block, tasks[t].prn);
+namespace {
+// Per-device scratch, stream-ordered on that device's engine stream (no device-wide synchronisation in mid-pipeline):
+// work already enqueued keeps the old buffer until it has run.
+int grow_dev(gpsacq_multi* m, size_t i, size_t nbytes, size_t n_tasks) {
+    hipStream_t st = (hipStream_t)gpsacq_stream(m->eng[i]);
+    if (nbytes > m->bits_cap[i]) {
+        if (m->d_bits[i]) HIPM(hipFreeAsync(m->d_bits[i], st));
+        m->d_bits[i] = nullptr;
+        m->bits_cap[i] = 0;
+        HIPM(hipMallocAsync((void**)&m->d_bits[i], nbytes, st));
+        m->bits_cap[i] = nbytes;
+    }
+    if (n_tasks > m->task_cap[i]) {
+        for (void** p : {(void**)&m->d_tasks[i], (void**)&m->d_peaks[i], (void**)&m->d_keys[i]}) {
+            if (*p) HIPM(hipFreeAsync(*p, st));
+            *p = nullptr;
+        }
+        m->task_cap[i] = 0;
+        HIPM(hipMallocAsync((void**)&m->d_tasks[i], n_tasks * sizeof(Task), st));
+        HIPM(hipMallocAsync((void**)&m->d_peaks[i], n_tasks * sizeof(Peak), st));
+        HIPM(hipMallocAsync((void**)&m->d_keys[i], (n_tasks + GPSACQ_NUM_SATS) * sizeof(unsigned long long), st));  // + the 32 per-PRN keys
+        m->task_cap[i] = n_tasks;
+    }
+    return GPSACQ_OK;
+}
+// wait for everything enqueued on every engine stream (also the way out of a failed call: nothing of it keeps running)
+void drain(gpsacq_multi* m) {
+    for (size_t i = 0; i < m->eng.size(); ++i) {
+        (void)hipSetDevice(m->dev[i]);
+        (void)hipStreamSynchronize((hipStream_t)gpsacq_stream(m->eng[i]));
+    }
+}
+// the path's one collective: all-reduce(MAX) of `count` 64-bit keys at keys[i] + offset[i] across the devices
+int allreduce_keys(gpsacq_multi* m, const std::vector<unsigned long long*>& keys, size_t count) {
+    ncclResult_t r = g_rccl.GroupStart();
+    if (r != ncclSuccess) return failf(GPSACQ_ERR_DEVICE, "ncclGroupStart: %s", g_rccl.GetErrorString(r));
+    ncclResult_t first_bad = ncclSuccess;
+    int bad_dev = -1;
+    for (size_t i = 0; i < m->eng.size(); ++i) {
+        // every rank of the group is enqueued even after a failure: ending a group that some ranks never joined can hang
+        r = g_rccl.AllReduce(keys[i], keys[i], count, ncclUint64, ncclMax, m->comm[i], (hipStream_t)gpsacq_stream(m->eng[i]));
+        if (r != ncclSuccess && first_bad == ncclSuccess) {
+            first_bad = r;
+            bad_dev = m->dev[i];
+        }
+    }
+    r = g_rccl.GroupEnd();
+    if (first_bad != ncclSuccess) return failf(GPSACQ_ERR_DEVICE, "ncclAllReduce on device %d: %s", bad_dev, g_rccl.GetErrorString(first_bad));
+    if (r != ncclSuccess) return failf(GPSACQ_ERR_DEVICE, "ncclGroupEnd: %s", g_rccl.GetErrorString(r));
+    return GPSACQ_OK;
+}
+void unpack_key(unsigned long long k, int kmax, gpsacq_peak* p) {
+    const uint32_t sb = (uint32_t)(k >> 32);
+    float snr;
+    memcpy(&snr, &sb, sizeof snr);
+    p->snr = snr;
+    p->lo_shift = k ? (int32_t)(0xFFFF - ((k >> 16) & 0xFFFF)) - kmax : 0;
+    p->ca_shift = (int32_t)(k & 0xFFFF);
+    p->max_pwr = 0.f;  // not carried by the key
+}
+}  // namespace
+
+static int search_grid_impl(gpsacq_multi* m, const uint8_t* bits, size_t n_blocks, size_t stride, const gpsacq_task* tasks,
+                            size_t n_tasks, gpsacq_peak* peaks) {
     const size_t n = m->eng.size();
     const size_t nbytes = (n_blocks - 1) * stride + (stride < (size_t)GPSACQ_BLOCK_BYTES ? stride : (size_t)GPSACQ_BLOCK_BYTES);
     const int total = m->info.num_doppler_total, first = m->info.first_doppler_total, kmax = -first;
-    std::vector<int> active;
     for (size_t i = 0; i < n; ++i) {
         // contiguous, balanced slab of the grid for device i (possibly empty when there are more devices than points)
         const int base = total / (int)n, rem = total % (int)n;
         const int cnt = base + ((int)i < rem ? 1 : 0), off = (int)i * base + ((int)i < rem ? (int)i : rem);
         HIPM(hipSetDevice(m->dev[i]));
         hipStream_t st = (hipStream_t)gpsacq_stream(m->eng[i]);
-        if (nbytes > m->bits_cap[i]) {
-            if (m->d_bits[i]) HIPM(hipFree(m->d_bits[i]));
-            m->d_bits[i] = nullptr;
-            HIPM(hipMalloc((void**)&m->d_bits[i], nbytes));
-            m->bits_cap[i] = nbytes;
-        }
-        if (n_tasks > m->task_cap[i]) {
-            for (void** p : {(void**)&m->d_tasks[i], (void**)&m->d_peaks[i], (void**)&m->d_keys[i]}) {
-                if (*p) HIPM(hipFree(*p));
-                *p = nullptr;
-            }
-            HIPM(hipMalloc((void**)&m->d_tasks[i], n_tasks * sizeof(Task)));
-            HIPM(hipMalloc((void**)&m->d_peaks[i], n_tasks * sizeof(Peak)));
-            HIPM(hipMalloc((void**)&m->d_keys[i], n_tasks * sizeof(unsigned long long)));
-            m->task_cap[i] = n_tasks;
-        }
+        if (int rc = grow_dev(m, i, nbytes, n_tasks)) return rc;
         if (cnt > 0) {
             HIPM(hipMemcpyAsync(m->d_bits[i], bits, nbytes, hipMemcpyHostToDevice, st));
             HIPM(hipMemcpyAsync(m->d_tasks[i], tasks, n_tasks * sizeof(Task), hipMemcpyHostToDevice, st));
@@ -194,16 +248,7 @@ extern "C" int gpsacq_multi_search_grid(gpsacq_multi* m, const uint8_t* bits, si
             HIPM(hipMemsetAsync(m->d_keys[i], 0, n_tasks * sizeof(unsigned long long), st));  // key 0 = "nothing found": neutral for MAX
         }
     }
-    // the path's one collective: all-reduce(MAX) of n_tasks 64-bit keys across the devices' communicators
-    NCCLM(g_rccl.GroupStart());
-    for (size_t i = 0; i < n; ++i) {
-        ncclResult_t r = g_rccl.AllReduce(m->d_keys[i], m->d_keys[i], n_tasks, ncclUint64, ncclMax, m->comm[i], (hipStream_t)gpsacq_stream(m->eng[i]));
-        if (r != ncclSuccess) {
-            (void)g_rccl.GroupEnd();
-            return failf(GPSACQ_ERR_DEVICE, "ncclAllReduce on device %d: %s", m->dev[i], g_rccl.GetErrorString(r));
-        }
-    }
-    NCCLM(g_rccl.GroupEnd());
+    if (int rc = allreduce_keys(m, m->d_keys, n_tasks)) return rc;
     std::vector<unsigned long long> keys(n_tasks);
     HIPM(hipSetDevice(m->dev[0]));
     HIPM(hipMemcpyAsync(keys.data(), m->d_keys[0], n_tasks * sizeof(unsigned long long), hipMemcpyDeviceToHost, (hipStream_t)gpsacq_stream(m->eng[0])));
@@ -211,15 +256,79 @@ extern "C" int gpsacq_multi_search_grid(gpsacq_multi* m, const uint8_t* bits, si
         HIPM(hipSetDevice(m->dev[i]));
         HIPM(hipStreamSynchronize((hipStream_t)gpsacq_stream(m->eng[i])));
     }
-    for (size_t t = 0; t < n_tasks; ++t) {
-        const unsigned long long k = keys[t];
-        const uint32_t sb = (uint32_t)(k >> 32);
-        float snr;
-        memcpy(&snr, &sb, sizeof snr);
-        peaks[t].snr = snr;
-        peaks[t].lo_shift = k ? (int32_t)(0xFFFF - ((k >> 16) & 0xFFFF)) - kmax : 0;
-        peaks[t].ca_shift = (int32_t)(k & 0xFFFF);
-        peaks[t].max_pwr = 0.f;  // not carried by the key
+    for (size_t t = 0; t < n_tasks; ++t) unpack_key(keys[t], kmax, &peaks[t]);
+    return GPSACQ_OK;
+}
+
+extern "C" int gpsacq_multi_search_grid(gpsacq_multi* m, const uint8_t* bits, size_t n_blocks, size_t stride, const gpsacq_task* tasks,
+                                        size_t n_tasks, gpsacq_peak* peaks) {
+    if (!m || !bits || !tasks || !peaks || n_blocks == 0 || n_tasks == 0 || stride < 5000) return failf(GPSACQ_ERR_ARG, "gpsacq_multi_search_grid: bad argument");
+    for (size_t t = 0; t < n_tasks; ++t)
+        if (tasks[t].block < 0 || (size_t)tasks[t].block >= n_blocks || tasks[t].prn < 0 || tasks[t].prn >= GPSACQ_NUM_SATS)
+            return failf(GPSACQ_ERR_ARG, "task %zu = (block %d, prn %d) out of range", t, tasks[t].block, tasks[t].prn);
+    DeviceGuard guard;
+    // the slabs are set through each engine's Doppler window: remember the windows and put them back whatever happens
+    std::vector<gpsacq_info> before(m->eng.size());
+    for (size_t i = 0; i < m->eng.size(); ++i) (void)gpsacq_get_info(m->eng[i], &before[i]);
+    const int rc = search_grid_impl(m, bits, n_blocks, stride, tasks, n_tasks, peaks);
+    std::string err = rc ? gpsacq_last_error() : "";
+    if (rc) drain(m);  // nothing of a failed call keeps running on any device
+    for (size_t i = 0; i < m->eng.size(); ++i) (void)gpsacq_set_doppler_window(m->eng[i], before[i].first_doppler, before[i].num_doppler);
+    if (rc) return acq::set_last_error(rc, err.c_str());
+    return GPSACQ_OK;
+}
+
+// ---- the block decomposition: whole runs of the reference schedule split over the devices -------------------------------
+static int search_blocks_impl(gpsacq_multi* m, const uint8_t* bits, size_t n_runs, size_t stride, gpsacq_peak* peaks, gpsacq_peak* best) {
+    const size_t n = m->eng.size();
+    const int first = m->info.first_doppler_total, total = m->info.num_doppler_total, kmax = -first;
+    std::vector<unsigned long long*> prn_keys(n, nullptr);
+    for (size_t i = 0; i < n; ++i) {
+        // contiguous, balanced range of whole runs for device i; a run starts at PRN index 0, so the reference schedule
+        // (block t <-> PRN t % 32) holds inside every range
+        const size_t base = n_runs / n, rem = n_runs % n;
+        const size_t cnt = base + (i < rem ? 1 : 0), off = i * base + (i < rem ? i : rem);
+        const size_t nblk = cnt * GPSACQ_NUM_SATS;
+        HIPM(hipSetDevice(m->dev[i]));
+        hipStream_t st = (hipStream_t)gpsacq_stream(m->eng[i]);
+        const size_t nbytes = nblk ? (nblk - 1) * stride + GPSACQ_BLOCK_BYTES : 0;
+        if (int rc = grow_dev(m, i, std::max(nbytes, (size_t)1), std::max(nblk, (size_t)1))) return rc;
+        prn_keys[i] = m->d_keys[i] + m->task_cap[i];  // the 32 per-PRN keys live behind the per-task keys
+        if (nblk > 0) {
+            HIPM(hipMemcpyAsync(m->d_bits[i], bits + off * GPSACQ_NUM_SATS * stride, nbytes, hipMemcpyHostToDevice, st));
+            if (int rc = gpsacq_set_doppler_window(m->eng[i], first, total)) return rc;  // every device scans the whole grid
+            if (int rc = gpsacq_search_device(m->eng[i], m->d_bits[i], nblk, stride, nullptr, nblk, nullptr, m->d_peaks[i], 0)) return rc;
+            launch_pack_keys(m->d_peaks[i], m->d_keys[i], (int)nblk, kmax, st);
+            launch_prn_best(m->d_keys[i], (int)nblk, prn_keys[i], st);
+            HIPM(hipGetLastError());
+            if (peaks) HIPM(hipMemcpyAsync(peaks + off * GPSACQ_NUM_SATS, m->d_peaks[i], nblk * sizeof(Peak), hipMemcpyDeviceToHost, st));
+        } else {
+            HIPM(hipMemsetAsync(prn_keys[i], 0, GPSACQ_NUM_SATS * sizeof(unsigned long long), st));  // neutral for MAX
+        }
     }
+    if (int rc = allreduce_keys(m, prn_keys, GPSACQ_NUM_SATS)) return rc;
+    unsigned long long keys[GPSACQ_NUM_SATS];
+    HIPM(hipSetDevice(m->dev[0]));
+    HIPM(hipMemcpyAsync(keys, prn_keys[0], sizeof keys, hipMemcpyDeviceToHost, (hipStream_t)gpsacq_stream(m->eng[0])));
+    for (size_t i = 0; i < n; ++i) {
+        HIPM(hipSetDevice(m->dev[i]));
+        HIPM(hipStreamSynchronize((hipStream_t)gpsacq_stream(m->eng[i])));
+    }
+    if (best)
+        for (int sv = 0; sv < GPSACQ_NUM_SATS; ++sv) unpack_key(keys[sv], kmax, &best[sv]);
+    return GPSACQ_OK;
+}
+
+extern "C" int gpsacq_multi_search_blocks(gpsacq_multi* m, const uint8_t* bits, size_t n_runs, size_t stride, gpsacq_peak* peaks, gpsacq_peak* best) {
+    if (!m || !bits || n_runs == 0 || stride < (size_t)GPSACQ_BLOCK_BYTES || (!peaks && !best))
+        return failf(GPSACQ_ERR_ARG, "gpsacq_multi_search_blocks: bad argument (whole runs of 32 blocks, stride >= 5120)");
+    DeviceGuard guard;
+    std::vector<gpsacq_info> before(m->eng.size());
+    for (size_t i = 0; i < m->eng.size(); ++i) (void)gpsacq_get_info(m->eng[i], &before[i]);
+    const int rc = search_blocks_impl(m, bits, n_runs, stride, peaks, best);
+    std::string err = rc ? gpsacq_last_error() : "";
+    if (rc) drain(m);
+    for (size_t i = 0; i < m->eng.size(); ++i) (void)gpsacq_set_doppler_window(m->eng[i], before[i].first_doppler, before[i].num_doppler);
+    if (rc) return acq::set_last_error(rc, err.c_str());
     return GPSACQ_OK;
 }

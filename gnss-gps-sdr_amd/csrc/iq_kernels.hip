@@ -70,28 +70,7 @@ __global__ __launch_bounds__(256) void k_iq_to_bits(IqArgs a) {
             raw[(s - s0) >> 1] |= pair << (16 * ((s - s0) & 1));
         }
     }
-    unsigned out = 0;
-#pragma unroll
-    for (int k = 0; k < 8; ++k) {
-        const size_t n = s0 + k;
-        const unsigned pair = (raw[k >> 1] >> (16 * (k & 1))) & 0xffffu;
-        double yi, yq;
-        if (a.is_signed) { yi = (double)(int8_t)(pair & 0xff); yq = (double)(int8_t)(pair >> 8); }
-        else { yi = (double)(int)(pair & 0xff) - 128.0; yq = (double)(int)(pair >> 8) - 128.0; }
-        yi -= a.mean_i;
-        yq -= a.mean_q;
-        double r = yi;
-        if (a.mix) {
-            // theta in the operation order of proc_rtl_bin_for_gps.m:41: ((((2*pi)*fc)*n)*(1/fs))
-            const double th = (a.two_pi_fc * (double)n) * a.inv_fs;
-            double sn, cs;
-            sincos(th, &sn, &cs);
-            r = yi * cs - yq * sn;
-        }
-        // (1 - sign(r)) / 2 written as ubit1: r > 0 -> 0, r < 0 -> 1, r == 0 -> 0.5 which fwrite rounds to 1
-        const unsigned bit = (n < a.n_samples) ? (r > 0.0 ? 0u : 1u) : 0u;
-        out |= bit << k;
-    }
+    const unsigned out = iq8_byte(raw, a.first_sample + s0, a.first_sample + a.n_samples, a.conv);
     a.bits[byte] = (uint8_t)out;
 }
 

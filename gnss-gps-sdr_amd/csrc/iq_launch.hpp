@@ -4,17 +4,16 @@
 #include <stddef.h>
 #include <stdint.h>
 
+#include "iq_convert.hpp"
+
 namespace acq {
 
 struct IqArgs {
     const uint8_t* iq;   // interleaved I,Q bytes, 2 per sample (16-byte aligned)
     uint8_t* bits;       // ceil(n_samples / 8) output bytes, LSB first
     size_t n_samples;
-    int is_signed;       // 0: uint8 offset 128 (rtl-sdr), 1: int8 (HackRF)
-    int mix;             // 0: real part only, 1: real(y * exp(i theta))
-    double mean_i, mean_q;
-    double two_pi_fc;    // (2*pi)*fc
-    double inv_fs;       // 1/fs
+    size_t first_sample; // capture sample index of iq[0] (the mixer's n)
+    IqConv conv;         // format, mean, mixer (iq_convert.hpp)
 };
 
 void launch_iq_sums(const uint8_t* iq, size_t n_samples, int is_signed, unsigned long long* sums, hipStream_t s);

@@ -2,18 +2,34 @@
 // (c/search_offline.cpp:74-117,205-292) on top of the gpsacq C ABI.  The file loop, the
 // threshold and the report format are host work; every correlation runs on the GPU(s).
 //
+// SearchTask() is a pipeline: batches of whole runs are read straight into pinned staging buffers
+// (gpsacq_pipe_buffer), handed to the engine(s) without waiting (gpsacq_pipe_submit: upload on a second
+// stream, search behind it) and collected one batch later, so the fread of batch k+1 and the printf of
+// batch k-1 overlap the search of batch k.  The first batches are short (1, 2, 4, ... runs) so that the
+// first run's report leaves as early as the reference's does; every run is printed and flushed as soon
+// as its batch lands (the reference prints run by run, :264-287).
+//
 // Environment (the reference has no options besides its three globals):
 //   GPSACQ_DEVICE=<n>       HIP device ordinal (default 0)
-//   GPSACQ_DEVICES=a,b,..   several devices: each batch of runs is split into contiguous ranges,
-//                           one host thread and one engine per device (runs are independent; the
-//                           report is printed in file order).  Overrides GPSACQ_DEVICE.
+//   GPSACQ_DEVICES=a,b,..   several devices: each batch of runs is split into contiguous ranges, one engine
+//                           per device, all fed from this one thread (submits do not block; runs are
+//                           independent; the report is printed in file order).  Overrides GPSACQ_DEVICE.
 //   GPSACQ_REF_QUIRKS=1     reproduce the reference's fwd_buf overrun on PRN index 0
-//   GPSACQ_BATCH_RUNS=<n>   runs (32 blocks each) searched per device per batch (default 64)
+//   GPSACQ_BATCH_RUNS=<n>   most runs (32 blocks each) searched per device per batch (default 64; 16 for IQ input)
+//   GPSACQ_INPUT=bits|iq_u8|iq_s8   the capture file's format: gps_test's own 1-bit stream (default), or the 8-bit IQ
+//                           file of an rtl-sdr (uint8, offset 128) / HackRF (int8) -- README.md:83-115's flow without the
+//                           MATLAB step (proc_rtl_bin_for_gps.m, proc_hackrf_bin_for_gps.m): mean removal, mixer and
+//                           sign happen on the GPU inside the forward transform
+//   GPSACQ_MIX_HZ=<f>       IQ input: mix the baseband capture up to this real IF first (proc_rtl_bin_for_gps.m:31-47,
+//                           fc = 0.62e6 there); 0 / unset: take the real part (:12-26).  FC should name the same IF.
+//   GPSACQ_IQ_KEEP_DC=1     IQ input: skip `y = y - mean(y)` (the scripts always remove it)
+//   GPSACQ_TRACE=1          wall-clock split of SearchInit / SearchTask on stderr
+#include <chrono>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <deque>
 #include <string>
-#include <thread>
 #include <vector>
 
 #include "../../include/gps_search.h"
@@ -22,6 +38,10 @@
 static std::vector<gpsacq_engine *> g_engines;
 static bool g_busy[GPSACQ_NUM_SATS];
 static int g_status = 0;  // status of the last SearchTask(): 0, or the gpsacq error that stopped it (SearchStatus())
+static double g_init_ms = 0;
+
+typedef std::chrono::steady_clock Clock;
+static double ms_since(Clock::time_point t0) { return std::chrono::duration<double, std::milli>(Clock::now() - t0).count(); }
 
 static int env_int(const char *name, int dflt) {
     const char *v = getenv(name);
@@ -51,6 +71,7 @@ void SearchFree() {
 }
 
 int SearchInit() {
+    const Clock::time_point t0 = Clock::now();
     SearchFree();
     for (int dev : device_list()) {
         gpsacq_params p;
@@ -68,6 +89,7 @@ int SearchInit() {
         }
         g_engines.push_back(e);
     }
+    g_init_ms = ms_since(t0);
     return 0;
 }
 
@@ -79,8 +101,45 @@ int SearchCode(int sv, int g1) { return gpsacq_search_code(sv, g1); }
 
 int SearchStatus() { return g_status; }
 
+// the five lines + blank of one run (:264-287)
+static void print_run(int run, const gpsacq_peak *pk) {
+    int hit[GPSACQ_NUM_SATS], hit_count = 0;
+    for (int sv = 0; sv < GPSACQ_NUM_SATS; sv++)
+        if (!(pk[sv].snr < 25)) hit[hit_count++] = sv;  // :248
+    printf("%2d satellite: ", run);
+    for (int i = 0; i < hit_count; i++) printf("%5d ", hit[i]);
+    printf("\n");
+    printf("%2d SNR(>=25): ", run);
+    for (int i = 0; i < hit_count; i++) printf("%5.1f ", pk[hit[i]].snr);
+    printf("\n");
+    printf("%2d  lo_shift: ", run);
+    for (int i = 0; i < hit_count; i++) printf("%5d ", pk[hit[i]].lo_shift);
+    printf("\n");
+    printf("%2d  ca_shift: ", run);
+    for (int i = 0; i < hit_count; i++) printf("%5d ", pk[hit[i]].ca_shift);
+    printf("\n");
+    for (int sv = 0; sv < GPSACQ_NUM_SATS; sv++) printf("%2.0f ", pk[sv].snr);
+    printf("\n\n");
+}
+
+static void fail_with(const char *what) {
+    fprintf(stderr, "gpsacq: %s%s\n", what, gpsacq_last_error());
+    g_status = GPSACQ_ERR_DEVICE;
+}
+
+static size_t read_fully(FILE *fp, unsigned char *dst, size_t want) {
+    size_t got = 0;
+    while (got < want) {
+        size_t r = fread(dst + got, 1, want - got, fp);
+        if (r == 0) break;
+        got += r;
+    }
+    return got;
+}
+
 void SearchTask(char *filename_1bit_bin) {
     g_status = 0;
+    const Clock::time_point t_start = Clock::now();
     FILE *fp = fopen(filename_1bit_bin, "rb");
     if (fp == NULL) {
         printf("can not open file!\n");
@@ -92,73 +151,153 @@ void SearchTask(char *filename_1bit_bin) {
         g_status = GPSACQ_ERR_ARG;
         return;
     }
-    const size_t run_bytes = (size_t)GPSACQ_NUM_SATS * GPSACQ_BLOCK_BYTES;
+    const bool trace = env_int("GPSACQ_TRACE", 0) != 0;
+    double ms_sums = 0, ms_read = 0, ms_submit = 0, ms_wait = 0, ms_print = 0;
+
+    // ---- input format -------------------------------------------------------------------------------------------
+    const char *fmt = getenv("GPSACQ_INPUT");
+    bool iq = false;
+    gpsacq_iq8_input iqin;
+    memset(&iqin, 0, sizeof iqin);
+    if (fmt && *fmt && strcmp(fmt, "bits") != 0) {
+        if (strcmp(fmt, "iq_u8") == 0) iqin.format = GPSACQ_IQ_U8;
+        else if (strcmp(fmt, "iq_s8") == 0) iqin.format = GPSACQ_IQ_S8;
+        else {
+            fprintf(stderr, "gpsacq: GPSACQ_INPUT=%s is not one of bits, iq_u8, iq_s8\n", fmt);
+            fclose(fp);
+            g_status = GPSACQ_ERR_ARG;
+            return;
+        }
+        iq = true;
+        const char *mix = getenv("GPSACQ_MIX_HZ");
+        iqin.mix_hz = (mix && *mix) ? atof(mix) : 0.0;
+        iqin.fs = FS;
+        iqin.remove_dc = env_int("GPSACQ_IQ_KEEP_DC", 0) ? 0 : 1;
+    }
+    const size_t block_bytes = iq ? (size_t)GPSACQ_BLOCK_BYTES * 16 : (size_t)GPSACQ_BLOCK_BYTES;  // one Sample(): 40960 samples
+    const size_t run_bytes = (size_t)GPSACQ_NUM_SATS * block_bytes;
     const size_t n_dev = g_engines.size();
-    const int batch_env = env_int("GPSACQ_BATCH_RUNS", 64);
-    const size_t batch_runs = (size_t)(batch_env > 0 ? batch_env : 64) * n_dev;
-    std::vector<unsigned char> buf(run_bytes * batch_runs);
-    std::vector<gpsacq_peak> peaks((size_t)GPSACQ_NUM_SATS * batch_runs);
-    int run_count = 0;
-    for (;;) {
-        size_t got = 0;
-        while (got < buf.size()) {
-            size_t r = fread(buf.data() + got, 1, buf.size() - got, fp);
-            if (r == 0) break;
-            got += r;
-        }
-        // a run is complete when all 32 of its Sample() calls got their 10 x 512 bytes (:135-140,239-244)
-        const size_t runs = got / run_bytes;
-        if (runs > 0) {
-            // contiguous run ranges, one per device; a run always starts at PRN index 0, so the
-            // reference schedule (block t <-> PRN t % 32) holds inside every range
-            std::vector<int> rcs(n_dev, GPSACQ_OK);
-            std::vector<std::string> errs(n_dev);
-            std::vector<std::thread> workers;
-            for (size_t d = 0; d < n_dev; d++) {
-                const size_t first = runs * d / n_dev, last = runs * (d + 1) / n_dev;
-                if (last == first) continue;
-                auto job = [&, d, first, last]() {
-                    const size_t nblk = (last - first) * GPSACQ_NUM_SATS;
-                    rcs[d] = gpsacq_search(g_engines[d], buf.data() + first * run_bytes, nblk, GPSACQ_BLOCK_BYTES, NULL, nblk,
-                                           NULL, peaks.data() + first * GPSACQ_NUM_SATS);
-                    if (rcs[d] != GPSACQ_OK) errs[d] = gpsacq_last_error();
-                };
-                if (n_dev == 1) job();
-                else workers.emplace_back(job);
-            }
-            for (std::thread &w : workers) w.join();
-            for (size_t d = 0; d < n_dev; d++)
-                if (rcs[d] != GPSACQ_OK) {  // a library function does not exit(): report, stop, leave the status for the caller
-                    fprintf(stderr, "gpsacq: %s\n", errs[d].c_str());
-                    g_status = rcs[d];
+    // per device per batch; an IQ run is 16 times the bytes of a 1-bit run (2.6 MB), so fewer of them fill a staging buffer
+    const int batch_dflt = iq ? 16 : 64, batch_env = env_int("GPSACQ_BATCH_RUNS", batch_dflt);
+    const size_t max_runs = (size_t)(batch_env > 0 ? batch_env : batch_dflt);
+
+    if (iq) {
+        // `y = y - mean(y)` is the mean of the WHOLE capture (proc_rtl_bin_for_gps.m:17): one pass for the two integer sums
+        const Clock::time_point t0 = Clock::now();
+        fseek(fp, 0, SEEK_END);
+        const long long fsize = ftell(fp);
+        fseek(fp, 0, SEEK_SET);
+        iqin.total_samples = (uint64_t)(fsize / 2);
+        if (iqin.remove_dc && iqin.total_samples > 0) {
+            int64_t sums[2] = {0, 0};
+            std::vector<unsigned char> chunk((size_t)64 << 20);
+            uint64_t left = iqin.total_samples;
+            while (left > 0) {
+                const size_t want = (size_t)(left * 2 < chunk.size() ? left * 2 : chunk.size());
+                const size_t got = read_fully(fp, chunk.data(), want);
+                if (got < 2) break;
+                if (gpsacq_iq8_accumulate_sums(g_engines[0], chunk.data(), got / 2, iqin.format, sums) != GPSACQ_OK) {
+                    fail_with("");
+                    fclose(fp);
+                    return;
                 }
-            if (g_status != 0) break;
-            for (size_t r = 0; r < runs; r++, run_count++) {
-                const gpsacq_peak *pk = &peaks[r * GPSACQ_NUM_SATS];
-                int hit[GPSACQ_NUM_SATS], hit_count = 0;
-                for (int sv = 0; sv < GPSACQ_NUM_SATS; sv++)
-                    if (!(pk[sv].snr < 25)) hit[hit_count++] = sv;  // :248
-                printf("%2d satellite: ", run_count);
-                for (int i = 0; i < hit_count; i++) printf("%5d ", hit[i]);
-                printf("\n");
-                printf("%2d SNR(>=25): ", run_count);
-                for (int i = 0; i < hit_count; i++) printf("%5.1f ", pk[hit[i]].snr);
-                printf("\n");
-                printf("%2d  lo_shift: ", run_count);
-                for (int i = 0; i < hit_count; i++) printf("%5d ", pk[hit[i]].lo_shift);
-                printf("\n");
-                printf("%2d  ca_shift: ", run_count);
-                for (int i = 0; i < hit_count; i++) printf("%5d ", pk[hit[i]].ca_shift);
-                printf("\n");
-                for (int sv = 0; sv < GPSACQ_NUM_SATS; sv++) printf("%2.0f ", pk[sv].snr);
-                printf("\n\n");
+                left -= got / 2;
+                if (got < want) break;
             }
-            fflush(stdout);  // the reference prints run by run; here a batch of runs at a time
+            iqin.mean_i = (double)sums[0] / (double)iqin.total_samples;  // exact sums; MATLAB's mean() of integer-valued doubles
+            iqin.mean_q = (double)sums[1] / (double)iqin.total_samples;
+            fseek(fp, 0, SEEK_SET);
         }
-        if (got < buf.size()) {
-            printf("run out of file!\n");
-            break;
+        ms_sums = ms_since(t0);
+    }
+
+    // ---- the pipeline -------------------------------------------------------------------------------------------
+    struct Batch {
+        int slot;
+        std::vector<size_t> runs;  // per device
+    };
+    std::deque<Batch> inflight;
+    int run_count = 0, slot = 0;
+    size_t ramp = 1;  // runs per device of the next batch: 1, 2, 4, ... max_runs
+    uint64_t sample_pos = 0;
+    bool eof = false;
+
+    auto drain_one = [&]() -> bool {  // collect + print the oldest batch
+        Batch b = inflight.front();
+        inflight.pop_front();
+        for (size_t d = 0; d < n_dev; d++) {
+            if (b.runs[d] == 0) continue;
+            const gpsacq_peak *pk = nullptr;
+            size_t n = 0;
+            Clock::time_point t0 = Clock::now();
+            if (gpsacq_pipe_collect(g_engines[d], b.slot, &pk, &n) != GPSACQ_OK) {
+                fail_with("");
+                return false;
+            }
+            ms_wait += ms_since(t0);
+            t0 = Clock::now();
+            for (size_t r = 0; r < b.runs[d]; r++, run_count++) print_run(run_count, pk + r * GPSACQ_NUM_SATS);
+            fflush(stdout);
+            ms_print += ms_since(t0);
         }
+        return true;
+    };
+
+    while (!eof && g_status == 0) {
+        Batch b;
+        b.slot = slot;
+        b.runs.assign(n_dev, 0);
+        size_t total = 0;
+        for (size_t d = 0; d < n_dev && !eof; d++) {
+            const size_t want = ramp * run_bytes;
+            unsigned char *buf = gpsacq_pipe_buffer(g_engines[d], slot, max_runs * run_bytes);
+            if (!buf) {
+                fail_with("");
+                break;
+            }
+            Clock::time_point t0 = Clock::now();
+            const size_t got = read_fully(fp, buf, want);
+            ms_read += ms_since(t0);
+            if (got < want) eof = true;
+            // a run is complete when all 32 of its Sample() calls got their 10 x 512 bytes (:135-140,239-244)
+            const size_t runs = got / run_bytes;
+            if (runs == 0) continue;
+            t0 = Clock::now();
+            iqin.first_sample = sample_pos;
+            const int rc = gpsacq_pipe_submit(g_engines[d], slot, runs * GPSACQ_NUM_SATS, block_bytes, iq ? &iqin : NULL);
+            ms_submit += ms_since(t0);
+            if (rc != GPSACQ_OK) {  // a library function does not exit(): report, stop, leave the status for the caller
+                fprintf(stderr, "gpsacq: %s\n", gpsacq_last_error());
+                g_status = rc;
+                break;
+            }
+            sample_pos += (uint64_t)runs * GPSACQ_NUM_SATS * GPSACQ_BLOCK_BYTES * 8;
+            b.runs[d] = runs;
+            total += runs;
+        }
+        if (total > 0) inflight.push_back(b);
+        if (g_status != 0) break;
+        // keep one batch in flight while the next is read, unless the file is finished
+        while (inflight.size() > (eof ? 0u : 1u))
+            if (!drain_one()) break;
+        slot = (slot + 1) % GPSACQ_PIPE_SLOTS;
+        if (ramp < max_runs) ramp = ramp * 2 < max_runs ? ramp * 2 : max_runs;
+    }
+    if (g_status != 0) {
+        // finish what is in flight so that no search outlives the call, print nothing more
+        while (!inflight.empty()) {
+            Batch b = inflight.front();
+            inflight.pop_front();
+            for (size_t d = 0; d < n_dev; d++)
+                if (b.runs[d]) (void)gpsacq_pipe_collect(g_engines[d], b.slot, NULL, NULL);
+        }
+    } else {
+        printf("run out of file!\n");
     }
     fclose(fp);
+    if (trace)
+        fprintf(stderr,
+                "gpsacq trace: SearchInit %.1f ms | SearchTask %.1f ms = mean pass %.1f + read %.1f + submit %.1f + wait for GPU %.1f + report %.1f "
+                "(+ overlap); %d runs, %zu device(s), input %s\n",
+                g_init_ms, ms_since(t_start), ms_sums, ms_read, ms_submit, ms_wait, ms_print, run_count, n_dev, iq ? fmt : "bits");
 }

@@ -50,6 +50,11 @@ class Handoff(ctypes.Structure):
                 ("ca_rate", ctypes.c_uint32), ("ca_shift", ctypes.c_int32), ("ca_pause", ctypes.c_uint32)]
 
 
+class Iq8Input(ctypes.Structure):
+    _fields_ = [("format", ctypes.c_int32), ("remove_dc", ctypes.c_int32), ("mean_i", ctypes.c_double), ("mean_q", ctypes.c_double),
+                ("mix_hz", ctypes.c_double), ("fs", ctypes.c_double), ("first_sample", ctypes.c_uint64), ("total_samples", ctypes.c_uint64)]
+
+
 class Sat(ctypes.Structure):
     _fields_ = [("prn", ctypes.c_int32), ("amplitude", ctypes.c_float), ("doppler_hz", ctypes.c_double),
                 ("code_phase_samples", ctypes.c_double), ("carrier_phase_cycles", ctypes.c_double)]
@@ -58,7 +63,9 @@ class Sat(ctypes.Structure):
 EXPORTS = ["gpsacq_generate", "gpsacq_generate_device", "gpsacq_generate_sig", "gpsacq_sig_bytes", "gpsacq_handoff", "gpsacq_iq8_to_bits", "gpsacq_iq8_to_bits_device", "gpsacq_create", "gpsacq_destroy", "gpsacq_last_error", "gpsacq_get_info", "gpsacq_search",
            "gpsacq_search_device", "gpsacq_set_doppler_window", "gpsacq_set_doppler_step", "gpsacq_set_noncoherent", "gpsacq_set_creep_compensation", "gpsacq_aligned_stride", "gpsacq_synchronize", "gpsacq_last_timing", "gpsacq_timing_ago", "gpsacq_stream", "gpsacq_search_code",
            "gpsacq_sample_spectrum", "gpsacq_code_spectrum", "gpsacq_multi_create", "gpsacq_multi_destroy",
-           "gpsacq_multi_set_doppler_step", "gpsacq_multi_get_info", "gpsacq_multi_search_grid"]
+           "gpsacq_multi_set_doppler_step", "gpsacq_multi_get_info", "gpsacq_multi_search_grid", "gpsacq_multi_search_blocks",
+           "gpsacq_pipe_buffer", "gpsacq_pipe_submit", "gpsacq_pipe_collect", "gpsacq_search_iq8", "gpsacq_search_iq8_device",
+           "gpsacq_iq8_accumulate_sums", "gpsacq_handoff_step", "gpsacq_handoff_engine"]
 
 _lib = None
 
@@ -154,6 +161,24 @@ def load_library(path=None):
     lib.gpsacq_multi_get_info.restype = ctypes.c_int
     lib.gpsacq_multi_search_grid.argtypes = [vp, vp, sz, sz, vp, sz, vp]
     lib.gpsacq_multi_search_grid.restype = ctypes.c_int
+    lib.gpsacq_multi_search_blocks.argtypes = [vp, vp, sz, sz, vp, vp]
+    lib.gpsacq_multi_search_blocks.restype = ctypes.c_int
+    lib.gpsacq_pipe_buffer.argtypes = [vp, ctypes.c_int, sz]
+    lib.gpsacq_pipe_buffer.restype = ctypes.c_void_p
+    lib.gpsacq_pipe_submit.argtypes = [vp, ctypes.c_int, sz, sz, ctypes.POINTER(Iq8Input)]
+    lib.gpsacq_pipe_submit.restype = ctypes.c_int
+    lib.gpsacq_pipe_collect.argtypes = [vp, ctypes.c_int, ctypes.POINTER(vp), ctypes.POINTER(sz)]
+    lib.gpsacq_pipe_collect.restype = ctypes.c_int
+    lib.gpsacq_search_iq8.argtypes = [vp, ctypes.POINTER(Iq8Input), vp, sz, sz, vp, sz, vp, vp]
+    lib.gpsacq_search_iq8.restype = ctypes.c_int
+    lib.gpsacq_search_iq8_device.argtypes = [vp, ctypes.POINTER(Iq8Input), vp, sz, sz, vp, sz, vp, vp, ctypes.c_int]
+    lib.gpsacq_search_iq8_device.restype = ctypes.c_int
+    lib.gpsacq_iq8_accumulate_sums.argtypes = [vp, vp, sz, ctypes.c_int, ctypes.POINTER(ctypes.c_int64)]
+    lib.gpsacq_iq8_accumulate_sums.restype = ctypes.c_int
+    lib.gpsacq_handoff_step.argtypes = [vp, ctypes.c_double, ctypes.c_double, ctypes.c_double, ctypes.c_double, ctypes.POINTER(Handoff)]
+    lib.gpsacq_handoff_step.restype = ctypes.c_int
+    lib.gpsacq_handoff_engine.argtypes = [vp, vp, ctypes.c_double, ctypes.POINTER(Handoff)]
+    lib.gpsacq_handoff_engine.restype = ctypes.c_int
     if path is None:
         _lib = lib
     return lib
@@ -170,13 +195,15 @@ def _check(lib, rc):
         raise GpsAcqError(rc, lib.gpsacq_last_error().decode(errors="replace"))
 
 
-def handoff(peak, fc, fs, secs_since_sample=0.0):
-    """CHANNEL::Start()'s NCO set-up from a search hit (c/channel.cpp:134-163).  peak: a PEAK_DTYPE record."""
+def handoff(peak, fc, fs, secs_since_sample=0.0, step_hz=0.0):
+    """CHANNEL::Start()'s NCO set-up from a search hit (c/channel.cpp:134-163).  peak: a PEAK_DTYPE record.
+    step_hz: what one unit of lo_shift is worth -- 0 for the reference grid (FFT bins of fs/40000), else the engine's
+    doppler_step_hz after set_doppler_step() (Engine.handoff() passes it by itself)."""
     lib = load_library()
     pk = np.zeros(1, dtype=PEAK_DTYPE)
     pk[0] = peak
     h = Handoff()
-    _check(lib, lib.gpsacq_handoff(pk.ctypes.data_as(ctypes.c_void_p), float(fc), float(fs), float(secs_since_sample), ctypes.byref(h)))
+    _check(lib, lib.gpsacq_handoff_step(pk.ctypes.data_as(ctypes.c_void_p), float(fc), float(fs), float(step_hz), float(secs_since_sample), ctypes.byref(h)))
     return {k: getattr(h, k) for k, _ in Handoff._fields_}
 
 
@@ -195,6 +222,7 @@ class Engine:
         _check(self._lib, self._lib.gpsacq_create(ctypes.byref(prm), ctypes.byref(self._h)))
         self._refresh_info()
         self.fc, self.fs, self.max_fo = float(fc), float(fs), float(max_fo)
+        self._quirks = bool(ref_quirks)
 
     def _refresh_info(self):
         info = Info()
@@ -253,6 +281,72 @@ class Engine:
             self.close()
         except Exception:
             pass
+
+    def handoff(self, peak, secs_since_sample=0.0):
+        """Hand-off record of a hit of THIS engine: its fc, fs and current Doppler grid step."""
+        pk = np.zeros(1, dtype=PEAK_DTYPE)
+        pk[0] = peak
+        h = Handoff()
+        _check(self._lib, self._lib.gpsacq_handoff_engine(self._h, pk.ctypes.data_as(ctypes.c_void_p), float(secs_since_sample), ctypes.byref(h)))
+        return {k: getattr(h, k) for k, _ in Handoff._fields_}
+
+    # ---- 8-bit IQ capture searched directly (no 1-bit intermediate) -------------------------
+    @staticmethod
+    def iq8_input(signed=False, remove_dc=True, mean=(0.0, 0.0), mix_hz=0.0, fs=0.0, first_sample=0, total_samples=0):
+        return Iq8Input(1 if signed else 0, 1 if remove_dc else 0, float(mean[0]), float(mean[1]), float(mix_hz), float(fs),
+                        int(first_sample), int(total_samples))
+
+    def iq8_mean(self, iq, signed=False, chunk_samples=1 << 22):
+        """Complex mean of a whole 8-bit IQ capture as (mean_i, mean_q): exact integer sums on the device, in pieces."""
+        buf = np.ascontiguousarray(np.asarray(iq).view(np.uint8).ravel())
+        n = buf.size // 2
+        sums = (ctypes.c_int64 * 2)(0, 0)
+        for s0 in range(0, n, chunk_samples):
+            m = min(chunk_samples, n - s0)
+            part = buf[2 * s0:2 * (s0 + m)]
+            _check(self._lib, self._lib.gpsacq_iq8_accumulate_sums(self._h, part.ctypes.data_as(ctypes.c_void_p), m, 1 if signed else 0, sums))
+        return sums[0] / n, sums[1] / n
+
+    def search_iq8(self, iq, inp, tasks=None, stride=16 * BLOCK_BYTES, want_cells=True):
+        """Search interleaved 8-bit I,Q bytes directly (gpsacq_search_iq8): blocks `stride` bytes apart (81920 = the 40960
+        samples of one Sample() call).  inp: Engine.iq8_input(...)."""
+        buf = np.ascontiguousarray(np.asarray(iq).view(np.uint8).ravel())
+        need = 16 * (BLOCK_BYTES if self._quirks else 5000)
+        n_blocks = (buf.size - min(stride, need)) // stride + 1 if buf.size >= min(stride, need) else 0
+        if n_blocks <= 0:
+            raise ValueError("capture shorter than one block")
+        if tasks is None:
+            n_tasks, tptr = n_blocks, None
+        else:
+            t = np.ascontiguousarray(np.asarray(tasks, dtype=np.int32).reshape(-1, 2))
+            n_tasks, tptr = t.shape[0], t.ctypes.data_as(ctypes.c_void_p)
+        cells = np.zeros((n_tasks, self.num_doppler), dtype=CELL_DTYPE) if want_cells else None
+        peaks = np.zeros(n_tasks, dtype=PEAK_DTYPE)
+        _check(self._lib, self._lib.gpsacq_search_iq8(
+            self._h, ctypes.byref(inp), buf.ctypes.data_as(ctypes.c_void_p), n_blocks, stride, tptr, n_tasks,
+            cells.ctypes.data_as(ctypes.c_void_p) if want_cells else None, peaks.ctypes.data_as(ctypes.c_void_p)))
+        return cells, peaks
+
+    def search_iq8_device(self, d_iq_ptr, inp, n_blocks, d_peaks_ptr, stride=16 * BLOCK_BYTES, sync=True):
+        _check(self._lib, self._lib.gpsacq_search_iq8_device(self._h, ctypes.byref(inp), d_iq_ptr, n_blocks, stride, None, n_blocks,
+                                                             None, d_peaks_ptr, 1 if sync else 0))
+
+    # ---- pipelined host-buffer searches (gpsacq_pipe_*) --------------------------------------
+    def pipe_buffer(self, slot, nbytes):
+        """The slot's pinned staging buffer as a writable uint8 array of nbytes."""
+        ptr = self._lib.gpsacq_pipe_buffer(self._h, int(slot), int(nbytes))
+        if not ptr:
+            raise GpsAcqError(-1, self._lib.gpsacq_last_error().decode(errors="replace"))
+        return np.ctypeslib.as_array(ctypes.cast(ptr, ctypes.POINTER(ctypes.c_uint8)), shape=(int(nbytes),))
+
+    def pipe_submit(self, slot, n_blocks, stride=BLOCK_BYTES, iq=None):
+        _check(self._lib, self._lib.gpsacq_pipe_submit(self._h, int(slot), int(n_blocks), int(stride), ctypes.byref(iq) if iq is not None else None))
+
+    def pipe_collect(self, slot):
+        p, n = ctypes.c_void_p(), ctypes.c_size_t()
+        _check(self._lib, self._lib.gpsacq_pipe_collect(self._h, int(slot), ctypes.byref(p), ctypes.byref(n)))
+        arr = np.ctypeslib.as_array(ctypes.cast(p, ctypes.POINTER(ctypes.c_uint8)), shape=(n.value * PEAK_DTYPE.itemsize,))
+        return arr.view(PEAK_DTYPE).copy()
 
     # ---- host-buffer path ----------------------------------------------------------------
     def search(self, bits, tasks=None, stride=BLOCK_BYTES, want_cells=True, n_tasks=None):
@@ -385,6 +479,20 @@ class MultiEngine:
         _check(self._lib, self._lib.gpsacq_multi_search_grid(self._h, buf.ctypes.data_as(ctypes.c_void_p), n_blocks, stride,
                                                              t.ctypes.data_as(ctypes.c_void_p), t.shape[0], peaks.ctypes.data_as(ctypes.c_void_p)))
         return peaks
+
+    def search_blocks(self, bits, stride=BLOCK_BYTES):
+        """gpsacq_multi_search_blocks: whole runs of the reference schedule split over the devices.  Returns
+        (peaks[n_runs * 32] in file order, best[32] = per-PRN best after the all-reduce)."""
+        buf = np.ascontiguousarray(np.frombuffer(bits, dtype=np.uint8) if not isinstance(bits, np.ndarray) else bits.view(np.uint8))
+        n_blocks = (buf.size - BLOCK_BYTES) // stride + 1 if buf.size >= BLOCK_BYTES else 0
+        n_runs = n_blocks // NUM_SATS
+        if n_runs <= 0:
+            raise ValueError("capture shorter than one run of 32 blocks")
+        peaks = np.zeros(n_runs * NUM_SATS, dtype=PEAK_DTYPE)
+        best = np.zeros(NUM_SATS, dtype=PEAK_DTYPE)
+        _check(self._lib, self._lib.gpsacq_multi_search_blocks(self._h, buf.ctypes.data_as(ctypes.c_void_p), n_runs, stride,
+                                                               peaks.ctypes.data_as(ctypes.c_void_p), best.ctypes.data_as(ctypes.c_void_p)))
+        return peaks, best
 
     def close(self):
         if self._h:

@@ -15,8 +15,13 @@
  *                            for a batch of 5120-byte blocks (the body of the
  *                            SearchTask() loop, :239-246)
  *   gpsacq_search_device     same, capture already resident in HBM
+ *   gpsacq_pipe_*            same, batches in flight: the SearchTask() loop's fread of batch k+1 overlaps the search of batch k
+ *   gpsacq_search_iq8        same on an 8-bit IQ capture: what proc_rtl_bin_for_gps.m / proc_hackrf_bin_for_gps.m + gps_test
+ *                            do in two steps through a 1-bit file, fused into the forward transform
  *   gpsacq_set_doppler_step  the Doppler grid of Correlate()'s loop, :176,182 (finer or coarser than fs/40000)
  *   gpsacq_multi_search_grid the same Correlate() grid cut over several GPUs, peaks merged by one RCCL all-reduce
+ *   gpsacq_multi_search_blocks  the SearchTask() run loop (:237-262) cut over several GPUs by whole runs, per-PRN best
+ *                            peak merged by one RCCL all-reduce
  *   gpsacq_search_code       SearchCode()            c/search_offline.cpp:205-209
  *   gpsacq_iq8_to_bits       the MATLAB pre-processing that produces gps_test's input from an 8-bit IQ
  *                            capture: proc_rtl_bin_for_gps.m:12-26,31-47, proc_hackrf_bin_for_gps.m:7-19
@@ -149,6 +154,21 @@ GPSACQ_API int gpsacq_search(gpsacq_engine* e, const uint8_t* bits, size_t n_blo
 GPSACQ_API int gpsacq_search_device(gpsacq_engine* e, const void* d_bits, size_t n_blocks, size_t stride,
                          const void* d_tasks, size_t n_tasks, void* d_cells, void* d_peaks, int sync);
 /*
+ * Pipelined host-buffer searches on the reference schedule (task t = block t against PRN t % 32, the body of SearchTask()'s
+ * loop :237-262).  A slot owns a pinned host staging buffer, a device copy and a pinned peak array:
+ *   buf = gpsacq_pipe_buffer(e, slot, nbytes)      pinned buffer of >= nbytes (fread the batch straight into it); NULL on error
+ *   gpsacq_pipe_submit(e, slot, n_blocks, stride, iq)   upload on a second stream + search, returns at once (iq == NULL: 1-bit
+ *                                                  blocks `stride` bytes apart; else 8-bit IQ, see gpsacq_search_iq8)
+ *   gpsacq_pipe_collect(e, slot, &peaks, &n)       waits for THAT slot's search; peaks stay valid until its next submit
+ * Searches run in submit order.  With 2-3 slots the caller's read of batch k+1 and report of batch k-1 overlap batch k.
+ */
+#define GPSACQ_PIPE_SLOTS 3
+struct gpsacq_iq8_input;
+GPSACQ_API uint8_t* gpsacq_pipe_buffer(gpsacq_engine* e, int slot, size_t nbytes);
+GPSACQ_API int gpsacq_pipe_submit(gpsacq_engine* e, int slot, size_t n_blocks, size_t stride, const struct gpsacq_iq8_input* iq);
+GPSACQ_API int gpsacq_pipe_collect(gpsacq_engine* e, int slot, const gpsacq_peak** peaks, size_t* n_peaks);
+
+/*
  * Restrict the search to Doppler bins first_bin .. first_bin+n_bins-1 (within -dmax..+dmax).
  * Used to shard one block's PRN x Doppler grid over several GPUs (no reference equivalent: the
  * reference always scans the full range, :176).  cells rows then hold n_bins entries and
@@ -220,6 +240,32 @@ GPSACQ_API int gpsacq_iq8_to_bits_device(gpsacq_engine* e, const void* d_iq, siz
                               double mix_hz, double fs, void* d_bits_out, int sync);
 
 /*
+ * Search an 8-bit IQ capture directly: README.md:83-115's rtl-sdr / HackRF flow (MATLAB conversion to a 1-bit file, then
+ * gps_test on that file) as one call.  The forward transform stages each block from the IQ bytes -- mean removal, mixer,
+ * sign, LO quadrature mix and bit transpose in one pass -- so the 1-bit stream is never written; results are identical to
+ * gpsacq_iq8_to_bits() followed by gpsacq_search() (same per-sample arithmetic, csrc/iq_convert.hpp).  Block b starts
+ * `stride` bytes into `iq` (a multiple of 16, >= 80000; 81920 = the 40960 samples one Sample() call consumes) and its
+ * first 40000 samples are transformed.  With ref_quirks the stream is converted to bits first (the patch needs samples
+ * 40000..40959 as bits) -- same results, one more pass.
+ */
+typedef struct gpsacq_iq8_input {
+    int32_t format;          /* GPSACQ_IQ_U8 / GPSACQ_IQ_S8 */
+    int32_t remove_dc;       /* subtract (mean_i, mean_q) */
+    double mean_i, mean_q;   /* complex mean of the WHOLE capture in sample units (`y - mean(y)`, proc_rtl_bin_for_gps.m:17):
+                                integer sums / sample count; gpsacq_iq8_accumulate_sums() for a capture streamed in pieces */
+    double mix_hz;           /* 0: real part; else real(y * exp(2 pi i mix_hz n / fs))  (proc_rtl_bin_for_gps.m:41) */
+    double fs;               /* sampling rate of the mixer phase; <= 0: the engine's */
+    uint64_t first_sample;   /* capture sample index of the buffer's first sample: the mixer's n */
+    uint64_t total_samples;  /* samples in the whole capture (bits beyond it read 0); 0: every block handed over is complete */
+} gpsacq_iq8_input;
+GPSACQ_API int gpsacq_search_iq8(gpsacq_engine* e, const gpsacq_iq8_input* in, const void* iq, size_t n_blocks, size_t stride,
+                      const gpsacq_task* tasks, size_t n_tasks, gpsacq_cell* cells, gpsacq_peak* peaks);
+GPSACQ_API int gpsacq_search_iq8_device(gpsacq_engine* e, const gpsacq_iq8_input* in, const void* d_iq, size_t n_blocks, size_t stride,
+                             const void* d_tasks, size_t n_tasks, void* d_cells, void* d_peaks, int sync);
+/* adds the exact integer sums of I and Q (offset removed for GPSACQ_IQ_U8) over n_samples of a host buffer to sums[0..1] */
+GPSACQ_API int gpsacq_iq8_accumulate_sums(gpsacq_engine* e, const void* iq, size_t n_samples, int format, int64_t sums[2]);
+
+/*
  * Synthetic 1-bit real-IF capture generated on the device (the reference's gps_sig_gen.m writes one
  * noise-free PRN; this is the signal model of SURVEY.md section 8d): white Gaussian noise of standard
  * deviation noise_sigma plus, per satellite, amplitude * C/A chip * cos(2 pi ((fc + doppler)/fs m +
@@ -266,6 +312,11 @@ typedef struct {
                            per millisecond (the reference hard-codes 20000 / 10000 for its 10 MHz FPGA, :163) */
 } gpsacq_handoff_t;
 GPSACQ_API int gpsacq_handoff(const gpsacq_peak* peak, double fc, double fs, double secs_since_sample, gpsacq_handoff_t* out);
+/* gpsacq_handoff() reads lo_shift in FFT bins of fs / 40000 Hz -- the reference grid.  After gpsacq_set_doppler_step(), and
+ * for gpsacq_multi_search_grid() peaks, lo_shift counts grid points of gpsacq_info.doppler_step_hz: pass that step here
+ * (step_hz <= 0: FFT bins), or let the engine supply its own fc, fs and current step. */
+GPSACQ_API int gpsacq_handoff_step(const gpsacq_peak* peak, double fc, double fs, double step_hz, double secs_since_sample, gpsacq_handoff_t* out);
+GPSACQ_API int gpsacq_handoff_engine(const gpsacq_engine* e, const gpsacq_peak* peak, double secs_since_sample, gpsacq_handoff_t* out);
 
 /*
  * Single-process multi-GPU search of ONE capture's PRN x Doppler grid (BASELINE.json configs[4]; the reference is
@@ -284,6 +335,17 @@ GPSACQ_API int gpsacq_multi_set_doppler_step(gpsacq_multi* m, double step_hz);
 GPSACQ_API int gpsacq_multi_get_info(const gpsacq_multi* m, gpsacq_info* info, int32_t* n_devices);
 GPSACQ_API int gpsacq_multi_search_grid(gpsacq_multi* m, const uint8_t* bits, size_t n_blocks, size_t stride,
                              const gpsacq_task* tasks, size_t n_tasks, gpsacq_peak* peaks);
+/*
+ * The headline decomposition (BASELINE.json north_star) in one process: a capture of whole runs
+ * (32 blocks of `stride` >= 5120 bytes each, block b against PRN b % 32 -- the SearchTask() loop, c/search_offline.cpp:237-262)
+ * is cut into one contiguous range of runs per device; every device searches its runs over the full Doppler grid, reduces
+ * its peaks to the best per PRN as packed keys, and ONE ncclAllReduce(MAX, uint64) of 32 keys merges them.  Outputs, either
+ * may be NULL: peaks[n_runs * 32] -- every (run, PRN) peak in file order, what SearchTask() reports -- and best[32], the
+ * merged per-PRN best over the whole capture (max_pwr reads 0: the key does not carry it).  n_devices == 1 is the
+ * degenerate case.  The engines' Doppler windows are left as they were.
+ */
+GPSACQ_API int gpsacq_multi_search_blocks(gpsacq_multi* m, const uint8_t* bits, size_t n_runs, size_t stride, gpsacq_peak* peaks,
+                               gpsacq_peak* best);
 
 /* SearchCode(): chips to clock PRN sv's generator until its G1 register reads g1 (-1 if never) */
 GPSACQ_API int gpsacq_search_code(int sv, int g1);

@@ -483,3 +483,45 @@ long oracle_bench_blocks(oracle_t *o, const unsigned char *bits, long n_blocks, 
     }
     return cells;
 }
+
+/* The same port on several cores for bench.py's all-cores figure: one oracle instance per OpenMP thread (SearchInit of every
+ * instance untimed, behind a barrier), then the threads take blocks of the sample round-robin (block b against PRN b % 32, the
+ * reference schedule) until `seconds` have passed.  Returns the cells searched; *elapsed gets the timed span and
+ * *threads_used what the runtime really gave.  Test infrastructure, like the rest of this file. */
+#ifdef _OPENMP
+#include <omp.h>
+long oracle_bench_omp(double fc, double fs, double max_fo, const unsigned char *bits, long n_blocks, long stride, int nthreads,
+                      double seconds, double *elapsed, int *threads_used) {
+    long cells = 0;
+    double t_begin = 0, t_end = 0;
+    int used = 0;
+    if (nthreads < 1) nthreads = 1;
+#pragma omp parallel num_threads(nthreads) reduction(+ : cells)
+    {
+        oracle_t *o = oracle_create(fc, fs, max_fo, 0);
+#pragma omp barrier
+#pragma omp master
+        {
+            t_begin = omp_get_wtime();
+            used = omp_get_num_threads();
+        }
+#pragma omp barrier
+        const int tid = omp_get_thread_num(), nt = omp_get_num_threads();
+        const double deadline = omp_get_wtime() + seconds;
+        for (long b = tid; o && omp_get_wtime() < deadline; b += nt) {
+            oracle_peak pk;
+            const long blk = b % n_blocks;
+            oracle_search_block(o, bits + blk * stride, (int)(blk % NUM_SATS), NULL, &pk);
+            cells += 2 * o->dmax + 1;
+        }
+#pragma omp barrier
+#pragma omp master
+        t_end = omp_get_wtime();
+        if (o) oracle_destroy(o);
+    }
+    if (elapsed) *elapsed = t_end - t_begin;
+    if (threads_used) *threads_used = used;
+    return cells;
+}
+#endif
+

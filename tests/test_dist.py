@@ -122,3 +122,47 @@ def test_shard_helpers():
     assert [p[1] for p in parts] == [1, 1, 1, 0, 0, 0, 0, 0]
     # strong scaling of bench.py: 340 runs (the Nottingham capture) over 8 ranks
     assert [D.shard_runs(340, r, 8)[1] for r in range(8)] == [43, 43, 43, 43, 42, 42, 42, 42]
+
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _bench_cli(*args, env=None):
+    import subprocess
+    import sys
+    e = dict(os.environ)
+    for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT"):
+        e.pop(k, None)
+    e.update(env or {})
+    return subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), *args], capture_output=True, text=True, timeout=300, env=e)
+
+
+def test_bench_gpus_n_spawns_its_own_ranks():
+    """`python bench.py --gpus 2` without WORLD_SIZE must not measure one GPU and call it two: it re-launches
+    itself under torch.distributed.run; --spawn-check stops every rank after the rendezvous so this runs without a GPU."""
+    import json
+    r = _bench_cli("--gpus", "2", "--spawn-check", env={"GPSACQ_DIST_BACKEND": "gloo"})
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, r.stdout
+    j = json.loads(lines[0])
+    assert j["n_gpus"] == 2 and j["rccl_ranks_seen"] == 2 and j["world_size_env"] == 2
+    # one rank stays one process
+    r = _bench_cli("--spawn-check")
+    j = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][0])
+    assert j["n_gpus"] == 1 and j["rccl_ranks_seen"] == 1
+
+
+def test_bench_gpus_n_without_the_devices_fails_loudly():
+    """RCCL backend, fewer visible devices than --gpus: non-zero exit and no JSON line (here: no GPU at all)."""
+    import torch
+    if torch.cuda.is_available() and torch.cuda.device_count() >= 8:
+        pytest.skip("8 devices visible")
+    r = _bench_cli("--gpus", "8")
+    assert r.returncode != 0
+    assert "--gpus 8" in r.stderr and "visible" in r.stderr
+    assert not [l for l in r.stdout.splitlines() if l.startswith("{")]
+    # a WORLD_SIZE that contradicts --gpus is refused too (both directions)
+    r = _bench_cli("--gpus", "1", "--spawn-check", env={"WORLD_SIZE": "2", "RANK": "0"})
+    assert r.returncode != 0 and "WORLD_SIZE=2" in r.stderr
+

@@ -91,7 +91,17 @@ try:
                     onchip[name] = d[key] / d["SQ_WAVE_CYCLES"]
         if "GRBM_GUI_ACTIVE" in d and "TCP_TCC_READ_REQ_sum" in d:
             onchip["l2_to_l1_bytes_per_cell"] = d["TCP_TCC_READ_REQ_sum"] * 64.0 / cells
-        json.dump({"tag": tag, "kernel": "k_corr", "cells_per_launch_profiled": cells,
+        # ties the counters to the kernel sources they were collected on: bench.py recomputes the hash and flags a mismatch
+        # ("traffic_stale").  The summary is made in the authoring container from the GPU box's output of the SAME tree.
+        import hashlib
+        h = hashlib.sha256()
+        root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+        for name in ("acq_kernels.hip", "acq_phases.hpp", "acq_math.hpp", "acq_launch.hpp", "iq_convert.hpp"):
+            h.update(open(os.path.join(root, "gnss-gps-sdr_amd", "csrc", name), "rb").read())
+        sha_file = os.path.join(src, "kernel_source_sha.txt")  # written on the GPU box by tools/profile.sh
+        sha = open(sha_file).read().strip() if os.path.exists(sha_file) else h.hexdigest()[:16]
+        json.dump({"tag": tag, "kernel": "k_corr", "kernel_instance": "k_corr<22,3,2>", "kernel_source_sha": sha,
+                   "cells_per_launch_profiled": cells,
                    "hbm_read_bytes_per_cell": d["FETCH_SIZE"] * 1024 * 2 / cells,
                    "hbm_write_bytes_per_cell": d["WRITE_SIZE"] * 1024 / cells,
                    "onchip_counters": onchip,
