@@ -21,9 +21,13 @@ $(LIBDIR)/libgpsacq.so: $(CSRC)/acq_kernels.hip $(CSRC)/iq_kernels.hip $(CSRC)/g
 	$(HIPCC) $(HIPFLAGS) -c $(CSRC)/acq_kernels.hip -o $(LIBDIR)/acq_kernels.o
 	$(HIPCC) $(HIPFLAGS) -c $(CSRC)/iq_kernels.hip -o $(LIBDIR)/iq_kernels.o
 	$(HIPCC) $(HIPFLAGS) -c $(CSRC)/gen_kernels.hip -o $(LIBDIR)/gen_kernels.o
-	$(HIPCC) --offload-arch=$(ARCH) -shared -fPIC -o $@ $(LIBDIR)/acq_kernels.o $(LIBDIR)/iq_kernels.o $(LIBDIR)/gen_kernels.o $(LIBDIR)/gpsacq_engine.o $(LIBDIR)/gpsacq_multi.o -ldl
+	$(HIPCC) --offload-arch=$(ARCH) -shared -fPIC -o $@ $(LIBDIR)/acq_kernels.o $(LIBDIR)/iq_kernels.o $(LIBDIR)/gen_kernels.o $(LIBDIR)/gpsacq_engine.o $(LIBDIR)/gpsacq_multi.o -ldl -pthread
 
-host: $(LIBDIR)/libgps_search.so $(BINDIR)/gps_test
+host: $(LIBDIR)/libgps_search.so $(BINDIR)/gps_test $(BINDIR)/hip_floor
+# measurement aid of bench.py's e2e_cli leg: the wall clock of a HIP process that does nothing (runtime start-up floor)
+$(BINDIR)/hip_floor: tools/ubench/hip_floor.hip
+	@mkdir -p $(BINDIR)
+	$(HIPCC) --offload-arch=$(ARCH) -O2 -o $@ $<
 $(LIBDIR)/libgps_search.so: $(HOST)/search_api.cpp include/gps_search.h include/gpsacq.h $(LIBDIR)/libgpsacq.so
 	$(CXX) $(HOSTFLAGS) -pthread -shared -o $@ $(HOST)/search_api.cpp -L$(LIBDIR) -lgpsacq -Wl,-rpath,'$$ORIGIN'
 $(BINDIR)/gps_test: $(HOST)/gps_test.cpp include/gps_search.h $(LIBDIR)/libgps_search.so

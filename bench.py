@@ -165,13 +165,19 @@ def cpu_baseline_all_cores(cfg, bits, ndop, one_thread_rate, target_s=8.0):
         ncpu = len(os.sched_getaffinity(0))
     except (AttributeError, OSError):
         ncpu = os.cpu_count() or 1
+    quota = None  # a container's CPU bandwidth limit (cgroup v2 cpu.max): the cores the process can really use at once
+    try:
+        q, per = open("/sys/fs/cgroup/cpu.max").read().split()[:2]
+        quota = None if q == "max" else float(q) / float(per)
+    except (OSError, ValueError):
+        pass
     buf = np.ascontiguousarray(bits)
     nblk = buf.size // 5120
     el, used = ctypes.c_double(), ctypes.c_int()
     cells = L.oracle_bench_omp(cfg["fc"], cfg["fs"], cfg["max_fo"], buf.ctypes.data, nblk, 5120, ncpu, target_s, ctypes.byref(el), ctypes.byref(used))
     rate = cells / el.value
     return {"value": rate, "unit": "cells/s", "cores": used.value, "kind": "port",
-            "sched_getaffinity_cores": ncpu, "os_cpu_count": os.cpu_count(),
+            "sched_getaffinity_cores": ncpu, "os_cpu_count": os.cpu_count(), "cgroup_cpu_quota_cores": quota,
             "speedup_over_1_thread": rate / one_thread_rate if one_thread_rate else None,
             "sample": f"OpenMP, {used.value} threads (sched_getaffinity: {ncpu} cores), blocks of the same {nblk}-block sample dealt "
                       f"round-robin x {ndop} bins for {el.value:.1f} s = {cells} cells"}
@@ -201,11 +207,20 @@ def e2e_cli(cfg, d_bits, n_runs, ndop, reps=3):
                 return {"error": f"gps_test exit {r.returncode}: {r.stderr[-300:]}"}
             runs = r.stdout.count("satellite:")
             traces.append([ln for ln in r.stderr.splitlines() if ln.startswith("gpsacq trace")][-1])
+    floor_exe, floor = os.path.join(ROOT, "gnss-gps-sdr_amd", "bin", "hip_floor"), None
+    if os.path.exists(floor_exe):  # a HIP process that creates a stream, launches an empty kernel and exits
+        fw = []
+        for _ in range(reps):
+            t0 = time.perf_counter()
+            subprocess.run([floor_exe], capture_output=True)
+            fw.append(time.perf_counter() - t0)
+        floor = min(fw)
     best = int(np.argmin(walls))
     nums = {k: float(v) for k, v in re.findall(r"(SearchInit|SearchTask|mean pass|read|submit|wait for GPU|report) ([0-9.]+)", traces[best])}
     cells = runs * 32 * ndop
     return {"wall_s": walls[best], "wall_s_all": walls, "runs_reported": runs, "cells": cells, "cells_per_s": cells / walls[best],
-            "file_bytes": int(host.size), "split_ms": nums,
+            "file_bytes": int(host.size), "split_ms": nums, "hip_process_floor_s": floor,
+            "wall_above_floor_s": (walls[best] - floor) if floor else None,
             "note": "process start + HIP runtime/module load + SearchInit + pipelined SearchTask (fread k+1 || search k || printf k-1)"}
 
 

@@ -145,9 +145,26 @@ __global__ __launch_bounds__(WG) void k_quirk_patch(QuirkArgs a) {
 // grid point; 0 = plain sum): power of lag n goes to lag (n - round(k * creep * point)) mod S.
 // W1H: half of the pass-1 twiddles derived instead of held (acq_math.hpp): 18 registers for 18 packed multiplies.
 // PROF: s_memtime stamps per segment, summed over the launch into a.prof[1024][16] (GPSACQ_PROF=1; costs a few per cent).
-// L: LDS slot map (acq_math.hpp): LayB everywhere except the two widest non-coherent instances, whose per-lag power array
-// leaves room for the 40 KB map only (33 columns: 77 KB -> still two workgroups per CU).
-template <int MC, int WPS, int NB, bool NC, bool W1H = false, bool PROF = false, class L = LayB>
+// L: LDS slot map and lane map (acq_math.hpp): LayC (LayB's slots, conflict-free lane assignment) everywhere except the two
+// widest non-coherent instances, whose per-lag power array leaves room for the 40 KB map LayA only (33 columns: 77 KB -> still two
+// workgroups per CU).
+#ifndef ACQ_CORR_LAYOUT
+#define ACQ_CORR_LAYOUT LayC  // -DACQ_CORR_LAYOUT=LayB builds round 2's lane map for A/B runs (tools/build_variant.sh)
+#endif
+// Experiment hook (tools/build_variant.sh -DACQ_EXP_PRIO=n; off in the product): static wave priority per phase, s_setprio.
+//   1: raised from the first input load of a sub-transform until its pass-1 stores are out   2: raised outside pass 2   3: raised in pass 2
+#ifndef ACQ_EXP_PRIO
+#define ACQ_EXP_PRIO 0
+#endif
+#define ACQ_SETPRIO(when, level)                                         \
+    do {                                                                 \
+        if (ACQ_EXP_PRIO == (when)) __builtin_amdgcn_s_setprio(level);   \
+    } while (0)
+template <class L> __device__ __forceinline__ int corr_rho(const CorrArgs& a, int t3) {
+    if constexpr (L::REMAP) return (int)a.rho_map[t3];
+    else return pass3_rho<L>(t3);
+}
+template <int MC, int WPS, int NB, bool NC, bool W1H = false, bool PROF = false, class L = ACQ_CORR_LAYOUT>
 __global__ __launch_bounds__(WG, WPS) void k_corr(CorrArgs a) {
     __shared__ __attribute__((aligned(16))) cf lds[L::SIZE];  // transform buffer
     __shared__ cf t2s[NT2];    // the 500 pass-2 twiddles
@@ -179,7 +196,7 @@ __global__ __launch_bounds__(WG, WPS) void k_corr(CorrArgs a) {
     // q-independent twiddles: pass 2's table into LDS (16-byte copies), pass 1's into registers
     for (int i = tid; i < NT2; i += WG) t2s[i] = a.t2[i];
     cf w1[2][RA - 1];
-    load_tw1<W1H>(tid, a.t1, w1);
+    load_tw1<W1H, L>(tid, a.t1, w1);
 
     cf acc[MC];
 #pragma unroll
@@ -197,23 +214,35 @@ __global__ __launch_bounds__(WG, WPS) void k_corr(CorrArgs a) {
         tm = now_;                                                    \
     }
     const int t3 = tid < NBF3 ? tid : 0;
+    const int rho = corr_rho<L>(a, t3);  // the radix-20 butterfly (output residue) this thread owns
     const int n_acc = NC ? a.n_acc : 1;
     for (int k = 0; k < n_acc; ++k) {
         const cf* dk = dpp + (size_t)k * a.acc_step * a.sub * NPOLY * M_SUB;
         for (int q = 0; q < NPOLY; ++q) {
-            const cf b = a.bq[q * NBF3 + t3];  // per-thread rotation of this sub-transform
-            cf wqv[MC];                        // wave-uniform rotations: scalar loads, SGPR operands
+            const cf b = a.bq[q * NBF3 + rho];  // per-thread rotation of this sub-transform
+            // wave-uniform rotations: scalar loads, SGPR operands.  Up to 22 columns are fetched here, ahead of the sub-transform;
+            // the wide instances fetch them in chunks inside pass 3 (corr_phase3) to stay inside the SGPR file
+            cf wq_early[MC <= 22 ? MC : 1];
+            if (MC <= 22) {
 #pragma unroll
-            for (int m = 0; m < MC; ++m) wqv[m] = c_wq[q * WQ_STRIDE + a.m0 + m];
+                for (int m = 0; m < MC; ++m) wq_early[m] = c_wq[q * WQ_STRIDE + a.m0 + m];
+            }
+            const cf* wqv = MC <= 22 ? wq_early : c_wq + q * WQ_STRIDE + a.m0;
+            ACQ_SETPRIO(1, 2);
             corr_phase1<NB, W1H, L>(tid, q, dop, dk, cpp, a.crow, a.halo, w1, lds);
+            ACQ_SETPRIO(1, 0);
+            ACQ_SETPRIO(2, 0);
             ACQ_STAMP(1);  // inputs loaded and multiplied, pass 1, its LDS stores drained (the stamp waits on lgkmcnt)
             __syncthreads();  // also orders the t2s fill before its first use
             ACQ_STAMP(2);
+            ACQ_SETPRIO(3, 2);
             corr_phase2<L>(tid, t2s, lds);
+            ACQ_SETPRIO(3, 0);
             ACQ_STAMP(3);
             __syncthreads();
             ACQ_STAMP(4);
-            corr_phase3<MC, L>(tid, b, wqv, lds, acc);
+            ACQ_SETPRIO(2, 2);
+            corr_phase3<MC, L>(tid, rho, b, wqv, lds, acc);
             ACQ_STAMP(5);
             __syncthreads();
             ACQ_STAMP(6);
@@ -221,7 +250,7 @@ __global__ __launch_bounds__(WG, WPS) void k_corr(CorrArgs a) {
         if (NC) {
             // every lag has one owner per block, so the scatter needs no atomics; successive blocks'
             // updates are separated by the barriers of the next 8 sub-transforms
-            corr_accumulate_power<MC>(tid, a.nlags, a.m0, __float2int_rn((float)k * a.creep * (float)(di + a.dop_first)), acc, pws);
+            corr_accumulate_power<MC>(tid, rho, a.nlags, a.m0, __float2int_rn((float)k * a.creep * (float)(di + a.dop_first)), acc, pws);
         }
     }
 
@@ -229,9 +258,9 @@ __global__ __launch_bounds__(WG, WPS) void k_corr(CorrArgs a) {
     int mi;
     if (NC) {
         __syncthreads();  // the last block's scatter
-        corr_scan_power<MC>(tid, a.nlags, a.m0, pws, mx, mi, sum);
+        corr_scan_power<MC>(tid, rho, a.nlags, a.m0, pws, mx, mi, sum);
     }
-    else corr_scan<MC>(tid, a.nlags, a.m0, acc, mx, mi, sum);
+    else corr_scan<MC>(tid, rho, a.nlags, a.m0, acc, mx, mi, sum);
     // wave reduction (64 lanes), then across the 4 waves through LDS
 #pragma unroll
     for (int off = 32; off > 0; off >>= 1) {

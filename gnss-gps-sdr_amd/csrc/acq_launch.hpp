@@ -43,7 +43,8 @@ struct CorrArgs {
     const Task* tasks; // [n_tasks]
     const cf* t1;
     const cf* t2;
-    const cf* bq;
+    const cf* bq;      // [8][250] by rho
+    const unsigned char* rho_map;  // [256] LayC: pass-3 thread -> rho (acq_math.hpp kRhoC)
     Cell* cells;       // [n_tasks][ndop]
     int n_tasks, ndop, dop_first, nlags, crow, halo;  // bins dop_first .. dop_first+ndop-1
     int m0;               // first accumulator column of this pass (multiple of 40; 0 unless fs > 10 MHz)

@@ -320,8 +320,57 @@ ACQ_HD void ld2u(const cf* p, cf& a, cf& b) {
 //                          neighbours, so their outputs leave as ONE 16-byte store per alpha, and a pass-3 thread's 20
 //                          elements are contiguous (ten 16-byte reads); 22 and 564 keep every access conflict-free
 //                          (176-byte lane stride for the 16-byte reads, 564 - 20 = 17 * 32 across the alpha boundary of pass 2)
-struct LayA { static constexpr int SA = NBF1, SJ = RB, SB = 1, SIZE = M_SUB; };
-struct LayB { static constexpr int SA = 564, SJ = 1, SB = 22, SIZE = 10 * 564; };
+//   LayC (k_corr, round 3)  LayB's slots with the WORK re-dealt over the lanes so that every LDS instruction of the three passes is
+//                          bank-conflict free (the hardware services a wave's access in fixed lane groups -- 8 contiguous lanes for
+//                          16-byte stores, 16 for 8-byte accesses, the interleaved 16-lane sets of ds_read_b128 -- and only lanes of
+//                          one group can collide, MI355X_MICROARCH.md section LDS):
+//                            pass 1  thread t owns the butterfly pair (b, j), j' = 20 b + 2 j: t < 200 -> (t / 8, t % 8); the pairs
+//                                    j = 8, 9 of four rows b with distinct (3 b) mod 8 share a group of 8 (pass1_jp)
+//                            pass 2  lane e < 160 -> (alpha, j'') = (e / 16, e % 16); the j'' = 16..19 of four alpha share a group
+//                                    (their twiddle reads then hit ONE address per j'': a broadcast) (pass2_owner)
+//                            pass 3  thread -> rho through a 250-entry table (kRhoC) that gives every 16-lane read group 16
+//                                    distinct bank classes (10 alpha + 11 beta) mod 16
+//                          Same elements, same arithmetic per element: passes 1 and 2 are bit-identical to LayB, pass 3 only
+//                          changes which thread accumulates which lag.  LDS-array cycles per sub-transform 1930 -> 1462 in the
+//                          instruction-level model that reproduces the measured conflict count of LayB (488) exactly.
+struct LayA { static constexpr int SA = NBF1, SJ = RB, SB = 1, SIZE = M_SUB; static constexpr bool REMAP = false; };
+struct LayB { static constexpr int SA = 564, SJ = 1, SB = 22, SIZE = 10 * 564; static constexpr bool REMAP = false; };
+struct LayC { static constexpr int SA = 564, SJ = 1, SB = 22, SIZE = 10 * 564; static constexpr bool REMAP = true; };
+
+// LayC: thread t3 (< 250) of pass 3 -> rho = 10 beta + alpha of the radix-20 butterfly it owns (generated by tools/lds_maps.py)
+static const unsigned char kRhoC[NBF3] = {
+      0,  20,  40,  60, 160, 180, 200, 220, 170, 190, 210, 240,  10,  30,  50,  80,   1, 230, 121, 141, 140,  70, 100, 120, 150,
+     90, 110, 130,  11, 111, 131, 151,  21,  41,  61,  81, 181, 201, 221, 241, 191, 211, 231, 122,  31,  51,  71, 101,  22, 112,
+      3, 162, 161,  91, 142,   2, 171, 132, 152,  12,  32, 153,  13, 172,  42,  62,  82, 102, 202, 222, 242, 123, 212, 232, 113,
+      4,  52,  72,  92, 143,  43, 154,  24, 183, 182, 133, 163,  23, 192,  14, 173,  33,  53, 174,  34, 193,  63,  83, 103, 144,
+    223, 243, 124,   5, 233, 114, 155,  25,  73,  93, 134, 164,  64, 175,  45, 204, 203,  15, 184,  44, 213,  35, 194,  54,  74,
+    195,  55, 214,  84, 104, 145, 165, 244, 125,   6,  26, 115, 156, 176,  46,  94, 135,  16, 185,  85, 196,  66, 225, 224,  36,
+    205,  65, 234,  56, 215,  75,  95, 216,  76, 235, 105, 146, 166, 186, 126,   7,  27,  47, 157, 177, 197,  67, 136,  17,  37,
+    206, 106, 217,  87, 246, 245,  57, 226,  86, 116,  77, 236,  96, 137, 237,  97, 117, 147, 167, 187, 207,   8,  28,  48,  68,
+    178, 198, 218,  88,  18,  38,  58, 227, 148, 238, 108, 128, 127,  78, 247, 107, 158,  98, 118, 138,  19, 119, 139, 159, 168,
+    188, 208, 228,  49,  69,  89, 189, 199, 219, 239, 109,  39,  59,  79, 248, 169, 209, 229, 249,   9,  99, 129, 149, 179,  29};
+
+// first (even) butterfly j' of the pair pass-1 thread t owns
+template <class L> ACQ_HD int pass1_jp(int t) {
+    if (!L::REMAP) return 2 * t;
+    if (t < 200) return RC * (t >> 3) + 2 * (t & 7);
+    const int r = t - 200, g = r >> 3, i = r & 7;  // the pairs j = 8, 9: rows {0,2,4,6}+8g, then {1,3,5,7}+8(g-3), then row 24
+    const int b = g < 3 ? 8 * g + 2 * (i >> 1) : (g < 6 ? 8 * (g - 3) + 2 * (i >> 1) + 1 : 24);
+    return RC * b + 16 + 2 * (i & 1);
+}
+// (alpha, j'') of the radix-25 butterfly pass-2 lane e (< 200) owns
+template <class L> ACQ_HD void pass2_owner(int e, int& al, int& jpp) {
+    if (!L::REMAP) {
+        al = e / RC;
+        jpp = e - al * RC;
+    } else if (e < 160) {
+        al = e >> 4;
+        jpp = e & 15;
+    } else {
+        al = (e - 160) >> 2;
+        jpp = 16 + (e & 3);
+    }
+}
 
 // pass 1 for butterfly jp (0..499): x[a] = element jp + 500 a; w[al-1] = t1[al*500 + jp].
 template <int DIR, class L = LayA> ACQ_HD void pass1_store(const cf* x, int jp, const cf* w, cf* lds) {
@@ -346,8 +395,8 @@ template <int AL> ACQ_HD cf w5000() {
            : AL == 8 ? mk(0.99994946807088674f, -0.010052927156601628f)
                      : mk(0.99993604567026163f, -0.011309492350427326f);
 }
-// LayB: butterflies jp = 2 t and 2 t + 1 together, one 16-byte store per alpha.  w0[al-1] = W_5000^{2 t al}.
-// W1H = false: w1[al-1] = W_5000^{(2 t + 1) al} comes from registers too (36 twiddle registers per thread);
+// LayB / LayC: butterflies jp and jp + 1 (jp even) together, one 16-byte store per alpha.  w0[al-1] = W_5000^{jp al}.
+// W1H = false: w1[al-1] = W_5000^{(jp + 1) al} comes from registers too (36 twiddle registers per thread);
 // W1H = true: it is formed as w0 * W_5000^al (wave-uniform constant): 9 more complex multiplies per sub-transform,
 // 18 registers fewer -- what lets the 33-column instance run three workgroups per CU.
 template <int DIR, bool W1H, int AL> ACQ_HD void pass1_pair_one(const cf* y0, const cf* y1, const cf* w0, const cf* w1, cf* dst) {
@@ -364,11 +413,11 @@ template <int DIR, bool W1H, int AL> ACQ_HD void pass1_pair_one(const cf* y0, co
     v.zw = a1;
     *reinterpret_cast<cf2*>(dst + LayB::SA * AL) = v;
 }
-template <int DIR, bool W1H = false> ACQ_HD void pass1_store_pair(const cf* x0, const cf* x1, int t, const cf* w0, const cf* w1, cf* lds) {
+template <int DIR, bool W1H = false> ACQ_HD void pass1_store_pair(const cf* x0, const cf* x1, int jp, const cf* w0, const cf* w1, cf* lds) {
     cf y0[RA], y1[RA];
     radix10<DIR>(x0, y0);
     radix10<DIR>(x1, y1);
-    const int jp = 2 * t, b = jp / RC, jpp = jp - b * RC;  // jpp even: the pair never straddles a row of 20
+    const int b = jp / RC, jpp = jp - b * RC;  // jp, hence jpp, even: the pair never straddles a row of 20
     cf* dst = lds + LayB::SB * b + jpp;
     pass1_pair_one<DIR, W1H, 0>(y0, y1, w0, w1, dst);
     pass1_pair_one<DIR, W1H, 1>(y0, y1, w0, w1, dst);
@@ -385,7 +434,8 @@ template <int DIR, bool W1H = false> ACQ_HD void pass1_store_pair(const cf* x0, 
 // pass 2 for butterfly e (0..199), in place; t2 may live in LDS (its own allocation, so the
 // compiler knows the in-place stores do not alias it) or in global memory.
 template <int DIR, class L = LayA> ACQ_HD void pass2_inplace(int e, const cf* __restrict__ t2, cf* lds) {
-    const int al = e / RC, jpp = e - al * RC;
+    int al, jpp;
+    pass2_owner<L>(e, al, jpp);
     cf* p = lds + L::SA * al + L::SJ * jpp;
     cf x[RB], y[RB];
 #pragma unroll
@@ -396,9 +446,9 @@ template <int DIR, class L = LayA> ACQ_HD void pass2_inplace(int e, const cf* __
     for (int be = 1; be < RB; ++be) p[L::SB * be] = tw<DIR>(y[be], t2[be * RC + jpp]);
 }
 
-// pass 3 for butterfly t3 (0..249): y[n''] = F[250 n'' + rho(t3)].
-template <int DIR, class L = LayA> ACQ_HD void pass3_load(int t3, const cf* lds, cf* y) {
-    const int al = t3 / RB, be = t3 - al * RB;
+// pass 3 for the butterfly rho = 10 beta + alpha (0..249): y[n''] = F[250 n'' + rho].
+template <int DIR, class L = LayA> ACQ_HD void pass3_load(int rho, const cf* lds, cf* y) {
+    const int be = rho / RA, al = rho - be * RA;
     const cf* p = lds + L::SA * al + L::SB * be;
     cf x[RC];
     if (L::SJ == 1) {  // contiguous: 16-byte reads (SA and SB keep p 16-byte aligned)
@@ -410,7 +460,9 @@ template <int DIR, class L = LayA> ACQ_HD void pass3_load(int t3, const cf* lds,
     }
     radix20<DIR>(x, y);
 }
-ACQ_HD int pass3_rho(int t3) {
+// which butterfly pass-3 thread t3 (< 250) owns
+template <class L = LayA> ACQ_HD int pass3_rho(int t3) {
+    if (L::REMAP) return kRhoC[t3];  // (host / emulation; the kernels read the same table from device memory)
     const int al = t3 / RB, be = t3 - al * RB;
     return RA * be + al;
 }

@@ -43,16 +43,17 @@ struct Task {  // one (block spectrum, code spectrum) pair to search over all Do
     int32_t code;
 };
 
-// Thread tid (< 250) owns the pass-1 butterflies jp = 2 tid and 2 tid + 1.
+// Thread tid (< 250) owns the pass-1 butterflies jp and jp + 1, jp = pass1_jp<L>(tid) (2 tid but for LayC).
 // Their 2 x 9 twiddles W_5000^{jp alpha}; loaded once per cell by the correlator.
-// W1H: only butterfly 2 tid's (the neighbour's are derived, acq_math.hpp pass1_store_pair)
-template <bool W1H = false>
+// W1H: only butterfly jp's (the neighbour's are derived, acq_math.hpp pass1_store_pair)
+template <bool W1H = false, class L = LayA>
 ACQ_HD void load_tw1(int tid, const cf* __restrict__ t1, cf (&w)[2][RA - 1]) {
     if (tid >= NBF3) return;
+    const int jp = pass1_jp<L>(tid);
 #pragma unroll
     for (int al = 1; al < RA; ++al) {
-        if (W1H) w[0][al - 1] = t1[al * NBF1 + 2 * tid];
-        else ld2(t1 + al * NBF1 + 2 * tid, w[0][al - 1], w[1][al - 1]);
+        if (W1H) w[0][al - 1] = t1[al * NBF1 + jp];
+        else ld2(t1 + al * NBF1 + jp, w[0][al - 1], w[1][al - 1]);
     }
 }
 
@@ -69,6 +70,7 @@ template <int NB, bool W1H = false, class L = LayB>
 ACQ_HD void corr_phase1(int tid, int q, int dop, const cf* __restrict__ dpp, const cf* __restrict__ cpp,
                         int crow, int halo, const cf (&w)[2][RA - 1], cf* lds) {
     if (tid >= NBF3) return;
+    const int jp = pass1_jp<L>(tid);  // this thread's butterflies jp, jp + 1: elements jp + 500 a, two neighbours per 16-byte load
     int qp, c;
     shift_split(q, dop, qp, c);
     cf x0[RA], x1[RA];
@@ -82,10 +84,10 @@ ACQ_HD void corr_phase1(int tid, int q, int dop, const cf* __restrict__ dpp, con
     const __amdgpu_buffer_rsrc_t rd = __builtin_amdgcn_make_buffer_rsrc((void*)dpp, 0, NPOLY * M_SUB * (int)sizeof(cf), 0x00020000);
     const __amdgpu_buffer_rsrc_t rc = __builtin_amdgcn_make_buffer_rsrc((void*)cpp, 0, NPOLY * crow * (int)sizeof(cf), 0x00020000);
     const int sd = q * M_SUB * (int)sizeof(cf), sc = (qp * crow + halo + c) * (int)sizeof(cf);
-    const int lane = 2 * tid * (int)sizeof(cf);
+    const int lane = jp * (int)sizeof(cf);
 #else
-    const cf* drow = dpp + q * M_SUB + 2 * tid;
-    const cf* crw = cpp + (long)qp * crow + halo + c + 2 * tid;
+    const cf* drow = dpp + q * M_SUB + jp;
+    const cf* crw = cpp + (long)qp * crow + halo + c + jp;
 #endif
 #pragma unroll
     for (int b = 0; b < NB; ++b) {
@@ -109,11 +111,11 @@ ACQ_HD void corr_phase1(int tid, int q, int dop, const cf* __restrict__ dpp, con
         }
     }
     if (L::SJ == 1) {
-        pass1_store_pair<+1, W1H>(x0, x1, tid, w[0], w[1], lds);  // slot map LayB (acq_math.hpp): one 16-byte store per alpha
+        pass1_store_pair<+1, W1H>(x0, x1, jp, w[0], w[1], lds);  // slot maps LayB / LayC (acq_math.hpp): one 16-byte store per alpha
     } else {
         static_assert(L::SJ == 1 || !W1H, "derived twiddles are implemented for slot map LayB");
-        pass1_store<+1, L>(x0, 2 * tid, w[0], lds);
-        pass1_store<+1, L>(x1, 2 * tid + 1, w[1], lds);
+        pass1_store<+1, L>(x0, jp, w[0], lds);
+        pass1_store<+1, L>(x1, jp + 1, w[1], lds);
     }
 }
 
@@ -124,16 +126,30 @@ ACQ_HD void corr_phase2(int tid, const cf* t2, cf* lds) {
 
 // acc[m] accumulates y[n] for n = 250 (m0 + m) + rho over the 8 polyphase components (m0, the first
 // column of this pass, is a multiple of 20 so that column m0 + m reads radix-20 output m % 20):
-// W_N^{-q n} = conj(b) (per thread, b = bq[q][tid]) * conj(wqv[m]) (wave-uniform, wqv[m] = W_160^{q m}).
+// W_N^{-q n} = conj(b) (per thread, b = bq[q][rho]) * conj(wqv[m]) (wave-uniform, wqv[m] = W_160^{q m}).
+// rho: the radix-20 butterfly this thread owns (pass3_rho<L>(tid); the kernels read LayC's table from device memory).
 template <int MC, class L = LayB>
-ACQ_HD void corr_phase3(int tid, cf b, const cf* wqv, const cf* lds, cf* acc) {
+ACQ_HD void corr_phase3(int tid, int rho, cf b, const cf* wqv, const cf* lds, cf* acc) {
     if (tid >= NBF3) return;
     cf y[RC];
-    pass3_load<+1, L>(tid, lds, y);
+    pass3_load<+1, L>(rho, lds, y);
 #pragma unroll
     for (int n = 0; n < RC; ++n) y[n] = cmulc(y[n], b);
+    // The wave-uniform factors come as SGPR pairs (scalar loads from constant memory in the kernel).  More than ~14 columns
+    // of them at once (28 SGPRs, next to the radix-25's constants and the buffer descriptors) overflow the 102 SGPRs and
+    // hipcc parks the rest in VGPR lanes (90 v_readlane per sub-transform in the 33-column instance): wide instances take
+    // them in chunks, each chunk's scalar loads issued before the previous chunk's FMAs.
+    constexpr int NCH = (MC + 13) / 14, CH = (MC + NCH - 1) / NCH;
 #pragma unroll
-    for (int m = 0; m < MC; ++m) acc[m] = cmacc_u(acc[m], y[m % RC], wqv[m]);
+    for (int c0 = 0; c0 < MC; c0 += CH) {
+        cf w[CH];
+#pragma unroll
+        for (int i = 0; i < CH; ++i) w[i] = wqv[c0 + i < MC ? c0 + i : 0];
+        if (NCH > 1) ACQ_SCHED_FENCE();
+#pragma unroll
+        for (int i = 0; i < CH; ++i)
+            if (c0 + i < MC) acc[c0 + i] = cmacc_u(acc[c0 + i], y[(c0 + i) % RC], w[i]);
+    }
 }
 
 // Doppler grid point k (in units of the grid step) -> whole-bin shift `dop` of the code spectrum (:182) and the
@@ -151,12 +167,11 @@ ACQ_HD void grid_point(int k, int sub, int dstride, int& dop, int& r) {
 
 // Peak scan over the first S lags (:190-194), this thread's share, ascending n.
 template <int MC>
-ACQ_HD void corr_scan(int tid, int S, int m0, const cf* acc, float& mx, int& mi, float& sum) {
+ACQ_HD void corr_scan(int tid, int rho, int S, int m0, const cf* acc, float& mx, int& mi, float& sum) {
     mx = 0.f;
     mi = 0;
     sum = 0.f;
     if (tid >= NBF3) return;
-    const int rho = pass3_rho(tid);
 #pragma unroll
     for (int m = 0; m < MC; ++m) {  // branch-free: lags beyond S contribute a power of 0
         const int n = NBF3 * (m0 + m) + rho;
@@ -171,9 +186,8 @@ ACQ_HD void corr_scan(int tid, int S, int m0, const cf* acc, float& mx, int& mi,
 // pws[n - 250 m0]), moved down by `shift` whole samples modulo the S lags (shift = 0 when the search
 // takes several passes, m0 > 0), and clear the accumulators for the next block
 template <int MC>
-ACQ_HD void corr_accumulate_power(int tid, int S, int m0, int shift, cf* acc, float* pws) {
+ACQ_HD void corr_accumulate_power(int tid, int rho, int S, int m0, int shift, cf* acc, float* pws) {
     if (tid >= NBF3) return;
-    const int rho = pass3_rho(tid);
     int sh = shift % S;
     if (sh < 0) sh += S;
 #pragma unroll
@@ -189,12 +203,11 @@ ACQ_HD void corr_accumulate_power(int tid, int S, int m0, int shift, cf* acc, fl
 }
 // same scan as corr_scan over the summed powers
 template <int MC>
-ACQ_HD void corr_scan_power(int tid, int S, int m0, const float* pws, float& mx, int& mi, float& sum) {
+ACQ_HD void corr_scan_power(int tid, int rho, int S, int m0, const float* pws, float& mx, int& mi, float& sum) {
     mx = 0.f;
     mi = 0;
     sum = 0.f;
     if (tid >= NBF3) return;
-    const int rho = pass3_rho(tid);
 #pragma unroll
     for (int m = 0; m < MC; ++m) {
         const int n = NBF3 * (m0 + m) + rho;
@@ -296,7 +309,7 @@ ACQ_HD void fwd_phase2(int tid, const cf* __restrict__ t2, cf* lds) {
 }
 // pass 3 into registers (all threads must finish before fwd_phase3_store overwrites the LDS)
 ACQ_HD void fwd_phase3_load(int tid, const cf* lds, cf* y) {
-    if (tid < NBF3) pass3_load<-1>(tid, lds, y);
+    if (tid < NBF3) pass3_load<-1>(pass3_rho(tid), lds, y);
 }
 // natural order k' = 250 n'' + rho; conjugated for block spectra (Correlate multiplies by conj(data), :183-184)
 ACQ_HD void fwd_phase3_store(int tid, bool conj_out, const cf* y, cf* dst) {

@@ -23,7 +23,7 @@ inline cf unit_fwd(long long num, long long den) {  // exp(-2 pi i num/den)
 struct Tables {
     std::vector<cf> t1;  // [10][500]   W_5000^{j' alpha}
     std::vector<cf> t2;  // [25][20]    W_500^{j'' beta}
-    std::vector<cf> bq;  // [8][250]    W_40000^{q rho(t3)}, rho = 10 (t3 % 25) + t3 / 25
+    std::vector<cf> bq;  // [8][250]    W_40000^{q rho}, indexed by the radix-20 butterfly rho = 10 beta + alpha a pass-3 thread owns
     std::vector<cf> wq;  // [8][40]     W_160^{q m}
     std::vector<cf> tn;  // [8][5000]   W_40000^{n' kappa}: forward transform's decimation-in-frequency twiddle
     Tables() : t1(RA * NBF1), t2((size_t)NT2), bq((size_t)NPOLY * NBF3), wq(NPOLY * WQ_STRIDE), tn((size_t)NPOLY * M_SUB) {
@@ -34,7 +34,7 @@ struct Tables {
         for (int be = 0; be < RB; ++be)
             for (int jpp = 0; jpp < RC; ++jpp) t2[(size_t)be * RC + jpp] = unit_fwd((long long)jpp * be, NBF1);
         for (int q = 0; q < NPOLY; ++q)
-            for (int t3 = 0; t3 < NBF3; ++t3) bq[(size_t)q * NBF3 + t3] = unit_fwd((long long)q * pass3_rho(t3), N_FFT);
+            for (int rho = 0; rho < NBF3; ++rho) bq[(size_t)q * NBF3 + rho] = unit_fwd((long long)q * rho, N_FFT);
         for (int q = 0; q < NPOLY; ++q)
             for (int m = 0; m < WQ_STRIDE; ++m) wq[q * WQ_STRIDE + m] = unit_fwd((long long)q * m, NW160);
     }

@@ -5,11 +5,14 @@
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
+#include <chrono>
 #include <cmath>
 #include <cstdarg>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <future>
+#include <memory>
 #include <string>
 #include <vector>
 
@@ -66,6 +69,7 @@ struct gpsacq_engine {
     long searches = 0;  // searches enqueued so far; search k uses ring slot k % kTimingRing
     // constants
     cf *d_t1 = nullptr, *d_t2 = nullptr, *d_bq = nullptr, *d_tn = nullptr;
+    unsigned char* d_rho = nullptr;  // LayC's pass-3 thread -> rho table (acq_math.hpp kRhoC)
     uint8_t *d_cos = nullptr, *d_sin = nullptr;
     uint64_t *d_cos_t = nullptr, *d_sin_t = nullptr;  // bit-transposed masks for k_fwd
     cf* d_code = nullptr;  // [32 + patch_cap][8][crow]
@@ -199,7 +203,7 @@ extern "C" void gpsacq_destroy(gpsacq_engine* e) {
     if (!e) return;
     (void)hipSetDevice(e->p.device);
     if (e->stream) (void)hipStreamSynchronize(e->stream);
-    void* bufs[] = {e->d_t1, e->d_t2, e->d_bq, e->d_tn, e->d_cos, e->d_sin, e->d_cos_t, e->d_sin_t, e->d_code, e->d_patch_blocks, e->d_bits, e->d_iq, e->d_iqbits, e->d_sums, e->d_sats, e->d_gen, e->d_prof, e->d_rot8,
+    void* bufs[] = {e->d_t1, e->d_t2, e->d_bq, e->d_tn, e->d_rho, e->d_cos, e->d_sin, e->d_cos_t, e->d_sin_t, e->d_code, e->d_patch_blocks, e->d_bits, e->d_iq, e->d_iqbits, e->d_sums, e->d_sats, e->d_gen, e->d_prof, e->d_rot8,
                     e->d_dpp, e->d_parts, e->d_tasks, e->d_cells, e->d_peaks};
     for (void* b : bufs)
         if (b) (void)hipFree(b);
@@ -233,6 +237,43 @@ extern "C" int gpsacq_create(const gpsacq_params* params, gpsacq_engine** out) {
     const int mc = corr_columns(nlags);
     if (dmax >= N_FFT / 2) return fail(GPSACQ_ERR_UNSUPPORTED, "max_fo = %g Hz exceeds half the sampling rate", params->max_fo);
 
+    const char* trace_env = getenv("GPSACQ_TRACE");
+    const bool trace = trace_env && atoi(trace_env) != 0;
+    const auto t_begin = std::chrono::steady_clock::now();
+    auto lap = [&]() { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_begin).count(); };
+    // Everything the host computes -- twiddles, LO masks, the 32 float-sequential code replicas (15-20 ms) -- needs no device:
+    // it runs in a worker while this thread sits in the HIP runtime's start-up (>100 ms in the first HIP call of a process).
+    struct HostPrep {
+        Tables T;
+        std::vector<cf> tn, rot8;
+        std::vector<uint8_t> cosm, sinm;
+        std::vector<uint64_t> cos_t, sin_t;
+        std::vector<float> rep;
+        std::vector<uint32_t> chips;
+    };
+    const gpsacq_params prm = *params;
+    std::future<std::unique_ptr<HostPrep>> prep_job = std::async(std::launch::async, [prm]() {
+        std::unique_ptr<HostPrep> h(new HostPrep());
+        forward_tables(1, h->tn, h->rot8);
+        h->cosm.resize(BLOCK_BYTES);
+        h->sinm.resize(BLOCK_BYTES);
+        lo_masks(prm.fc, prm.fs, BLOCK_BYTES, h->cosm.data(), h->sinm.data());
+        h->cos_t.resize(625);
+        h->sin_t.resize(625);
+        transpose_masks(h->cosm.data(), h->cos_t.data());
+        transpose_masks(h->sinm.data(), h->sin_t.data());
+        h->rep.resize((size_t)GPSACQ_NUM_SATS * N_FFT);
+        for (int sv = 0; sv < GPSACQ_NUM_SATS; ++sv) code_replica(prm.fs, sv, &h->rep[(size_t)sv * N_FFT]);
+        h->chips.assign(32 * 32, 0u);  // C/A chips of all 32 PRNs for the capture generator
+        for (int sv = 0; sv < GPSACQ_NUM_SATS; ++sv) {
+            CaCode ca(kTaps[sv][0], kTaps[sv][1]);
+            for (int i = 0; i < 1023; ++i) {
+                if (ca.chip()) h->chips[sv * 32 + (i >> 5)] |= 1u << (i & 31);
+                ca.clock();
+            }
+        }
+        return h;
+    });
     (void)hipGetLastError();  // HIP's last-error slot is sticky: do not inherit an earlier, unrelated failure of this thread
     int ndev = 0;
     hipError_t he = hipGetDeviceCount(&ndev);
@@ -270,55 +311,46 @@ extern "C" int gpsacq_create(const gpsacq_params* params, gpsacq_engine** out) {
             return rc_;                                                               \
         }                                                                             \
     } while (0)
+    const double ms_runtime = lap();  // HIP runtime + device initialisation happen inside the first calls above
     HCK(hipStreamCreateWithFlags(&e->stream, hipStreamNonBlocking));
     for (auto& set : e->ev)
         for (auto& ev : set) HCK(hipEventCreate(&ev));
 
-    Tables T;
+    const double ms_before_prep = lap();
+    std::unique_ptr<HostPrep> hp = prep_job.get();
+    const Tables& T = hp->T;
+    const double ms_prep_wait = lap() - ms_before_prep;
     HCK(hipMalloc((void**)&e->d_t1, T.t1.size() * sizeof(cf)));
     HCK(hipMalloc((void**)&e->d_t2, T.t2.size() * sizeof(cf)));
-    {
-        std::vector<cf> tn, rot8;
-        forward_tables(1, tn, rot8);
-        HCK(hipMalloc((void**)&e->d_tn, tn.size() * sizeof(cf)));
-        HCK(hipMemcpy(e->d_tn, tn.data(), tn.size() * sizeof(cf), hipMemcpyHostToDevice));
-        HCK(hipMalloc((void**)&e->d_rot8, rot8.size() * sizeof(cf)));
-        HCK(hipMemcpy(e->d_rot8, rot8.data(), rot8.size() * sizeof(cf), hipMemcpyHostToDevice));
-    }
+    HCK(hipMalloc((void**)&e->d_tn, hp->tn.size() * sizeof(cf)));
+    HCK(hipMemcpy(e->d_tn, hp->tn.data(), hp->tn.size() * sizeof(cf), hipMemcpyHostToDevice));
+    HCK(hipMalloc((void**)&e->d_rot8, hp->rot8.size() * sizeof(cf)));
+    HCK(hipMemcpy(e->d_rot8, hp->rot8.data(), hp->rot8.size() * sizeof(cf), hipMemcpyHostToDevice));
     HCK(upload_wq(T.wq.data()));
-    {   // C/A chips of all 32 PRNs for the capture generator
-        std::vector<uint32_t> chips(32 * 32, 0u);
-        for (int sv = 0; sv < GPSACQ_NUM_SATS; ++sv) {
-            CaCode ca(kTaps[sv][0], kTaps[sv][1]);
-            for (int i = 0; i < 1023; ++i) {
-                if (ca.chip()) chips[sv * 32 + (i >> 5)] |= 1u << (i & 31);
-                ca.clock();
-            }
-        }
-        HCK(upload_chips(chips.data()));
+    HCK(upload_chips(hp->chips.data()));
+    {
+        unsigned char rho[256] = {0};
+        memcpy(rho, kRhoC, sizeof kRhoC);
+        HCK(hipMalloc((void**)&e->d_rho, sizeof rho));
+        HCK(hipMemcpy(e->d_rho, rho, sizeof rho, hipMemcpyHostToDevice));
     }
     HCK(hipMalloc((void**)&e->d_bq, T.bq.size() * sizeof(cf)));
     HCK(hipMemcpy(e->d_bq, T.bq.data(), T.bq.size() * sizeof(cf), hipMemcpyHostToDevice));
     HCK(hipMemcpy(e->d_t1, T.t1.data(), T.t1.size() * sizeof(cf), hipMemcpyHostToDevice));
     HCK(hipMemcpy(e->d_t2, T.t2.data(), T.t2.size() * sizeof(cf), hipMemcpyHostToDevice));
 
-    std::vector<uint8_t> cosm(BLOCK_BYTES), sinm(BLOCK_BYTES);
-    lo_masks(params->fc, params->fs, BLOCK_BYTES, cosm.data(), sinm.data());
     HCK(hipMalloc((void**)&e->d_cos, BLOCK_BYTES));
     HCK(hipMalloc((void**)&e->d_sin, BLOCK_BYTES));
-    HCK(hipMemcpy(e->d_cos, cosm.data(), BLOCK_BYTES, hipMemcpyHostToDevice));
-    HCK(hipMemcpy(e->d_sin, sinm.data(), BLOCK_BYTES, hipMemcpyHostToDevice));
-    std::vector<uint64_t> cos_t(625), sin_t(625);
-    transpose_masks(cosm.data(), cos_t.data());
-    transpose_masks(sinm.data(), sin_t.data());
+    HCK(hipMemcpy(e->d_cos, hp->cosm.data(), BLOCK_BYTES, hipMemcpyHostToDevice));
+    HCK(hipMemcpy(e->d_sin, hp->sinm.data(), BLOCK_BYTES, hipMemcpyHostToDevice));
     HCK(hipMalloc((void**)&e->d_cos_t, 625 * sizeof(uint64_t)));
     HCK(hipMalloc((void**)&e->d_sin_t, 625 * sizeof(uint64_t)));
-    HCK(hipMemcpy(e->d_cos_t, cos_t.data(), 625 * sizeof(uint64_t), hipMemcpyHostToDevice));
-    HCK(hipMemcpy(e->d_sin_t, sin_t.data(), 625 * sizeof(uint64_t), hipMemcpyHostToDevice));
+    HCK(hipMemcpy(e->d_cos_t, hp->cos_t.data(), 625 * sizeof(uint64_t), hipMemcpyHostToDevice));
+    HCK(hipMemcpy(e->d_sin_t, hp->sin_t.data(), 625 * sizeof(uint64_t), hipMemcpyHostToDevice));
 
+    const double ms_tables = lap();
     // SearchInit(): 32 resampled replicas (host, float-sequential NCO) -> code spectra (device)
-    std::vector<float> rep((size_t)GPSACQ_NUM_SATS * N_FFT);
-    for (int sv = 0; sv < GPSACQ_NUM_SATS; ++sv) code_replica(params->fs, sv, &rep[(size_t)sv * N_FFT]);
+    const std::vector<float>& rep = hp->rep;
     float* d_rep = nullptr;
     HCK(hipMalloc((void**)&d_rep, rep.size() * sizeof(float)));
     HCK(hipMemcpy(d_rep, rep.data(), rep.size() * sizeof(float), hipMemcpyHostToDevice));
@@ -338,6 +370,10 @@ extern "C" int gpsacq_create(const gpsacq_params* params, gpsacq_engine** out) {
     HCK(hipStreamSynchronize(e->stream));
     HCK(hipFree(d_rep));
 #undef HCK
+    if (trace)
+        fprintf(stderr, "gpsacq trace: gpsacq_create %.1f ms = HIP runtime/device start-up %.1f (host tables and code replicas computed meanwhile; "
+                        "waited %.1f more for them) + stream, events, table uploads, code object load %.1f + 32 code spectra %.1f\n",
+                lap(), ms_runtime, ms_prep_wait, ms_tables - ms_runtime - ms_prep_wait, lap() - ms_tables);
     *out = e;
     return GPSACQ_OK;
 }
@@ -480,6 +516,7 @@ static int search_core(gpsacq_engine* e, const Capture& cap_in, size_t n_blocks,
     ca.t1 = e->d_t1;
     ca.t2 = e->d_t2;
     ca.bq = e->d_bq;
+    ca.rho_map = e->d_rho;
     ca.cells = d_cells;
     ca.n_tasks = (int)n_tasks;
     ca.ndop = e->ndop;
@@ -731,6 +768,19 @@ extern "C" int gpsacq_pipe_collect(gpsacq_engine* e, int slot, const gpsacq_peak
     sl->busy = false;
     if (peaks) *peaks = reinterpret_cast<const gpsacq_peak*>(sl->h_peaks);
     if (n_peaks) *n_peaks = sl->n_tasks;
+    return GPSACQ_OK;
+}
+
+// Scratch for batches of up to n_blocks blocks (reference schedule), allocated once: a caller that knows its largest batch --
+// the pipelined front end -- spares every later search the stream-ordered regrowth of the spectra / cell / task buffers.
+extern "C" int gpsacq_reserve(gpsacq_engine* e, size_t n_blocks) {
+    if (!e || n_blocks == 0) return fail(GPSACQ_ERR_ARG, "gpsacq_reserve: bad argument");
+    HIPCHK(hipSetDevice(e->p.device));
+    if (int rc = grow(e->d_dpp, e->dpp_cap, n_blocks * (size_t)e->sub, e->stream, (size_t)NPOLY * M_SUB * sizeof(cf))) return rc;
+    if (int rc = grow(e->d_cells, e->cell_cap, n_blocks * (size_t)e->ndop, e->stream)) return rc;
+    if (int rc = grow(e->d_tasks, e->task_cap, n_blocks, e->stream)) return rc;
+    if (e->p.ref_quirks)
+        if (int rc = ensure_code_slots(e, (n_blocks + GPSACQ_NUM_SATS - 1) / GPSACQ_NUM_SATS)) return rc;
     return GPSACQ_OK;
 }
 

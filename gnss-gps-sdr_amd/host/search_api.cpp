@@ -212,6 +212,12 @@ void SearchTask(char *filename_1bit_bin) {
     }
 
     // ---- the pipeline -------------------------------------------------------------------------------------------
+    for (gpsacq_engine *e : g_engines)  // scratch for the largest batch once, not regrown as the batches ramp up
+        if (gpsacq_reserve(e, max_runs * GPSACQ_NUM_SATS) != GPSACQ_OK) {
+            fail_with("");
+            fclose(fp);
+            return;
+        }
     struct Batch {
         int slot;
         std::vector<size_t> runs;  // per device

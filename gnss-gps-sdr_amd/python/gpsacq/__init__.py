@@ -65,7 +65,7 @@ EXPORTS = ["gpsacq_generate", "gpsacq_generate_device", "gpsacq_generate_sig", "
            "gpsacq_sample_spectrum", "gpsacq_code_spectrum", "gpsacq_multi_create", "gpsacq_multi_destroy",
            "gpsacq_multi_set_doppler_step", "gpsacq_multi_get_info", "gpsacq_multi_search_grid", "gpsacq_multi_search_blocks",
            "gpsacq_pipe_buffer", "gpsacq_pipe_submit", "gpsacq_pipe_collect", "gpsacq_search_iq8", "gpsacq_search_iq8_device",
-           "gpsacq_iq8_accumulate_sums", "gpsacq_handoff_step", "gpsacq_handoff_engine"]
+           "gpsacq_iq8_accumulate_sums", "gpsacq_handoff_step", "gpsacq_handoff_engine", "gpsacq_reserve"]
 
 _lib = None
 
@@ -179,6 +179,8 @@ def load_library(path=None):
     lib.gpsacq_handoff_step.restype = ctypes.c_int
     lib.gpsacq_handoff_engine.argtypes = [vp, vp, ctypes.c_double, ctypes.POINTER(Handoff)]
     lib.gpsacq_handoff_engine.restype = ctypes.c_int
+    lib.gpsacq_reserve.argtypes = [vp, sz]
+    lib.gpsacq_reserve.restype = ctypes.c_int
     if path is None:
         _lib = lib
     return lib

@@ -162,6 +162,7 @@ GPSACQ_API int gpsacq_search_device(gpsacq_engine* e, const void* d_bits, size_t
  *   gpsacq_pipe_collect(e, slot, &peaks, &n)       waits for THAT slot's search; peaks stay valid until its next submit
  * Searches run in submit order.  With 2-3 slots the caller's read of batch k+1 and report of batch k-1 overlap batch k.
  */
+GPSACQ_API int gpsacq_reserve(gpsacq_engine* e, size_t n_blocks); /* scratch for batches of up to n_blocks blocks, once */
 #define GPSACQ_PIPE_SLOTS 3
 struct gpsacq_iq8_input;
 GPSACQ_API uint8_t* gpsacq_pipe_buffer(gpsacq_engine* e, int slot, size_t nbytes);

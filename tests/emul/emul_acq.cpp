@@ -79,11 +79,15 @@ void emul_forward_real(const float* x, float* out) {
     pp_to_natural(pp.data(), M_SUB, 0, false, out);
 }
 
+}  // extern "C"
+
 // One cell of Correlate(): data/code spectra given in natural order (data un-conjugated).
 // mc = accumulator columns of the kernel instance (12, 22, 33 or 40).
 // w1h: the instance derives half of its pass-1 twiddles (33 and 28 columns in the product).
-int emul_cell(const float* dspec, const float* cspec, int halo, int dop, int S, int mc, int w1h, float* max_pwr,
-              int* max_i, float* tot_pwr) {
+// lay: 1 = LayB (round 2's lane map), 2 = LayC (the product's: conflict-free lane assignment)
+template <class L>
+static int emul_cell_l(const float* dspec, const float* cspec, int halo, int dop, int S, int mc, int w1h, float* max_pwr,
+                       int* max_i, float* tot_pwr) {
     const Tables& T = tables();
     const int crow = M_SUB + 2 * halo;
     std::vector<cf> dpp((size_t)NPOLY * M_SUB), cpp((size_t)NPOLY * crow);
@@ -96,29 +100,32 @@ int emul_cell(const float* dspec, const float* cspec, int halo, int dop, int S, 
             cpp[(size_t)q * crow + h] = cpp[(size_t)q * crow + M_SUB + h];
             cpp[(size_t)q * crow + halo + M_SUB + h] = cpp[(size_t)q * crow + halo + h];
         }
-    std::vector<cf> lds(LayB::SIZE);
+    std::vector<cf> lds(L::SIZE);
     std::vector<cf> acc((size_t)WG * MC_MAX, mk(0.f, 0.f));
     std::vector<cf> w1((size_t)WG * 2 * (RA - 1));
     for (int tid = 0; tid < WG; ++tid) {
         auto& w = *reinterpret_cast<cf(*)[2][RA - 1]>(&w1[(size_t)tid * 2 * (RA - 1)]);
-        if (w1h) load_tw1<true>(tid, T.t1.data(), w);
-        else load_tw1<false>(tid, T.t1.data(), w);
+        if (w1h) load_tw1<true, L>(tid, T.t1.data(), w);
+        else load_tw1<false, L>(tid, T.t1.data(), w);
     }
     for (int q = 0; q < NPOLY; ++q) {
         for (int tid = 0; tid < WG; ++tid) {
             auto& w = *reinterpret_cast<cf(*)[2][RA - 1]>(&w1[(size_t)tid * 2 * (RA - 1)]);
-            if (w1h) corr_phase1<2, true>(tid, q, dop, dpp.data(), cpp.data(), crow, halo, w, lds.data());
-            else corr_phase1<2, false>(tid, q, dop, dpp.data(), cpp.data(), crow, halo, w, lds.data());
+            if (w1h) corr_phase1<2, true, L>(tid, q, dop, dpp.data(), cpp.data(), crow, halo, w, lds.data());
+            else corr_phase1<2, false, L>(tid, q, dop, dpp.data(), cpp.data(), crow, halo, w, lds.data());
         }
-        for (int tid = 0; tid < WG; ++tid) corr_phase2(tid, T.t2.data(), lds.data());
+        for (int tid = 0; tid < WG; ++tid) corr_phase2<L>(tid, T.t2.data(), lds.data());
         for (int tid = 0; tid < WG; ++tid) {
             cf* a = &acc[(size_t)tid * MC_MAX];
+            const int rho = pass3_rho<L>(tid < NBF3 ? tid : 0);
+            const cf b = T.bq[(size_t)q * NBF3 + rho];
+            const cf* wq = &T.wq[(size_t)q * WQ_STRIDE];
             switch (mc) {
-                case 12: corr_phase3<12>(tid, T.bq[(size_t)q * NBF3 + (tid < NBF3 ? tid : 0)], &T.wq[(size_t)q * WQ_STRIDE], lds.data(), a); break;
-                case 22: corr_phase3<22>(tid, T.bq[(size_t)q * NBF3 + (tid < NBF3 ? tid : 0)], &T.wq[(size_t)q * WQ_STRIDE], lds.data(), a); break;
-                case 28: corr_phase3<28>(tid, T.bq[(size_t)q * NBF3 + (tid < NBF3 ? tid : 0)], &T.wq[(size_t)q * WQ_STRIDE], lds.data(), a); break;
-                case 33: corr_phase3<33>(tid, T.bq[(size_t)q * NBF3 + (tid < NBF3 ? tid : 0)], &T.wq[(size_t)q * WQ_STRIDE], lds.data(), a); break;
-                case 40: corr_phase3<40>(tid, T.bq[(size_t)q * NBF3 + (tid < NBF3 ? tid : 0)], &T.wq[(size_t)q * WQ_STRIDE], lds.data(), a); break;
+                case 12: corr_phase3<12, L>(tid, rho, b, wq, lds.data(), a); break;
+                case 22: corr_phase3<22, L>(tid, rho, b, wq, lds.data(), a); break;
+                case 28: corr_phase3<28, L>(tid, rho, b, wq, lds.data(), a); break;
+                case 33: corr_phase3<33, L>(tid, rho, b, wq, lds.data(), a); break;
+                case 40: corr_phase3<40, L>(tid, rho, b, wq, lds.data(), a); break;
                 default: return -1;
             }
         }
@@ -129,12 +136,13 @@ int emul_cell(const float* dspec, const float* cspec, int halo, int dop, int S, 
         float tmx, tsum;
         int tmi;
         const cf* a = &acc[(size_t)tid * MC_MAX];
+        const int rho = pass3_rho<L>(tid < NBF3 ? tid : 0);
         switch (mc) {
-            case 12: corr_scan<12>(tid, S, 0, a, tmx, tmi, tsum); break;
-            case 22: corr_scan<22>(tid, S, 0, a, tmx, tmi, tsum); break;
-            case 28: corr_scan<28>(tid, S, 0, a, tmx, tmi, tsum); break;
-            case 33: corr_scan<33>(tid, S, 0, a, tmx, tmi, tsum); break;
-            default: corr_scan<40>(tid, S, 0, a, tmx, tmi, tsum); break;
+            case 12: corr_scan<12>(tid, rho, S, 0, a, tmx, tmi, tsum); break;
+            case 22: corr_scan<22>(tid, rho, S, 0, a, tmx, tmi, tsum); break;
+            case 28: corr_scan<28>(tid, rho, S, 0, a, tmx, tmi, tsum); break;
+            case 33: corr_scan<33>(tid, rho, S, 0, a, tmx, tmi, tsum); break;
+            default: corr_scan<40>(tid, rho, S, 0, a, tmx, tmi, tsum); break;
         }
         peak_merge(mx, mi, tmx, tmi);
         sum += tsum;
@@ -142,6 +150,37 @@ int emul_cell(const float* dspec, const float* cspec, int halo, int dop, int S, 
     *max_pwr = mx;
     *max_i = mi;
     *tot_pwr = sum;
+    return 0;
+}
+extern "C" {
+int emul_cell(const float* dspec, const float* cspec, int halo, int dop, int S, int mc, int w1h, int lay, float* max_pwr,
+              int* max_i, float* tot_pwr) {
+    if (lay == 1) return emul_cell_l<LayB>(dspec, cspec, halo, dop, S, mc, w1h, max_pwr, max_i, tot_pwr);
+    if (lay == 2) return emul_cell_l<LayC>(dspec, cspec, halo, dop, S, mc, w1h, max_pwr, max_i, tot_pwr);
+    return -1;
+}
+// the lane maps of LayC deal every butterfly of a pass to exactly one lane: 0 if so
+int emul_lane_maps_are_permutations(void) {
+    bool seen[M_SUB];
+    for (bool& b : seen) b = false;
+    for (int t = 0; t < NBF3; ++t) {
+        const int jp = pass1_jp<LayC>(t);
+        if (jp < 0 || jp + 1 >= NBF1 || (jp & 1) || seen[jp]) return 1;
+        seen[jp] = true;
+    }
+    for (int i = 0; i < NBF2; ++i) seen[i] = false;
+    for (int e = 0; e < NBF2; ++e) {
+        int al, jpp;
+        pass2_owner<LayC>(e, al, jpp);
+        if (al < 0 || al >= RA || jpp < 0 || jpp >= RC || seen[al * RC + jpp]) return 2;
+        seen[al * RC + jpp] = true;
+    }
+    for (int i = 0; i < NBF3; ++i) seen[i] = false;
+    for (int t = 0; t < NBF3; ++t) {
+        const int rho = pass3_rho<LayC>(t);
+        if (rho < 0 || rho >= NBF3 || seen[rho]) return 3;
+        seen[rho] = true;
+    }
     return 0;
 }
 

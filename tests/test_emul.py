@@ -23,7 +23,7 @@ def emul():
     E.emul_forward_bits.argtypes = [vp] * 4
     E.emul_forward_bits_sub.argtypes = [vp, vp, vp, i, i, vp]
     E.emul_forward_real.argtypes = [vp] * 2
-    E.emul_cell.argtypes = [vp, vp, i, i, i, i, i, vp, vp, vp]
+    E.emul_cell.argtypes = [vp, vp, i, i, i, i, i, i, vp, vp, vp]
     E.emul_code_replica.argtypes = [d, i, vp]
     E.emul_lo_masks.argtypes = [d, d, vp, vp]
     E.emul_search_code.argtypes = [i, i]
@@ -75,12 +75,18 @@ def test_emulated_kernels_vs_oracle(emul, golden_dir, fc, fs, file, mc, w1h):
     cells, _ = orc.search_block(blk, 7)
     d_in = np.ascontiguousarray(d_orc).view(np.float32)
     c_in = np.ascontiguousarray(c_orc).view(np.float32)
+    assert emul.emul_lane_maps_are_permutations() == 0
     for dop in (-orc.dmax, -9, 0, 1, orc.dmax):
-        mp, mi, tp = ctypes.c_float(), ctypes.c_int(), ctypes.c_float()
-        assert emul.emul_cell(_p(d_in), _p(c_in), 24, dop, orc.num_lags, mc, w1h, ctypes.byref(mp), ctypes.byref(mi), ctypes.byref(tp)) == 0
-        ref = cells[dop + orc.dmax]
-        assert abs(mp.value / ref["max_pwr"] - 1) < 2e-5 and abs(tp.value / ref["tot_pwr"] - 1) < 2e-5
-        assert mi.value == ref["max_i"]
+        got = {}
+        for lay in (1, 2):  # LayB (round 2's lane map) and LayC (the product's conflict-free lane assignment)
+            mp, mi, tp = ctypes.c_float(), ctypes.c_int(), ctypes.c_float()
+            assert emul.emul_cell(_p(d_in), _p(c_in), 24, dop, orc.num_lags, mc, w1h, lay, ctypes.byref(mp), ctypes.byref(mi), ctypes.byref(tp)) == 0
+            ref = cells[dop + orc.dmax]
+            assert abs(mp.value / ref["max_pwr"] - 1) < 2e-5 and abs(tp.value / ref["tot_pwr"] - 1) < 2e-5
+            assert mi.value == ref["max_i"]
+            got[lay] = (mp.value, mi.value, tp.value)
+        # the lane maps only re-deal the same butterflies: the peak is bit-identical, the power sum differs by its order at most
+        assert got[1][:2] == got[2][:2] and abs(got[1][2] / got[2][2] - 1) < 1e-6
 
 
 def test_emulated_subbin_forward_vs_oracle(emul, golden_dir):

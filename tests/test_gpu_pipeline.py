@@ -103,7 +103,8 @@ def test_fused_iq8_search_equals_convert_then_search(signed, mix, quirks):
         inp = eng.iq8_input(signed=signed, remove_dc=True, mean=mean, mix_hz=mix, fs=2.8e6, first_sample=0, total_samples=iq.size // 2)
         c2, p2 = eng.search_iq8(iq, inp, tasks=tasks)
         assert np.array_equal(c1, c2) and np.array_equal(p1, p2)
-        assert int(np.argmax([p2["snr"][i] for i in range(0, 3)])) == 0 and p2["snr"][0] > 25  # PRN 5 is found
+        if mix:  # mixed up to the IF the engine expects, PRN 5 is found (without the mixer the carrier sits at 0 Hz, not at fc)
+            assert int(np.argmax([p2["snr"][i] for i in range(0, 3)])) == 0 and p2["snr"][0] > 25
         # a batch that starts in mid-capture: first_sample carries the mixer phase
         off = 2
         inp2 = eng.iq8_input(signed=signed, remove_dc=True, mean=mean, mix_hz=mix, fs=2.8e6, first_sample=off * 40960, total_samples=iq.size // 2)

@@ -11,5 +11,5 @@ F="--offload-arch=gfx950 -O3 -std=c++17 -fPIC -Wno-unused-function $@"
 /opt/rocm/bin/hipcc $F -c gnss-gps-sdr_amd/csrc/acq_kernels.hip -o $d/k.o
 /opt/rocm/bin/hipcc $F -c gnss-gps-sdr_amd/csrc/iq_kernels.hip -o $d/i.o
 /opt/rocm/bin/hipcc $F -c gnss-gps-sdr_amd/csrc/gen_kernels.hip -o $d/g.o
-/opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o $d/libgpsacq.so $d/k.o $d/i.o $d/g.o $d/e.o $d/m.o -ldl
+/opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o $d/libgpsacq.so $d/k.o $d/i.o $d/g.o $d/e.o $d/m.o -ldl -pthread
 echo built $d/libgpsacq.so
