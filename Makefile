@@ -14,14 +14,15 @@ HOSTFLAGS:= -O2 -std=c++17 -fPIC -Wall -Wno-unknown-pragmas -ffp-contract=off
 all: lib host oracle emul
 
 lib: $(LIBDIR)/libgpsacq.so
-$(LIBDIR)/libgpsacq.so: $(CSRC)/acq_kernels.hip $(CSRC)/iq_kernels.hip $(CSRC)/gen_kernels.hip $(CSRC)/gpsacq_engine.cpp $(CSRC)/gpsacq_multi.cpp $(CSRC)/*.hpp include/gpsacq.h
+$(LIBDIR)/libgpsacq.so: $(CSRC)/acq_kernels.hip $(CSRC)/key_kernels.hip $(CSRC)/iq_kernels.hip $(CSRC)/gen_kernels.hip $(CSRC)/gpsacq_engine.cpp $(CSRC)/gpsacq_multi.cpp $(CSRC)/*.hpp include/gpsacq.h
 	@mkdir -p $(LIBDIR)
 	$(HIPCC) $(HIPFLAGS) -ffp-contract=off -c $(CSRC)/gpsacq_engine.cpp -o $(LIBDIR)/gpsacq_engine.o
 	$(HIPCC) $(HIPFLAGS) -c $(CSRC)/gpsacq_multi.cpp -o $(LIBDIR)/gpsacq_multi.o
 	$(HIPCC) $(HIPFLAGS) -c $(CSRC)/acq_kernels.hip -o $(LIBDIR)/acq_kernels.o
+	$(HIPCC) $(HIPFLAGS) -c $(CSRC)/key_kernels.hip -o $(LIBDIR)/key_kernels.o
 	$(HIPCC) $(HIPFLAGS) -c $(CSRC)/iq_kernels.hip -o $(LIBDIR)/iq_kernels.o
 	$(HIPCC) $(HIPFLAGS) -c $(CSRC)/gen_kernels.hip -o $(LIBDIR)/gen_kernels.o
-	$(HIPCC) --offload-arch=$(ARCH) -shared -fPIC -o $@ $(LIBDIR)/acq_kernels.o $(LIBDIR)/iq_kernels.o $(LIBDIR)/gen_kernels.o $(LIBDIR)/gpsacq_engine.o $(LIBDIR)/gpsacq_multi.o -ldl -pthread
+	$(HIPCC) --offload-arch=$(ARCH) -shared -fPIC -o $@ $(LIBDIR)/acq_kernels.o $(LIBDIR)/key_kernels.o $(LIBDIR)/iq_kernels.o $(LIBDIR)/gen_kernels.o $(LIBDIR)/gpsacq_engine.o $(LIBDIR)/gpsacq_multi.o -ldl -pthread
 
 host: $(LIBDIR)/libgps_search.so $(BINDIR)/gps_test $(BINDIR)/hip_floor
 # measurement aid of bench.py's e2e_cli leg: the wall clock of a HIP process that does nothing (runtime start-up floor)

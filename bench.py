@@ -146,7 +146,7 @@ def kernel_source_sha():
     on (tools/summarize_prof.py), so counters from another kernel binary are flagged instead of shipped silently."""
     import hashlib
     h = hashlib.sha256()
-    for name in ("acq_kernels.hip", "acq_phases.hpp", "acq_math.hpp", "acq_launch.hpp", "iq_convert.hpp"):
+    for name in ("acq_kernels.hip", "acq_phases.hpp", "acq_math.hpp"):
         with open(os.path.join(ROOT, "gnss-gps-sdr_amd", "csrc", name), "rb") as f:
             h.update(f.read())
     return h.hexdigest()[:16]
@@ -183,7 +183,7 @@ def cpu_baseline_all_cores(cfg, bits, ndop, one_thread_rate, target_s=8.0):
                       f"round-robin x {ndop} bins for {el.value:.1f} s = {cells} cells"}
 
 
-def e2e_cli(cfg, d_bits, n_runs, ndop, reps=3):
+def e2e_cli(cfg, d_bits, n_runs, ndop, reps=5):
     """The drop-in a user runs: wall clock of gnss-gps-sdr_amd/bin/gps_test on a capture FILE of the bench's size (written
     from the resident synthetic capture), process start to exit, with the front end's own split (GPSACQ_TRACE)."""
     import re
@@ -216,9 +216,9 @@ def e2e_cli(cfg, d_bits, n_runs, ndop, reps=3):
             fw.append(time.perf_counter() - t0)
         floor = min(fw)
     best = int(np.argmin(walls))
-    nums = {k: float(v) for k, v in re.findall(r"(SearchInit|SearchTask|mean pass|read|submit|wait for GPU|report) ([0-9.]+)", traces[best])}
+    nums = {k: float(v) for k, v in re.findall(r"(SearchInit|SearchTask|mean pass|buffers|read|submit|wait for GPU|report) ([0-9.]+)", traces[best])}
     cells = runs * 32 * ndop
-    return {"wall_s": walls[best], "wall_s_all": walls, "runs_reported": runs, "cells": cells, "cells_per_s": cells / walls[best],
+    return {"wall_s": walls[best], "wall_s_median": float(np.median(walls)), "wall_s_all": walls, "runs_reported": runs, "cells": cells, "cells_per_s": cells / walls[best],
             "file_bytes": int(host.size), "split_ms": nums, "hip_process_floor_s": floor,
             "wall_above_floor_s": (walls[best] - floor) if floor else None,
             "note": "process start + HIP runtime/module load + SearchInit + pipelined SearchTask (fread k+1 || search k || printf k-1)"}

@@ -151,15 +151,17 @@ __global__ __launch_bounds__(WG) void k_quirk_patch(QuirkArgs a) {
 #ifndef ACQ_CORR_LAYOUT
 #define ACQ_CORR_LAYOUT LayC  // -DACQ_CORR_LAYOUT=LayB builds round 2's lane map for A/B runs (tools/build_variant.sh)
 #endif
-// Experiment hook (tools/build_variant.sh -DACQ_EXP_PRIO=n; off in the product): static wave priority per phase, s_setprio.
-//   1: raised from the first input load of a sub-transform until its pass-1 stores are out   2: raised outside pass 2   3: raised in pass 2
-#ifndef ACQ_EXP_PRIO
-#define ACQ_EXP_PRIO 0
+// Wave priority (round 3, profiles/r03_experiments/b_priority_stagger.log): a wave runs the first phase of a sub-transform --
+// input loads, product, radix-10 pair, pass-1 stores: the short, latency-bound part that ends in the barrier its three
+// partner waves wait at -- one priority level above the long radix-25 / radix-20 phases of the waves of OTHER workgroups it
+// shares the SIMD with.  Measured -1.9 % kernel time, repeatably (16.36 vs 16.67 ms per 299 008 cells, same box, two passes);
+// levels 1, 2, 3 are equivalent; raising it only while the loads are issued, or also in pass 3, the scan or pass 2, gains
+// nothing or less.  -DACQ_NO_PHASE1_PRIO builds the kernel without it (tools/build_kvariant.sh).
+#ifdef ACQ_NO_PHASE1_PRIO
+#define ACQ_PHASE1_PRIO(level) ((void)0)
+#else
+#define ACQ_PHASE1_PRIO(level) __builtin_amdgcn_s_setprio(level)
 #endif
-#define ACQ_SETPRIO(when, level)                                         \
-    do {                                                                 \
-        if (ACQ_EXP_PRIO == (when)) __builtin_amdgcn_s_setprio(level);   \
-    } while (0)
 template <class L> __device__ __forceinline__ int corr_rho(const CorrArgs& a, int t3) {
     if constexpr (L::REMAP) return (int)a.rho_map[t3];
     else return pass3_rho<L>(t3);
@@ -228,20 +230,16 @@ __global__ __launch_bounds__(WG, WPS) void k_corr(CorrArgs a) {
                 for (int m = 0; m < MC; ++m) wq_early[m] = c_wq[q * WQ_STRIDE + a.m0 + m];
             }
             const cf* wqv = MC <= 22 ? wq_early : c_wq + q * WQ_STRIDE + a.m0;
-            ACQ_SETPRIO(1, 2);
+            ACQ_PHASE1_PRIO(1);
             corr_phase1<NB, W1H, L>(tid, q, dop, dk, cpp, a.crow, a.halo, w1, lds);
-            ACQ_SETPRIO(1, 0);
-            ACQ_SETPRIO(2, 0);
+            ACQ_PHASE1_PRIO(0);
             ACQ_STAMP(1);  // inputs loaded and multiplied, pass 1, its LDS stores drained (the stamp waits on lgkmcnt)
             __syncthreads();  // also orders the t2s fill before its first use
             ACQ_STAMP(2);
-            ACQ_SETPRIO(3, 2);
             corr_phase2<L>(tid, t2s, lds);
-            ACQ_SETPRIO(3, 0);
             ACQ_STAMP(3);
             __syncthreads();
             ACQ_STAMP(4);
-            ACQ_SETPRIO(2, 2);
             corr_phase3<MC, L>(tid, rho, b, wqv, lds, acc);
             ACQ_STAMP(5);
             __syncthreads();
@@ -357,34 +355,6 @@ __global__ __launch_bounds__(WG) void k_peaks(const Cell* cells, Peak* peaks, in
     }
 }
 
-// Multi-GPU merge key of a peak: integer MAX over
-//   key = snr bits << 32 | (0xFFFF - (lo_shift + kmax)) << 16 | ca_shift
-// picks the higher SNR and, on equal SNR, the LOWER Doppler grid point -- the reference's strict '>' scan over
-// ascending dop (:196-198).  Non-negative IEEE floats order like their bit patterns.
-__global__ void k_pack_keys(const Peak* peaks, unsigned long long* keys, int n, int kmax) {
-    const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= n) return;
-    const Peak p = peaks[i];
-    const unsigned long long snr = (unsigned long long)__float_as_uint(p.snr > 0.f ? p.snr : 0.f);
-    const unsigned long long lo = (unsigned long long)(0xFFFF - (p.lo_shift + kmax)) & 0xFFFFull;
-    keys[i] = (snr << 32) | (lo << 16) | ((unsigned long long)p.ca_shift & 0xFFFFull);
-}
-
-// Reference schedule (task t <-> PRN t % 32): the best key of each PRN over all runs of this device -- what the one
-// all-reduce of the block decomposition carries (32 keys).  One workgroup, thread (r, sv) strides over the runs.
-__global__ __launch_bounds__(WG) void k_prn_best(const unsigned long long* keys, int n_tasks, unsigned long long* best) {
-    __shared__ unsigned long long part[WG];
-    const int sv = threadIdx.x & 31, lane_run = threadIdx.x >> 5;  // 8 runs in flight per pass
-    unsigned long long k = 0;
-    for (int t = lane_run * 32 + sv; t < n_tasks; t += WG) k = keys[t] > k ? keys[t] : k;
-    part[threadIdx.x] = k;
-    __syncthreads();
-    if (threadIdx.x < 32) {
-        for (int r = 1; r < WG / 32; ++r) k = part[r * 32 + sv] > k ? part[r * 32 + sv] : k;
-        best[sv] = k;
-    }
-}
-
 // ---------------------------------------------------------------------------------------
 // launchers (host)
 void launch_fwd_bits(const FwdArgs& a, int n_items, hipStream_t s) {
@@ -444,12 +414,6 @@ int launch_corr(const CorrArgs& a, int mc, hipStream_t s) {
 }
 void launch_merge_cells(const Cell* parts, Cell* cells, size_t n_cells, int n_parts, int nlags, hipStream_t s) {
     hipLaunchKernelGGL(k_merge_cells, dim3((unsigned)((n_cells + 255) / 256)), dim3(256), 0, s, parts, cells, n_cells, n_parts, nlags);
-}
-void launch_pack_keys(const Peak* peaks, unsigned long long* keys, int n, int kmax, hipStream_t s) {
-    hipLaunchKernelGGL(k_pack_keys, dim3((n + 255) / 256), dim3(256), 0, s, peaks, keys, n, kmax);
-}
-void launch_prn_best(const unsigned long long* keys, int n_tasks, unsigned long long* best, hipStream_t s) {
-    hipLaunchKernelGGL(k_prn_best, dim3(1), dim3(WG), 0, s, keys, n_tasks, best);
 }
 void launch_peaks(const Cell* cells, Peak* peaks, int n_tasks, int ndop, int dop_first, hipStream_t s) {
     const int per_wg = WG / 64;

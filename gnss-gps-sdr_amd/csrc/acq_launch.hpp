@@ -68,7 +68,11 @@ hipError_t upload_wq(const cf* host);  // fills the __constant__ copy of wq on t
 int launch_corr(const CorrArgs& a, int mc, hipStream_t s);
 void launch_merge_cells(const Cell* parts, Cell* cells, size_t n_cells, int n_parts, int nlags, hipStream_t s);
 void launch_pack_keys(const Peak* peaks, unsigned long long* keys, int n, int kmax, hipStream_t s);
-void launch_prn_best(const unsigned long long* keys, int n_tasks, unsigned long long* best, hipStream_t s);
+void launch_prn_best(const unsigned long long* keys, const Peak* peaks, int n_tasks, unsigned long long* best, float* best_pwr, hipStream_t s);
+void launch_max_u64(unsigned long long* dst, const unsigned long long* src, int n, hipStream_t s);
+void launch_max_f32(float* dst, const float* src, int n, hipStream_t s);
+void launch_winner_pwr(const unsigned long long* own, const unsigned long long* merged, const float* own_pwr, float* out, int n, hipStream_t s);
+void launch_peak_pwr(const Peak* peaks, float* pwr, int n, hipStream_t s);
 void launch_peaks(const Cell* cells, Peak* peaks, int n_tasks, int ndop, int dop_first, hipStream_t s);
 
 }  // namespace acq

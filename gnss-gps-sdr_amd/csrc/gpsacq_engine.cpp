@@ -702,15 +702,29 @@ extern "C" uint8_t* gpsacq_pipe_buffer(gpsacq_engine* e, int slot, size_t nbytes
         return nullptr;
     }
     if (nbytes > sl->h_cap) {
+        // everything a batch of this size needs, once: pinned staging, its device copy, and peak arrays for the most blocks
+        // nbytes can hold (a block is at least 5000 bytes) -- submits then allocate nothing
         if (sl->h_in) (void)hipHostFree(sl->h_in);
+        if (sl->d_in) (void)hipFree(sl->d_in);
+        if (sl->d_peaks) (void)hipFree(sl->d_peaks);
+        if (sl->h_peaks) (void)hipHostFree(sl->h_peaks);
         sl->h_in = nullptr;
-        sl->h_cap = 0;
+        sl->d_in = nullptr;
+        sl->d_peaks = nullptr;
+        sl->h_peaks = nullptr;
+        sl->h_cap = sl->d_cap = sl->peak_cap = 0;
+        const size_t max_blocks = nbytes / (size_t)USED_BYTES + 1;
         hipError_t he = hipHostMalloc((void**)&sl->h_in, nbytes, hipHostMallocDefault);
+        if (he == hipSuccess) he = hipMalloc((void**)&sl->d_in, nbytes + 16);
+        if (he == hipSuccess) he = hipMalloc((void**)&sl->d_peaks, max_blocks * sizeof(Peak));
+        if (he == hipSuccess) he = hipHostMalloc((void**)&sl->h_peaks, max_blocks * sizeof(Peak), hipHostMallocDefault);
         if (he != hipSuccess) {
-            fail(he == hipErrorOutOfMemory ? GPSACQ_ERR_NOMEM : GPSACQ_ERR_DEVICE, "hipHostMalloc(%zu): %s", nbytes, hipGetErrorString(he));
+            fail(he == hipErrorOutOfMemory ? GPSACQ_ERR_NOMEM : GPSACQ_ERR_DEVICE, "gpsacq_pipe_buffer(%zu bytes): %s", nbytes, hipGetErrorString(he));
             return nullptr;
         }
         sl->h_cap = nbytes;
+        sl->d_cap = nbytes + 16;
+        sl->peak_cap = max_blocks;
     }
     return sl->h_in;
 }
@@ -730,24 +744,8 @@ extern "C" int gpsacq_pipe_submit(gpsacq_engine* e, int slot, size_t n_blocks, s
         nbytes = (n_blocks - 1) * stride + (stride < (size_t)BLOCK_BYTES ? stride : (size_t)BLOCK_BYTES);
     }
     if (!sl->h_in || nbytes > sl->h_cap) return fail(GPSACQ_ERR_ARG, "gpsacq_pipe_submit: slot %d holds %zu bytes, the batch needs %zu", slot, sl->h_cap, nbytes);
-    if (nbytes + 16 > sl->d_cap) {  // (the previous search of this slot was collected: nothing reads the old buffer)
-        if (sl->d_in) HIPCHK(hipFree(sl->d_in));
-        sl->d_in = nullptr;
-        sl->d_cap = 0;
-        const size_t want = std::max(nbytes + 16, sl->h_cap + 16);
-        HIPCHK(hipMalloc((void**)&sl->d_in, want));
-        sl->d_cap = want;
-    }
-    if (n_blocks > sl->peak_cap) {
-        if (sl->d_peaks) HIPCHK(hipFree(sl->d_peaks));
-        if (sl->h_peaks) HIPCHK(hipHostFree(sl->h_peaks));
-        sl->d_peaks = nullptr;
-        sl->h_peaks = nullptr;
-        sl->peak_cap = 0;
-        HIPCHK(hipMalloc((void**)&sl->d_peaks, n_blocks * sizeof(Peak)));
-        HIPCHK(hipHostMalloc((void**)&sl->h_peaks, n_blocks * sizeof(Peak), hipHostMallocDefault));
-        sl->peak_cap = n_blocks;
-    }
+    if (nbytes + 16 > sl->d_cap || n_blocks > sl->peak_cap)
+        return fail(GPSACQ_ERR_ARG, "gpsacq_pipe_submit: slot %d was sized for %zu bytes / %zu blocks", slot, sl->h_cap, sl->peak_cap);
     HIPCHK(hipMemcpyAsync(sl->d_in, sl->h_in, nbytes, hipMemcpyHostToDevice, e->copy_stream));
     HIPCHK(hipEventRecord(sl->uploaded, e->copy_stream));
     HIPCHK(hipStreamWaitEvent(e->stream, sl->uploaded, 0));

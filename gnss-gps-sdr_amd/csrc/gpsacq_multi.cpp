@@ -4,6 +4,11 @@
 // step of the path (BASELINE.json north_star: "RCCL all-reduce of the per-PRN peak only").  The reference has no
 // parallelism at all (c/search_offline.cpp is one thread); every (block, PRN, Doppler) cell is independent.
 //
+// Engines may share a physical GPU (the same ordinal listed more than once): RCCL joins distinct GPUs only, so engines of one
+// GPU first merge their keys on that GPU (k_max_u64) and one representative per GPU takes part in the all-reduce; with every
+// engine on one GPU no RCCL call is made at all (and RCCL is not even loaded) -- which is also how the N > 1 control flow
+// (partitions, per-engine buffers, merge, window restore) is tested on the one-GPU box.
+//
 // RCCL is loaded with dlopen at the first gpsacq_multi_create so that libgpsacq.so carries no link dependency on it
 // (a process that already holds an RCCL -- PyTorch bundles one under the same SONAME -- keeps using that copy).
 #include <dlfcn.h>
@@ -79,12 +84,19 @@ struct DeviceGuard {
 struct gpsacq_multi {
     std::vector<gpsacq_engine*> eng;
     std::vector<int> dev;
-    std::vector<ncclComm_t> comm;
+    std::vector<int> rep;            // engine i's representative: the first engine on the same physical GPU
+    std::vector<int> reps;           // the representatives (one engine per distinct GPU), engine 0 first
+    std::vector<ncclComm_t> comm;    // per engine; non-NULL for representatives when more than one GPU takes part
+    std::vector<hipEvent_t> ev;      // per engine: orders a partner's stream behind this engine's work
     std::vector<uint8_t*> d_bits;
     std::vector<size_t> bits_cap;
     std::vector<Task*> d_tasks;
     std::vector<Peak*> d_peaks;
+    // per engine, each (task_cap + 32) entries: own keys, merged keys; own winner powers, merged winner powers
     std::vector<unsigned long long*> d_keys;
+    std::vector<unsigned long long*> d_merged;
+    std::vector<float*> d_pwr;
+    std::vector<float*> d_pwr_merged;
     std::vector<size_t> task_cap;
     gpsacq_info info{};
 };
@@ -103,7 +115,9 @@ extern "C" void gpsacq_multi_destroy(gpsacq_multi* m) {
         (void)hipSetDevice(m->dev[i]);
         (void)gpsacq_synchronize(m->eng[i]);
         if (i < m->comm.size() && m->comm[i]) (void)g_rccl.CommDestroy(m->comm[i]);
-        for (void* p : {(void*)m->d_bits[i], (void*)m->d_tasks[i], (void*)m->d_peaks[i], (void*)m->d_keys[i]})
+        if (i < m->ev.size() && m->ev[i]) (void)hipEventDestroy(m->ev[i]);
+        for (void* p : {(void*)m->d_bits[i], (void*)m->d_tasks[i], (void*)m->d_peaks[i], (void*)m->d_keys[i], (void*)m->d_merged[i],
+                        (void*)m->d_pwr[i], (void*)m->d_pwr_merged[i]})
             if (p) (void)hipFree(p);
         gpsacq_destroy(m->eng[i]);
     }
@@ -113,34 +127,63 @@ extern "C" void gpsacq_multi_destroy(gpsacq_multi* m) {
 extern "C" int gpsacq_multi_create(const gpsacq_params* params, const int32_t* devices, int n_devices, gpsacq_multi** out) {
     if (!params || !out || n_devices < 1 || n_devices > 64) return failf(GPSACQ_ERR_ARG, "gpsacq_multi_create: bad argument");
     *out = nullptr;
-    if (const char* why = load_rccl()) return failf(GPSACQ_ERR_DEVICE, "RCCL unavailable: %s", why);
     DeviceGuard guard;
     gpsacq_multi* m = new gpsacq_multi();
     const size_t n = (size_t)n_devices;
     m->eng.assign(n, nullptr);
     m->dev.resize(n);
+    m->rep.resize(n);
+    m->comm.assign(n, nullptr);
+    m->ev.assign(n, nullptr);
     m->d_bits.assign(n, nullptr);
     m->bits_cap.assign(n, 0);
     m->d_tasks.assign(n, nullptr);
     m->d_peaks.assign(n, nullptr);
     m->d_keys.assign(n, nullptr);
+    m->d_merged.assign(n, nullptr);
+    m->d_pwr.assign(n, nullptr);
+    m->d_pwr_merged.assign(n, nullptr);
     m->task_cap.assign(n, 0);
     for (size_t i = 0; i < n; ++i) {
         m->dev[i] = devices ? devices[i] : (int)i;
+        m->rep[i] = (int)i;
+        for (size_t j = 0; j < i; ++j)
+            if (m->dev[j] == m->dev[i]) {
+                m->rep[i] = m->rep[j];
+                break;
+            }
+        if (m->rep[i] == (int)i) m->reps.push_back((int)i);
+    }
+    for (size_t i = 0; i < n; ++i) {
         gpsacq_params p = *params;
         p.device = m->dev[i];
         if (int rc = gpsacq_create(&p, &m->eng[i])) {
             gpsacq_multi_destroy(m);
             return rc;
         }
+        hipError_t he = hipEventCreateWithFlags(&m->ev[i], hipEventDisableTiming);
+        if (he != hipSuccess) {
+            int rc = failf(GPSACQ_ERR_DEVICE, "hipEventCreate: %s", hipGetErrorString(he));
+            gpsacq_multi_destroy(m);
+            return rc;
+        }
     }
-    m->comm.assign(n, nullptr);
-    ncclResult_t r = g_rccl.CommInitAll(m->comm.data(), n_devices, m->dev.data());
-    if (r != ncclSuccess) {
-        int rc = failf(GPSACQ_ERR_DEVICE, "ncclCommInitAll over %d device(s): %s", n_devices, g_rccl.GetErrorString(r));
-        for (auto& c : m->comm) c = nullptr;
-        gpsacq_multi_destroy(m);
-        return rc;
+    if (m->reps.size() > 1) {  // one communicator rank per distinct GPU
+        if (const char* why = load_rccl()) {
+            int rc = failf(GPSACQ_ERR_DEVICE, "RCCL unavailable: %s", why);
+            gpsacq_multi_destroy(m);
+            return rc;
+        }
+        std::vector<ncclComm_t> comms(m->reps.size(), nullptr);
+        std::vector<int> devs;
+        for (int r : m->reps) devs.push_back(m->dev[r]);
+        ncclResult_t r = g_rccl.CommInitAll(comms.data(), (int)devs.size(), devs.data());
+        if (r != ncclSuccess) {
+            int rc = failf(GPSACQ_ERR_DEVICE, "ncclCommInitAll over %zu device(s): %s", devs.size(), g_rccl.GetErrorString(r));
+            gpsacq_multi_destroy(m);
+            return rc;
+        }
+        for (size_t k = 0; k < m->reps.size(); ++k) m->comm[m->reps[k]] = comms[k];
     }
     (void)gpsacq_get_info(m->eng[0], &m->info);
     *out = m;
@@ -176,14 +219,20 @@ int grow_dev(gpsacq_multi* m, size_t i, size_t nbytes, size_t n_tasks) {
         m->bits_cap[i] = nbytes;
     }
     if (n_tasks > m->task_cap[i]) {
-        for (void** p : {(void**)&m->d_tasks[i], (void**)&m->d_peaks[i], (void**)&m->d_keys[i]}) {
+        // (a partner engine of the same GPU may still read the merge buffers of an earlier call: that call has been waited for)
+        for (void** p : {(void**)&m->d_tasks[i], (void**)&m->d_peaks[i], (void**)&m->d_keys[i], (void**)&m->d_merged[i], (void**)&m->d_pwr[i],
+                         (void**)&m->d_pwr_merged[i]}) {
             if (*p) HIPM(hipFreeAsync(*p, st));
             *p = nullptr;
         }
         m->task_cap[i] = 0;
+        const size_t nk = n_tasks + GPSACQ_NUM_SATS;  // + the 32 per-PRN entries of the block decomposition
         HIPM(hipMallocAsync((void**)&m->d_tasks[i], n_tasks * sizeof(Task), st));
         HIPM(hipMallocAsync((void**)&m->d_peaks[i], n_tasks * sizeof(Peak), st));
-        HIPM(hipMallocAsync((void**)&m->d_keys[i], (n_tasks + GPSACQ_NUM_SATS) * sizeof(unsigned long long), st));  // + the 32 per-PRN keys
+        HIPM(hipMallocAsync((void**)&m->d_keys[i], nk * sizeof(unsigned long long), st));
+        HIPM(hipMallocAsync((void**)&m->d_merged[i], nk * sizeof(unsigned long long), st));
+        HIPM(hipMallocAsync((void**)&m->d_pwr[i], nk * sizeof(float), st));
+        HIPM(hipMallocAsync((void**)&m->d_pwr_merged[i], nk * sizeof(float), st));
         m->task_cap[i] = n_tasks;
     }
     return GPSACQ_OK;
@@ -195,33 +244,88 @@ void drain(gpsacq_multi* m) {
         (void)hipStreamSynchronize((hipStream_t)gpsacq_stream(m->eng[i]));
     }
 }
-// the path's one collective: all-reduce(MAX) of `count` 64-bit keys at keys[i] + offset[i] across the devices
-int allreduce_keys(gpsacq_multi* m, const std::vector<unsigned long long*>& keys, size_t count) {
-    ncclResult_t r = g_rccl.GroupStart();
-    if (r != ncclSuccess) return failf(GPSACQ_ERR_DEVICE, "ncclGroupStart: %s", g_rccl.GetErrorString(r));
-    ncclResult_t first_bad = ncclSuccess;
-    int bad_dev = -1;
-    for (size_t i = 0; i < m->eng.size(); ++i) {
-        // every rank of the group is enqueued even after a failure: ending a group that some ranks never joined can hang
-        r = g_rccl.AllReduce(keys[i], keys[i], count, ncclUint64, ncclMax, m->comm[i], (hipStream_t)gpsacq_stream(m->eng[i]));
-        if (r != ncclSuccess && first_bad == ncclSuccess) {
-            first_bad = r;
-            bad_dev = m->dev[i];
+// MAX-merge of one array per engine (64-bit keys, or float powers): engines of one GPU merge into their representative on
+// the device, the representatives all-reduce over RCCL (the path's one exchange step between GPUs), and every engine gets
+// the result back.  buf[i]: engine i's array (in: own values, out: merged), `count` entries.
+template <class T>
+int merge_max(gpsacq_multi* m, const std::vector<T*>& buf, size_t count) {
+    const size_t n = m->eng.size();
+    auto stream = [&](size_t i) { return (hipStream_t)gpsacq_stream(m->eng[i]); };
+    auto launch_max = [&](T* dst, const T* src, hipStream_t st) {
+        if constexpr (sizeof(T) == 8) launch_max_u64((unsigned long long*)dst, (const unsigned long long*)src, (int)count, st);
+        else launch_max_f32((float*)dst, (const float*)src, (int)count, st);
+    };
+    // 1. partners -> representative, on the representative's stream, behind the partner's own work
+    for (size_t j = 0; j < n; ++j) {
+        if (m->rep[j] == (int)j) continue;
+        const size_t r = (size_t)m->rep[j];
+        HIPM(hipSetDevice(m->dev[j]));
+        HIPM(hipEventRecord(m->ev[j], stream(j)));
+        HIPM(hipStreamWaitEvent(stream(r), m->ev[j], 0));
+        launch_max(buf[r], buf[j], stream(r));
+        HIPM(hipGetLastError());
+    }
+    // 2. across GPUs
+    if (m->reps.size() > 1) {
+        ncclResult_t r = g_rccl.GroupStart();
+        if (r != ncclSuccess) return failf(GPSACQ_ERR_DEVICE, "ncclGroupStart: %s", g_rccl.GetErrorString(r));
+        ncclResult_t first_bad = ncclSuccess;
+        int bad_dev = -1;
+        for (int i : m->reps) {
+            // every rank of the group is enqueued even after a failure: ending a group that some ranks never joined can hang
+            r = g_rccl.AllReduce(buf[i], buf[i], count, sizeof(T) == 8 ? ncclUint64 : ncclFloat32, ncclMax, m->comm[i], stream((size_t)i));
+            if (r != ncclSuccess && first_bad == ncclSuccess) {
+                first_bad = r;
+                bad_dev = m->dev[i];
+            }
+        }
+        r = g_rccl.GroupEnd();
+        if (first_bad != ncclSuccess) return failf(GPSACQ_ERR_DEVICE, "ncclAllReduce on device %d: %s", bad_dev, g_rccl.GetErrorString(first_bad));
+        if (r != ncclSuccess) return failf(GPSACQ_ERR_DEVICE, "ncclGroupEnd: %s", g_rccl.GetErrorString(r));
+    }
+    // 3. representative -> partners
+    for (int ri : m->reps) {
+        bool has_partner = false;
+        for (size_t j = 0; j < n; ++j) has_partner |= (m->rep[j] == ri && (int)j != ri);
+        if (!has_partner) continue;
+        HIPM(hipSetDevice(m->dev[ri]));
+        HIPM(hipEventRecord(m->ev[ri], stream((size_t)ri)));
+        for (size_t j = 0; j < n; ++j) {
+            if (m->rep[j] != ri || (int)j == ri) continue;
+            HIPM(hipStreamWaitEvent(stream(j), m->ev[ri], 0));
+            HIPM(hipMemcpyAsync(buf[j], buf[ri], count * sizeof(T), hipMemcpyDeviceToDevice, stream(j)));
         }
     }
-    r = g_rccl.GroupEnd();
-    if (first_bad != ncclSuccess) return failf(GPSACQ_ERR_DEVICE, "ncclAllReduce on device %d: %s", bad_dev, g_rccl.GetErrorString(first_bad));
-    if (r != ncclSuccess) return failf(GPSACQ_ERR_DEVICE, "ncclGroupEnd: %s", g_rccl.GetErrorString(r));
     return GPSACQ_OK;
 }
-void unpack_key(unsigned long long k, int kmax, gpsacq_peak* p) {
+// keys: own -> merged (copy, merge); then the winners' max_pwr the same way.  own_keys / own_pwr are per-engine arrays at `off`.
+int merge_peaks(gpsacq_multi* m, size_t off, size_t count) {
+    const size_t n = m->eng.size();
+    std::vector<unsigned long long*> mk(n);
+    std::vector<float*> mp(n);
+    for (size_t i = 0; i < n; ++i) {
+        HIPM(hipSetDevice(m->dev[i]));
+        hipStream_t st = (hipStream_t)gpsacq_stream(m->eng[i]);
+        mk[i] = m->d_merged[i] + off;
+        mp[i] = m->d_pwr_merged[i] + off;
+        HIPM(hipMemcpyAsync(mk[i], m->d_keys[i] + off, count * sizeof(unsigned long long), hipMemcpyDeviceToDevice, st));
+    }
+    if (int rc = merge_max(m, mk, count)) return rc;
+    for (size_t i = 0; i < n; ++i) {
+        HIPM(hipSetDevice(m->dev[i]));
+        launch_winner_pwr(m->d_keys[i] + off, mk[i], m->d_pwr[i] + off, mp[i], (int)count, (hipStream_t)gpsacq_stream(m->eng[i]));
+        HIPM(hipGetLastError());
+    }
+    return merge_max(m, mp, count);
+}
+void unpack_key(unsigned long long k, float pwr, int kmax, gpsacq_peak* p) {
     const uint32_t sb = (uint32_t)(k >> 32);
     float snr;
     memcpy(&snr, &sb, sizeof snr);
     p->snr = snr;
     p->lo_shift = k ? (int32_t)(0xFFFF - ((k >> 16) & 0xFFFF)) - kmax : 0;
     p->ca_shift = (int32_t)(k & 0xFFFF);
-    p->max_pwr = 0.f;  // not carried by the key
+    p->max_pwr = pwr;  // not carried by the key: merged separately (the winner's value)
 }
 }  // namespace
 
@@ -243,20 +347,24 @@ static int search_grid_impl(gpsacq_multi* m, const uint8_t* bits, size_t n_block
             if (int rc = gpsacq_set_doppler_window(m->eng[i], first + off, cnt)) return rc;
             if (int rc = gpsacq_search_device(m->eng[i], m->d_bits[i], n_blocks, stride, m->d_tasks[i], n_tasks, nullptr, m->d_peaks[i], 0)) return rc;
             launch_pack_keys(m->d_peaks[i], m->d_keys[i], (int)n_tasks, kmax, st);
+            launch_peak_pwr(m->d_peaks[i], m->d_pwr[i], (int)n_tasks, st);
             HIPM(hipGetLastError());
         } else {
             HIPM(hipMemsetAsync(m->d_keys[i], 0, n_tasks * sizeof(unsigned long long), st));  // key 0 = "nothing found": neutral for MAX
+            HIPM(hipMemsetAsync(m->d_pwr[i], 0, n_tasks * sizeof(float), st));
         }
     }
-    if (int rc = allreduce_keys(m, m->d_keys, n_tasks)) return rc;
+    if (int rc = merge_peaks(m, 0, n_tasks)) return rc;
     std::vector<unsigned long long> keys(n_tasks);
+    std::vector<float> pwr(n_tasks);
     HIPM(hipSetDevice(m->dev[0]));
-    HIPM(hipMemcpyAsync(keys.data(), m->d_keys[0], n_tasks * sizeof(unsigned long long), hipMemcpyDeviceToHost, (hipStream_t)gpsacq_stream(m->eng[0])));
+    HIPM(hipMemcpyAsync(keys.data(), m->d_merged[0], n_tasks * sizeof(unsigned long long), hipMemcpyDeviceToHost, (hipStream_t)gpsacq_stream(m->eng[0])));
+    HIPM(hipMemcpyAsync(pwr.data(), m->d_pwr_merged[0], n_tasks * sizeof(float), hipMemcpyDeviceToHost, (hipStream_t)gpsacq_stream(m->eng[0])));
     for (size_t i = 0; i < n; ++i) {
         HIPM(hipSetDevice(m->dev[i]));
         HIPM(hipStreamSynchronize((hipStream_t)gpsacq_stream(m->eng[i])));
     }
-    for (size_t t = 0; t < n_tasks; ++t) unpack_key(keys[t], kmax, &peaks[t]);
+    for (size_t t = 0; t < n_tasks; ++t) unpack_key(keys[t], pwr[t], kmax, &peaks[t]);
     return GPSACQ_OK;
 }
 
@@ -282,40 +390,47 @@ extern "C" int gpsacq_multi_search_grid(gpsacq_multi* m, const uint8_t* bits, si
 static int search_blocks_impl(gpsacq_multi* m, const uint8_t* bits, size_t n_runs, size_t stride, gpsacq_peak* peaks, gpsacq_peak* best) {
     const size_t n = m->eng.size();
     const int first = m->info.first_doppler_total, total = m->info.num_doppler_total, kmax = -first;
-    std::vector<unsigned long long*> prn_keys(n, nullptr);
+    size_t off = 0;  // the 32 per-PRN entries live behind the per-task entries: the same offset on every engine
+    {
+        const size_t base = n_runs / n, rem = n_runs % n;
+        off = std::max((base + (rem ? 1 : 0)) * GPSACQ_NUM_SATS, (size_t)1);
+        for (size_t i = 0; i < n; ++i) off = std::max(off, m->task_cap[i]);
+    }
     for (size_t i = 0; i < n; ++i) {
         // contiguous, balanced range of whole runs for device i; a run starts at PRN index 0, so the reference schedule
         // (block t <-> PRN t % 32) holds inside every range
         const size_t base = n_runs / n, rem = n_runs % n;
-        const size_t cnt = base + (i < rem ? 1 : 0), off = i * base + (i < rem ? i : rem);
+        const size_t cnt = base + (i < rem ? 1 : 0), first_run = i * base + (i < rem ? i : rem);
         const size_t nblk = cnt * GPSACQ_NUM_SATS;
         HIPM(hipSetDevice(m->dev[i]));
         hipStream_t st = (hipStream_t)gpsacq_stream(m->eng[i]);
         const size_t nbytes = nblk ? (nblk - 1) * stride + GPSACQ_BLOCK_BYTES : 0;
-        if (int rc = grow_dev(m, i, std::max(nbytes, (size_t)1), std::max(nblk, (size_t)1))) return rc;
-        prn_keys[i] = m->d_keys[i] + m->task_cap[i];  // the 32 per-PRN keys live behind the per-task keys
+        if (int rc = grow_dev(m, i, std::max(nbytes, (size_t)1), off)) return rc;
         if (nblk > 0) {
-            HIPM(hipMemcpyAsync(m->d_bits[i], bits + off * GPSACQ_NUM_SATS * stride, nbytes, hipMemcpyHostToDevice, st));
+            HIPM(hipMemcpyAsync(m->d_bits[i], bits + first_run * GPSACQ_NUM_SATS * stride, nbytes, hipMemcpyHostToDevice, st));
             if (int rc = gpsacq_set_doppler_window(m->eng[i], first, total)) return rc;  // every device scans the whole grid
             if (int rc = gpsacq_search_device(m->eng[i], m->d_bits[i], nblk, stride, nullptr, nblk, nullptr, m->d_peaks[i], 0)) return rc;
             launch_pack_keys(m->d_peaks[i], m->d_keys[i], (int)nblk, kmax, st);
-            launch_prn_best(m->d_keys[i], (int)nblk, prn_keys[i], st);
+            launch_prn_best(m->d_keys[i], m->d_peaks[i], (int)nblk, m->d_keys[i] + off, m->d_pwr[i] + off, st);
             HIPM(hipGetLastError());
-            if (peaks) HIPM(hipMemcpyAsync(peaks + off * GPSACQ_NUM_SATS, m->d_peaks[i], nblk * sizeof(Peak), hipMemcpyDeviceToHost, st));
+            if (peaks) HIPM(hipMemcpyAsync(peaks + first_run * GPSACQ_NUM_SATS, m->d_peaks[i], nblk * sizeof(Peak), hipMemcpyDeviceToHost, st));
         } else {
-            HIPM(hipMemsetAsync(prn_keys[i], 0, GPSACQ_NUM_SATS * sizeof(unsigned long long), st));  // neutral for MAX
+            HIPM(hipMemsetAsync(m->d_keys[i] + off, 0, GPSACQ_NUM_SATS * sizeof(unsigned long long), st));  // neutral for MAX
+            HIPM(hipMemsetAsync(m->d_pwr[i] + off, 0, GPSACQ_NUM_SATS * sizeof(float), st));
         }
     }
-    if (int rc = allreduce_keys(m, prn_keys, GPSACQ_NUM_SATS)) return rc;
+    if (int rc = merge_peaks(m, off, GPSACQ_NUM_SATS)) return rc;
     unsigned long long keys[GPSACQ_NUM_SATS];
+    float pwr[GPSACQ_NUM_SATS];
     HIPM(hipSetDevice(m->dev[0]));
-    HIPM(hipMemcpyAsync(keys, prn_keys[0], sizeof keys, hipMemcpyDeviceToHost, (hipStream_t)gpsacq_stream(m->eng[0])));
+    HIPM(hipMemcpyAsync(keys, m->d_merged[0] + off, sizeof keys, hipMemcpyDeviceToHost, (hipStream_t)gpsacq_stream(m->eng[0])));
+    HIPM(hipMemcpyAsync(pwr, m->d_pwr_merged[0] + off, sizeof pwr, hipMemcpyDeviceToHost, (hipStream_t)gpsacq_stream(m->eng[0])));
     for (size_t i = 0; i < n; ++i) {
         HIPM(hipSetDevice(m->dev[i]));
         HIPM(hipStreamSynchronize((hipStream_t)gpsacq_stream(m->eng[i])));
     }
     if (best)
-        for (int sv = 0; sv < GPSACQ_NUM_SATS; ++sv) unpack_key(keys[sv], kmax, &best[sv]);
+        for (int sv = 0; sv < GPSACQ_NUM_SATS; ++sv) unpack_key(keys[sv], pwr[sv], kmax, &best[sv]);
     return GPSACQ_OK;
 }
 

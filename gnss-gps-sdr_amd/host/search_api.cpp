@@ -212,12 +212,17 @@ void SearchTask(char *filename_1bit_bin) {
     }
 
     // ---- the pipeline -------------------------------------------------------------------------------------------
-    for (gpsacq_engine *e : g_engines)  // scratch for the largest batch once, not regrown as the batches ramp up
-        if (gpsacq_reserve(e, max_runs * GPSACQ_NUM_SATS) != GPSACQ_OK) {
+    const Clock::time_point t_setup = Clock::now();
+    for (gpsacq_engine *e : g_engines) {  // scratch and staging for the largest batch once, not regrown as the batches ramp up
+        bool ok = gpsacq_reserve(e, max_runs * GPSACQ_NUM_SATS) == GPSACQ_OK;
+        for (int sl = 0; ok && sl < GPSACQ_PIPE_SLOTS; sl++) ok = gpsacq_pipe_buffer(e, sl, max_runs * run_bytes) != NULL;
+        if (!ok) {
             fail_with("");
             fclose(fp);
             return;
         }
+    }
+    const double ms_setup = ms_since(t_setup);
     struct Batch {
         int slot;
         std::vector<size_t> runs;  // per device
@@ -303,7 +308,7 @@ void SearchTask(char *filename_1bit_bin) {
     fclose(fp);
     if (trace)
         fprintf(stderr,
-                "gpsacq trace: SearchInit %.1f ms | SearchTask %.1f ms = mean pass %.1f + read %.1f + submit %.1f + wait for GPU %.1f + report %.1f "
+                "gpsacq trace: SearchInit %.1f ms | SearchTask %.1f ms = mean pass %.1f + buffers %.1f + read %.1f + submit %.1f + wait for GPU %.1f + report %.1f "
                 "(+ overlap); %d runs, %zu device(s), input %s\n",
-                g_init_ms, ms_since(t_start), ms_sums, ms_read, ms_submit, ms_wait, ms_print, run_count, n_dev, iq ? fmt : "bits");
+                g_init_ms, ms_since(t_start), ms_sums, ms_setup, ms_read, ms_submit, ms_wait, ms_print, run_count, n_dev, iq ? fmt : "bits");
 }

@@ -159,6 +159,15 @@ int emul_cell(const float* dspec, const float* cspec, int halo, int dop, int S, 
     if (lay == 2) return emul_cell_l<LayC>(dspec, cspec, halo, dop, S, mc, w1h, max_pwr, max_i, tot_pwr);
     return -1;
 }
+// the product's lane maps, for the LDS conflict model (tools/lds_maps.py): lay 1 = LayB, 2 = LayC
+int emul_pass1_jp(int lay, int t) { return lay == 2 ? pass1_jp<LayC>(t) : pass1_jp<LayB>(t); }
+int emul_pass2_owner(int lay, int e) {
+    int al, jpp;
+    if (lay == 2) pass2_owner<LayC>(e, al, jpp);
+    else pass2_owner<LayB>(e, al, jpp);
+    return al * 100 + jpp;
+}
+int emul_pass3_rho(int lay, int t3) { return lay == 2 ? pass3_rho<LayC>(t3) : pass3_rho<LayB>(t3); }
 // the lane maps of LayC deal every butterfly of a pass to exactly one lane: 0 if so
 int emul_lane_maps_are_permutations(void) {
     bool seen[M_SUB];

@@ -111,3 +111,22 @@ def test_emulated_subbin_forward_vs_oracle(emul, golden_dir):
     emul.emul_forward_bits_sub(_p(blk), _p(cosm), _p(sinm), 3, 0, _p(d0))
     emul.emul_forward_bits(_p(blk), _p(cosm), _p(sinm), _p(d1))
     assert np.array_equal(d0, d1)
+
+
+def test_lane_maps_are_bank_conflict_free_in_the_lds_model(emul):
+    """The lane maps the kernels really use (read out of acq_math.hpp through the emulation library) in the instruction-level
+    LDS model of tools/lds_maps.py: round 2's map (LayB) shows the 488 conflict cycles per sub-transform the hardware counter
+    measured (SQ_LDS_BANK_CONFLICT, 3904 per cell), the product's (LayC) at most 20, and a quarter fewer LDS cycles."""
+    import sys
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    import lds_maps
+    out = {}
+    for lay in (1, 2):
+        r = lds_maps.model(lambda t: emul.emul_pass1_jp(lay, t),
+                           lambda e: divmod(emul.emul_pass2_owner(lay, e), 100),
+                           lambda t: emul.emul_pass3_rho(lay, t))
+        out[lay] = (sum(v[0] for v in r.values()), sum(v[1] for v in r.values()))
+    assert out[1] == (1930, 488)
+    assert out[2][1] <= 20 and out[2][0] <= 1462
+    assert [emul.emul_pass3_rho(2, t) for t in range(250)] == lds_maps.make_rho_c()  # the committed table is the generator's
+

@@ -174,10 +174,36 @@ def test_multi_search_blocks_single_device(golden_dir):
         pk = me.search_grid(buf, tasks)
         with gpsacq.Engine(4.092e6, 5.456e6, 5000.0) as eng:
             _, w = eng.search(buf, tasks=tasks, want_cells=False)
-        assert np.array_equal(pk["lo_shift"], w["lo_shift"]) and np.array_equal(pk["ca_shift"], w["ca_shift"])
+        assert np.array_equal(pk, w)  # max_pwr too: the winner's value is merged next to the keys
         assert me.kmax == kmax
         with pytest.raises(ValueError):
             me.search_blocks(buf[:31 * 5120])
+
+
+@pytest.mark.parametrize("n_eng", [2, 3, 5])
+def test_multi_engines_sharing_one_gpu(golden_dir, n_eng):
+    """The N > 1 control flow of gpsacq_multi_* on the one-GPU box: N engines on device 0 (their keys merged on the device;
+    RCCL only joins distinct GPUs).  Block decomposition: every (run, PRN) peak and the per-PRN best equal the one-engine
+    results, max_pwr included; grid decomposition (Doppler slabs): the merged peaks equal the unsharded search."""
+    import gpsacq
+    buf = _nott(golden_dir)
+    with gpsacq.Engine(4.092e6, 5.456e6, 5000.0) as eng:
+        _, want = eng.search(buf, want_cells=False)
+        tasks = [(b, sv) for b in (0, 33) for sv in range(32)]
+        _, wgrid = eng.search(buf, tasks=tasks, want_cells=False)
+    with gpsacq.MultiEngine(4.092e6, 5.456e6, 5000.0, devices=(0,) * n_eng) as me:
+        assert me.n_devices == n_eng
+        for _ in range(2):  # twice: buffers are reused
+            peaks, best = me.search_blocks(buf)  # 2 runs over n_eng engines: some engines get no run at all
+            assert np.array_equal(peaks, want)
+            for sv in range(32):
+                cand = want[sv::32]
+                k = max((float(p["snr"]), -int(p["lo_shift"]), int(p["ca_shift"])) for p in cand)
+                assert (float(best["snr"][sv]), -int(best["lo_shift"][sv]), int(best["ca_shift"][sv])) == k
+                w = [p for p in cand if (float(p["snr"]), -int(p["lo_shift"]), int(p["ca_shift"])) == k][0]
+                assert float(best["max_pwr"][sv]) == float(w["max_pwr"])
+            got = me.search_grid(buf, tasks)
+            assert np.array_equal(got, wgrid)  # snr, lo_shift, ca_shift and the winner's max_pwr
 
 
 def test_sample_spectrum_on_a_fresh_fine_grid_engine(golden_dir):

@@ -96,7 +96,7 @@ try:
         import hashlib
         h = hashlib.sha256()
         root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-        for name in ("acq_kernels.hip", "acq_phases.hpp", "acq_math.hpp", "acq_launch.hpp", "iq_convert.hpp"):
+        for name in ("acq_kernels.hip", "acq_phases.hpp", "acq_math.hpp"):
             h.update(open(os.path.join(root, "gnss-gps-sdr_amd", "csrc", name), "rb").read())
         sha_file = os.path.join(src, "kernel_source_sha.txt")  # written on the GPU box by tools/profile.sh
         sha = open(sha_file).read().strip() if os.path.exists(sha_file) else h.hexdigest()[:16]
