@@ -297,6 +297,97 @@ __global__ __launch_bounds__(WG, WPS) void k_corr(CorrArgs a) {
     }
 }
 
+// ---------------------------------------------------------------------------------------
+// The 8-wave correlator (acq_corr8.hpp): the same cell as k_corr<MC> (coherent, one pass, up to 10000 lags) with the
+// 5000-point sub-transforms as 5 x 10 x 10 x 10 on 500 threads.  Same blockIdx -> cell map, same outputs.
+__constant__ cf c_wq8[NPOLY * WQ8_STRIDE];
+hipError_t upload_wq8(const cf* host) { return hipMemcpyToSymbol(HIP_SYMBOL(c_wq8), host, sizeof(cf) * NPOLY * WQ8_STRIDE); }
+
+template <int MC, int WPS>
+__global__ __launch_bounds__(WG8, WPS) void k_corr8(CorrArgs a) {
+    __shared__ __attribute__((aligned(16))) cf lds[Lay8::SIZE];
+    __shared__ cf t2s[NT8_T2];
+    __shared__ cf t3s[NT8_T3];
+    __shared__ float red[4 * (WG8 / 64)];
+    const int tid = threadIdx.x;
+    const int g = blockIdx.x, xcd = g & 7, slot = g >> 3;
+    const int grp = slot / a.ndop, di = slot - grp * a.ndop;
+    const int task = grp * 8 + xcd;
+    if (task >= a.n_tasks) return;
+    const Task tk = a.tasks[task];
+    if (tk.spec < 0 || tk.spec >= a.n_spec || tk.code < 0 || tk.code >= a.n_code) {  // device task lists are not seen by the host
+        if (tid == 0) {
+            Cell c;
+            c.max_pwr = 0.f;
+            c.max_i = -1;
+            c.tot_pwr = 0.f;
+            c.snr = 0.f;
+            a.cells[(size_t)task * a.ndop + di] = c;
+        }
+        return;
+    }
+    int dop, rsub;
+    grid_point(di + a.dop_first, a.sub, a.dstride, dop, rsub);
+    const cf* dpp = a.dpp + ((size_t)tk.spec * a.sub + rsub) * NPOLY * M_SUB;
+    const cf* cpp = a.cpp + (size_t)tk.code * NPOLY * a.crow;
+    for (int i = tid; i < NT8_T2; i += WG8) t2s[i] = a.t2_8[i];
+    if (tid < NT8_T3) t3s[tid] = a.t3_8[tid];
+    constexpr bool W1H = WPS >= 6;  // three workgroups per CU: 80 VGPRs -- half of the pass-1 twiddles derived
+    cf w1[2][R8A - 1];
+    load_tw8<W1H>(tid, a.t1_8, w1);
+    cf acc[MC];
+#pragma unroll
+    for (int m = 0; m < MC; ++m) acc[m] = mk(0.f, 0.f);
+    const int t4 = tid < NT8 ? tid : 0;
+    for (int q = 0; q < NPOLY; ++q) {
+        const cf b = a.bq8[q * NT8 + t4];
+        cf wqv[MC];
+#pragma unroll
+        for (int m = 0; m < MC; ++m) wqv[m] = c_wq8[q * WQ8_STRIDE + m];
+        ACQ_PHASE1_PRIO(1);
+        corr8_phase1<W1H>(tid, q, dop, dpp, cpp, a.crow, a.halo, w1, lds);
+        ACQ_PHASE1_PRIO(0);
+        __syncthreads();  // also orders the table fills before their first use
+        corr8_phase2(tid, t2s, lds);
+        __syncthreads();
+        corr8_phase3(tid, t3s, lds);
+        __syncthreads();
+        corr8_phase4<MC>(tid, b, wqv, lds, acc);
+        __syncthreads();
+    }
+    float mx, sum;
+    int mi;
+    corr8_scan<MC>(tid, a.nlags, acc, mx, mi, sum);
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) {
+        const float omx = __shfl_down(mx, off, 64);
+        const int omi = __shfl_down(mi, off, 64);
+        const float os = __shfl_down(sum, off, 64);
+        peak_merge(mx, mi, omx, omi);
+        sum += os;
+    }
+    const int wave = tid >> 6;
+    if ((tid & 63) == 0) {
+        red[wave * 4 + 0] = mx;
+        red[wave * 4 + 1] = __int_as_float(mi);
+        red[wave * 4 + 2] = sum;
+    }
+    __syncthreads();
+    if (tid == 0) {
+        for (int w = 1; w < WG8 / 64; ++w) {
+            peak_merge(mx, mi, red[w * 4 + 0], __float_as_int(red[w * 4 + 1]));
+            sum += red[w * 4 + 2];
+        }
+        Cell c;
+        c.max_pwr = mx;
+        c.max_i = mi;
+        c.tot_pwr = sum;
+        const float ave = sum / (float)a.nlags;  // :195 tot_pwr / i
+        c.snr = (sum > 0.f) ? mx / ave : 0.f;    // :196; 0/0 of the reference defined as 0
+        a.cells[(size_t)task * a.ndop + di] = c;
+    }
+}
+
 // More than 10000 lags (fs > 10 MHz) take several k_corr passes of 40 columns each; this folds the
 // partial cells (ascending lag ranges, so strict '>' keeps the first maximum) and sets the SNR.
 __global__ void k_merge_cells(const Cell* parts, Cell* cells, size_t n_cells, int n_parts, int nlags) {
@@ -410,6 +501,29 @@ int launch_corr(const CorrArgs& a, int mc, hipStream_t s) {
             break;
         default: return -1;
     }
+    return 0;
+}
+int corr8_columns(int nlags) {
+    const int need = (nlags + NT8 - 1) / NT8;
+    const int have[] = {6, 11, 14, 17, 20};
+    for (int m : have)
+        if (need <= m) return m;
+    return 0;
+}
+// wgs_per_cu: 2 -> the register allocator is held to 4 waves per SIMD (128 VGPRs), 3 -> 6 waves per SIMD (80 VGPRs)
+int launch_corr8(const CorrArgs& a, int mc8, int wgs_per_cu, hipStream_t s) {
+    const int groups = (a.n_tasks + 7) / 8;
+    const dim3 grid((unsigned)groups * 8u * (unsigned)a.ndop), block(WG8);
+#define K8(MCV)                                                                             \
+    case MCV:                                                                               \
+        if (wgs_per_cu >= 3) hipLaunchKernelGGL((k_corr8<MCV, 6>), grid, block, 0, s, a);   \
+        else hipLaunchKernelGGL((k_corr8<MCV, 4>), grid, block, 0, s, a);                   \
+        break;
+    switch (mc8) {
+        K8(6) K8(11) K8(14) K8(17) K8(20)
+        default: return -1;
+    }
+#undef K8
     return 0;
 }
 void launch_merge_cells(const Cell* parts, Cell* cells, size_t n_cells, int n_parts, int nlags, hipStream_t s) {

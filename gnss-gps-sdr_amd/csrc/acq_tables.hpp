@@ -40,6 +40,27 @@ struct Tables {
     }
 };
 
+// Tables of the 8-wave correlator (acq_corr8.hpp)
+struct Tables8 {
+    std::vector<cf> t1;  // [5][1000]   W_5000^{j' alpha}
+    std::vector<cf> t2;  // [9][100]    W_1000^{j'' beta}, beta = 1..9
+    std::vector<cf> t3;  // [9][10]     W_100^{d gamma}, gamma = 1..9
+    std::vector<cf> bq;  // [8][500]    W_40000^{q rho}
+    std::vector<cf> wq;  // [8][80]     W_80^{q m}
+    Tables8() : t1(5 * 1000), t2(9 * 100), t3(9 * 10), bq((size_t)NPOLY * 500), wq((size_t)NPOLY * 80) {
+        for (int al = 0; al < 5; ++al)
+            for (int jp = 0; jp < 1000; ++jp) t1[al * 1000 + jp] = unit_fwd((long long)jp * al, M_SUB);
+        for (int be = 1; be < 10; ++be)
+            for (int jpp = 0; jpp < 100; ++jpp) t2[(be - 1) * 100 + jpp] = unit_fwd((long long)jpp * be, 1000);
+        for (int ga = 1; ga < 10; ++ga)
+            for (int d = 0; d < 10; ++d) t3[(ga - 1) * 10 + d] = unit_fwd((long long)d * ga, 100);
+        for (int q = 0; q < NPOLY; ++q) {
+            for (int rho = 0; rho < 500; ++rho) bq[(size_t)q * 500 + rho] = unit_fwd((long long)q * rho, N_FFT);
+            for (int m = 0; m < 80; ++m) wq[(size_t)q * 80 + m] = unit_fwd((long long)q * m, 80);
+        }
+    }
+};
+
 // Forward-transform tables for `sub` sub-bin Doppler offsets r/sub (r < sub) of a bin (extension; the reference's grid is
 // sub = 1): spectrum r of a block is the transform of x[n] exp(-2 pi i (r/sub) n / N), i.e. the block's spectrum
 // evaluated r/sub of a bin higher, which the decimation-in-frequency split absorbs exactly into its twiddles:

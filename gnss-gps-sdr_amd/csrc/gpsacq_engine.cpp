@@ -69,7 +69,9 @@ struct gpsacq_engine {
     long searches = 0;  // searches enqueued so far; search k uses ring slot k % kTimingRing
     // constants
     cf *d_t1 = nullptr, *d_t2 = nullptr, *d_bq = nullptr, *d_tn = nullptr;
-    unsigned char* d_rho = nullptr;  // LayC's pass-3 thread -> rho table (acq_math.hpp kRhoC)
+    unsigned char* d_rho = nullptr;
+    cf *d_t1_8 = nullptr, *d_t2_8 = nullptr, *d_t3_8 = nullptr, *d_bq8 = nullptr;  // tables of the 8-wave correlator
+    int corr8 = 0;  // GPSACQ_CORR8=2|3: coherent single-pass searches run k_corr8 at that many workgroups per CU  // LayC's pass-3 thread -> rho table (acq_math.hpp kRhoC)
     uint8_t *d_cos = nullptr, *d_sin = nullptr;
     uint64_t *d_cos_t = nullptr, *d_sin_t = nullptr;  // bit-transposed masks for k_fwd
     cf* d_code = nullptr;  // [32 + patch_cap][8][crow]
@@ -203,7 +205,7 @@ extern "C" void gpsacq_destroy(gpsacq_engine* e) {
     if (!e) return;
     (void)hipSetDevice(e->p.device);
     if (e->stream) (void)hipStreamSynchronize(e->stream);
-    void* bufs[] = {e->d_t1, e->d_t2, e->d_bq, e->d_tn, e->d_rho, e->d_cos, e->d_sin, e->d_cos_t, e->d_sin_t, e->d_code, e->d_patch_blocks, e->d_bits, e->d_iq, e->d_iqbits, e->d_sums, e->d_sats, e->d_gen, e->d_prof, e->d_rot8,
+    void* bufs[] = {e->d_t1, e->d_t2, e->d_bq, e->d_tn, e->d_rho, e->d_t1_8, e->d_t2_8, e->d_t3_8, e->d_bq8, e->d_cos, e->d_sin, e->d_cos_t, e->d_sin_t, e->d_code, e->d_patch_blocks, e->d_bits, e->d_iq, e->d_iqbits, e->d_sums, e->d_sats, e->d_gen, e->d_prof, e->d_rot8,
                     e->d_dpp, e->d_parts, e->d_tasks, e->d_cells, e->d_peaks};
     for (void* b : bufs)
         if (b) (void)hipFree(b);
@@ -245,6 +247,7 @@ extern "C" int gpsacq_create(const gpsacq_params* params, gpsacq_engine** out) {
     // it runs in a worker while this thread sits in the HIP runtime's start-up (>100 ms in the first HIP call of a process).
     struct HostPrep {
         Tables T;
+        Tables8 T8;
         std::vector<cf> tn, rot8;
         std::vector<uint8_t> cosm, sinm;
         std::vector<uint64_t> cos_t, sin_t;
@@ -333,6 +336,20 @@ extern "C" int gpsacq_create(const gpsacq_params* params, gpsacq_engine** out) {
         memcpy(rho, kRhoC, sizeof kRhoC);
         HCK(hipMalloc((void**)&e->d_rho, sizeof rho));
         HCK(hipMemcpy(e->d_rho, rho, sizeof rho, hipMemcpyHostToDevice));
+    }
+    {
+        const Tables8& T8 = hp->T8;
+        HCK(hipMalloc((void**)&e->d_t1_8, T8.t1.size() * sizeof(cf)));
+        HCK(hipMalloc((void**)&e->d_t2_8, T8.t2.size() * sizeof(cf)));
+        HCK(hipMalloc((void**)&e->d_t3_8, T8.t3.size() * sizeof(cf)));
+        HCK(hipMalloc((void**)&e->d_bq8, T8.bq.size() * sizeof(cf)));
+        HCK(hipMemcpy(e->d_t1_8, T8.t1.data(), T8.t1.size() * sizeof(cf), hipMemcpyHostToDevice));
+        HCK(hipMemcpy(e->d_t2_8, T8.t2.data(), T8.t2.size() * sizeof(cf), hipMemcpyHostToDevice));
+        HCK(hipMemcpy(e->d_t3_8, T8.t3.data(), T8.t3.size() * sizeof(cf), hipMemcpyHostToDevice));
+        HCK(hipMemcpy(e->d_bq8, T8.bq.data(), T8.bq.size() * sizeof(cf), hipMemcpyHostToDevice));
+        HCK(upload_wq8(T8.wq.data()));
+        const char* c8 = getenv("GPSACQ_CORR8");
+        e->corr8 = (c8 && *c8) ? atoi(c8) : 0;
     }
     HCK(hipMalloc((void**)&e->d_bq, T.bq.size() * sizeof(cf)));
     HCK(hipMemcpy(e->d_bq, T.bq.data(), T.bq.size() * sizeof(cf), hipMemcpyHostToDevice));
@@ -517,6 +534,10 @@ static int search_core(gpsacq_engine* e, const Capture& cap_in, size_t n_blocks,
     ca.t2 = e->d_t2;
     ca.bq = e->d_bq;
     ca.rho_map = e->d_rho;
+    ca.t1_8 = e->d_t1_8;
+    ca.t2_8 = e->d_t2_8;
+    ca.t3_8 = e->d_t3_8;
+    ca.bq8 = e->d_bq8;
     ca.cells = d_cells;
     ca.n_tasks = (int)n_tasks;
     ca.ndop = e->ndop;
@@ -543,7 +564,10 @@ static int search_core(gpsacq_engine* e, const Capture& cap_in, size_t n_blocks,
         // samples the code advances per accumulated block per Doppler bin: elapsed samples x (bin Hz / L1)
         if (e->creep_comp && e->n_acc > 1)
             ca.creep = (float)((double)e->acc_step * block_samples * (e->p.fs / N_FFT * e->dstride / e->sub) / 1575.42e6);
-        if (launch_corr(ca, e->mc, e->stream) != 0) return fail(GPSACQ_ERR_UNSUPPORTED, "no correlate kernel for %d columns", e->mc);
+        const int mc8 = corr8_columns(e->nlags);
+        if (e->corr8 >= 2 && e->n_acc == 1 && mc8 > 0) {
+            if (launch_corr8(ca, mc8, e->corr8, e->stream) != 0) return fail(GPSACQ_ERR_UNSUPPORTED, "no 8-wave correlate kernel for %d columns", mc8);
+        } else if (launch_corr(ca, e->mc, e->stream) != 0) return fail(GPSACQ_ERR_UNSUPPORTED, "no correlate kernel for %d columns", e->mc);
     } else {
         const size_t n_cells = n_tasks * (size_t)e->ndop;
         if (int rc = grow(e->d_parts, e->parts_cap, n_cells * (size_t)n_pass, e->stream)) return rc;

@@ -8,6 +8,7 @@
 #include <vector>
 
 #include "../../gnss-gps-sdr_amd/csrc/acq_phases.hpp"
+#include "../../gnss-gps-sdr_amd/csrc/acq_corr8.hpp"
 #include "../../gnss-gps-sdr_amd/csrc/acq_tables.hpp"
 
 using namespace acq;
@@ -159,6 +160,60 @@ int emul_cell(const float* dspec, const float* cspec, int halo, int dop, int S, 
     if (lay == 2) return emul_cell_l<LayC>(dspec, cspec, halo, dop, S, mc, w1h, max_pwr, max_i, tot_pwr);
     return -1;
 }
+}  // extern "C"
+
+// One cell through the 8-wave correlator (acq_corr8.hpp): 5 x 10 x 10 x 10 on 500 threads.
+template <int MC>
+static int emul_cell8_mc(const cf* dpp, const cf* cpp, int crow, int halo, int dop, int S, float* max_pwr, int* max_i, float* tot_pwr) {
+    static Tables8 T;
+    std::vector<cf> lds(Lay8::SIZE);
+    std::vector<cf> acc((size_t)WG8 * MC8_MAX, mk(0.f, 0.f));
+    std::vector<cf> w1((size_t)WG8 * 2 * (R8A - 1));
+    for (int tid = 0; tid < WG8; ++tid) load_tw8(tid, T.t1.data(), *reinterpret_cast<cf(*)[2][R8A - 1]>(&w1[(size_t)tid * 2 * (R8A - 1)]));
+    for (int q = 0; q < NPOLY; ++q) {
+        for (int tid = 0; tid < WG8; ++tid)
+            corr8_phase1(tid, q, dop, dpp, cpp, crow, halo, *reinterpret_cast<cf(*)[2][R8A - 1]>(&w1[(size_t)tid * 2 * (R8A - 1)]), lds.data());
+        for (int tid = 0; tid < WG8; ++tid) corr8_phase2(tid, T.t2.data(), lds.data());
+        for (int tid = 0; tid < WG8; ++tid) corr8_phase3(tid, T.t3.data(), lds.data());
+        for (int tid = 0; tid < WG8; ++tid)
+            corr8_phase4<MC>(tid, T.bq[(size_t)q * 500 + (tid < NT8 ? tid : 0)], &T.wq[(size_t)q * WQ8_STRIDE], lds.data(), &acc[(size_t)tid * MC8_MAX]);
+    }
+    float mx = 0.f, sum = 0.f;
+    int mi = 0;
+    for (int tid = 0; tid < WG8; ++tid) {
+        float tmx, tsum;
+        int tmi;
+        corr8_scan<MC>(tid, S, &acc[(size_t)tid * MC8_MAX], tmx, tmi, tsum);
+        peak_merge(mx, mi, tmx, tmi);
+        sum += tsum;
+    }
+    *max_pwr = mx;
+    *max_i = mi;
+    *tot_pwr = sum;
+    return 0;
+}
+
+extern "C" {
+int emul_cell8(const float* dspec, const float* cspec, int halo, int dop, int S, float* max_pwr, int* max_i, float* tot_pwr) {
+    const int crow = M_SUB + 2 * halo;
+    std::vector<cf> dpp((size_t)NPOLY * M_SUB), cpp((size_t)NPOLY * crow);
+    for (int k = 0; k < N_FFT; ++k) {
+        dpp[(size_t)(k & 7) * M_SUB + (k >> 3)] = mk(dspec[2 * k], -dspec[2 * k + 1]);
+        cpp[(size_t)(k & 7) * crow + halo + (k >> 3)] = mk(cspec[2 * k], cspec[2 * k + 1]);
+    }
+    for (int q = 0; q < NPOLY; ++q)
+        for (int h = 0; h < halo; ++h) {
+            cpp[(size_t)q * crow + h] = cpp[(size_t)q * crow + M_SUB + h];
+            cpp[(size_t)q * crow + halo + M_SUB + h] = cpp[(size_t)q * crow + halo + h];
+        }
+    const int mc = (S + NT8 - 1) / NT8;
+    if (mc <= 6) return emul_cell8_mc<6>(dpp.data(), cpp.data(), crow, halo, dop, S, max_pwr, max_i, tot_pwr);
+    if (mc <= 11) return emul_cell8_mc<11>(dpp.data(), cpp.data(), crow, halo, dop, S, max_pwr, max_i, tot_pwr);
+    if (mc <= 17) return emul_cell8_mc<17>(dpp.data(), cpp.data(), crow, halo, dop, S, max_pwr, max_i, tot_pwr);
+    if (mc <= 20) return emul_cell8_mc<20>(dpp.data(), cpp.data(), crow, halo, dop, S, max_pwr, max_i, tot_pwr);
+    return -1;
+}
+
 // the product's lane maps, for the LDS conflict model (tools/lds_maps.py): lay 1 = LayB, 2 = LayC
 int emul_pass1_jp(int lay, int t) { return lay == 2 ? pass1_jp<LayC>(t) : pass1_jp<LayB>(t); }
 int emul_pass2_owner(int lay, int e) {

@@ -24,6 +24,7 @@ def emul():
     E.emul_forward_bits_sub.argtypes = [vp, vp, vp, i, i, vp]
     E.emul_forward_real.argtypes = [vp] * 2
     E.emul_cell.argtypes = [vp, vp, i, i, i, i, i, i, vp, vp, vp]
+    E.emul_cell8.argtypes = [vp, vp, i, i, i, vp, vp, vp]
     E.emul_code_replica.argtypes = [d, i, vp]
     E.emul_lo_masks.argtypes = [d, d, vp, vp]
     E.emul_search_code.argtypes = [i, i]
@@ -87,6 +88,10 @@ def test_emulated_kernels_vs_oracle(emul, golden_dir, fc, fs, file, mc, w1h):
             got[lay] = (mp.value, mi.value, tp.value)
         # the lane maps only re-deal the same butterflies: the peak is bit-identical, the power sum differs by its order at most
         assert got[1][:2] == got[2][:2] and abs(got[1][2] / got[2][2] - 1) < 1e-6
+        # the 8-wave correlator (5 x 10 x 10 x 10 on 500 threads, acq_corr8.hpp): another factorisation of the same transform
+        mp, mi, tp = ctypes.c_float(), ctypes.c_int(), ctypes.c_float()
+        assert emul.emul_cell8(_p(d_in), _p(c_in), 24, dop, orc.num_lags, ctypes.byref(mp), ctypes.byref(mi), ctypes.byref(tp)) == 0
+        assert abs(mp.value / ref["max_pwr"] - 1) < 2e-5 and abs(tp.value / ref["tot_pwr"] - 1) < 2e-5 and mi.value == ref["max_i"]
 
 
 def test_emulated_subbin_forward_vs_oracle(emul, golden_dir):
