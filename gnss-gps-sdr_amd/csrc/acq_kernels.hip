@@ -32,7 +32,7 @@ hipError_t upload_wq(const cf* host) { return hipMemcpyToSymbol(HIP_SYMBOL(c_wq)
 // SRC_REAL: float code replicas (SearchInit).  SRC_BITS: the 1-bit capture gps_test reads.  SRC_IQ8: an 8-bit IQ capture
 // (rtl-sdr / HackRF) -- mean removal, mixer, sign and the bit transpose happen while the block is staged, so the 1-bit
 // stream the reference's MATLAB scripts write to disk (proc_rtl_bin_for_gps.m:22-26,43-47) is never materialised.
-enum { SRC_REAL = 0, SRC_BITS = 1, SRC_IQ8 = 2 };
+enum { SRC_REAL = 0, SRC_BITS = 1, SRC_IQ8 = 2, SRC_REALMIX = 3 };  // SRC_REALMIX: multi-bit real-IF floats, LO applied as signs
 
 // iq8 staging, step 1: the block's first 5000 bytes of the 1-bit stream, made from the IQ bytes (one aligned 16-byte group
 // of 8 samples -> one byte; iq_convert.hpp) into a workgroup-local buffer -- the transform buffer, not yet in use.
@@ -61,7 +61,7 @@ __device__ __forceinline__ void fwd_convert_iq8(int tid, const uint8_t* __restri
 
 template <int SRC>
 __global__ __launch_bounds__(WG) void k_fwd(FwdArgs a) {
-    constexpr bool BITS = SRC != SRC_REAL;
+    constexpr bool BITS = SRC == SRC_BITS || SRC == SRC_IQ8;
     __shared__ cf lds[M_SUB];
     __shared__ uint64_t ib[BITS ? USED_BYTES / NPOLY : 1], qb[BITS ? USED_BYTES / NPOLY : 1];
     __shared__ cf lut[BITS ? 256 : 1];
@@ -83,6 +83,9 @@ __global__ __launch_bounds__(WG) void k_fwd(FwdArgs a) {
             fwd_build_lut(tid, a.rot8 + (r * NPOLY + kappa) * NPOLY, lut);
             __syncthreads();  // table (and, first time, the staged bits) ready; previous row's copy-out finished
             fwd_phase1(tid, kappa, BitsSrc{reinterpret_cast<const uint8_t*>(ib), reinterpret_cast<const uint8_t*>(qb), lut}, tn_row, w, lds);
+        } else if (SRC == SRC_REALMIX) {
+            __syncthreads();
+            fwd_phase1(tid, kappa, RealMixSrc{(const float*)a.src + (size_t)srci * a.src_stride, a.cos_mask, a.sin_mask}, tn_row, w, lds);
         } else {
             __syncthreads();
             fwd_phase1(tid, kappa, RealSrc{(const float*)a.src + (size_t)srci * a.src_stride}, tn_row, w, lds);
@@ -453,6 +456,9 @@ void launch_fwd_bits(const FwdArgs& a, int n_items, hipStream_t s) {
 }
 void launch_fwd_iq8(const FwdArgs& a, int n_items, hipStream_t s) {
     hipLaunchKernelGGL(k_fwd<SRC_IQ8>, dim3(n_items), dim3(WG), 0, s, a);
+}
+void launch_fwd_realmix(const FwdArgs& a, int n_items, hipStream_t s) {
+    hipLaunchKernelGGL(k_fwd<SRC_REALMIX>, dim3(n_items), dim3(WG), 0, s, a);
 }
 void launch_fwd_real(const FwdArgs& a, int n_items, hipStream_t s) {
     hipLaunchKernelGGL(k_fwd<SRC_REAL>, dim3(n_items), dim3(WG), 0, s, a);

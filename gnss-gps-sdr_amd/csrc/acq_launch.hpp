@@ -15,6 +15,7 @@ struct FwdArgs {
     IqConv iq;           // iq8 source: format, mean, mixer
     size_t iq_first;     // iq8 source: capture sample index of src's first sample (the mixer's n, proc_rtl_bin_for_gps.m:41)
     size_t iq_total;     // iq8 source: samples of the whole capture (samples beyond it read as bit 0, like the converter's tail)
+    const uint8_t *cos_mask, *sin_mask;  // [5120] LO masks, plain bit order (multi-bit float source only)
     const uint64_t* cos_t;  // [625] bit-transposed LO masks (bits source only)
     const uint64_t* sin_t;
     const cf* t1;
@@ -63,6 +64,7 @@ __attribute__((visibility("hidden"))) int set_last_error(int code, const char* m
 void launch_fwd_bits(const FwdArgs& a, int n_items, hipStream_t s);
 void launch_fwd_iq8(const FwdArgs& a, int n_items, hipStream_t s);
 void launch_fwd_real(const FwdArgs& a, int n_items, hipStream_t s);
+void launch_fwd_realmix(const FwdArgs& a, int n_items, hipStream_t s);
 void launch_code_halo(cf* cpp, int n_rows, int crow, int halo, hipStream_t s);
 void launch_quirk_patch(const QuirkArgs& a, int n_patch, hipStream_t s);
 int corr_columns(int nlags);

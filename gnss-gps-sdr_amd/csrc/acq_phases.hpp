@@ -266,6 +266,25 @@ struct RealSrc {
     }
 };
 
+// multi-bit real-IF samples (8-bit IQ capture kept at full amplitude, SURVEY.md section 8f.1 "direct float path"): the
+// quadrature LO of Sample() (:143-153) applied as signs to the float sample instead of XOR-ed into a sign bit:
+// I = +-x by lo_cos, Q = +-x by lo_sin (mask bit 1 <-> factor -1, like Bipolar(bit ^ lo))
+struct RealMixSrc {
+    const float* x;           // [>= 40000] real-IF samples of the block
+    const uint8_t* cos_mask;  // [5000] LO masks of lo_masks(), bit i of byte i / 8 (LSB first)
+    const uint8_t* sin_mask;
+    ACQ_HD cf partial(int np, cf c4, cf c2, cf c1) const {
+        cf v[NPOLY];
+#pragma unroll
+        for (int nu = 0; nu < NPOLY; ++nu) {
+            const int n = np + M_SUB * nu;
+            const float s = x[n];
+            v[nu] = mk(s * pm1((cos_mask[n >> 3] >> (n & 7)) & 1u), s * pm1((sin_mask[n >> 3] >> (n & 7)) & 1u));
+        }
+        return dft8_one(v, c4, c2, c1);
+    }
+};
+
 // rot[nu] = exp(-2 pi i nu (kappa + eps) / 8): the radix-8 step of row kappa, with the sub-bin Doppler offset eps of
 // this spectrum folded in (eps = 0: W_8^{nu kappa})
 ACQ_HD void fwd_build_lut(int tid, const cf* __restrict__ rot, cf* lut) {  // thread tid computes entry tid (WG = 256)

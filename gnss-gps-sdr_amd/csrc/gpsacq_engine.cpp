@@ -92,6 +92,8 @@ struct gpsacq_engine {
     size_t iq_cap = 0;
     uint8_t* d_iqbits = nullptr;
     size_t iqbits_cap = 0;
+    float* d_fsamp = nullptr;  // multi-bit path: real-IF float samples of the batch
+    size_t fsamp_cap = 0;
     unsigned long long* d_sums = nullptr;
     // capture generator scratch
     GenSat* d_sats = nullptr;
@@ -126,6 +128,7 @@ struct Capture {
     size_t stride = 0;               // bytes per block in d_src
     IqConv iq{};
     size_t iq_first = 0, iq_total = ~(size_t)0;
+    bool multibit = false;  // 8-bit IQ kept at full amplitude (float samples) instead of its sign
 };
 
 static const size_t kFwdChunk = 32768;  // blocks per forward-transform launch (grid.y bound)
@@ -164,15 +167,17 @@ static int ensure_code_slots(gpsacq_engine* e, size_t n_patch) {
 // forward transforms of n items into out (polyphase layout)
 // (sub spectra per source item when bits / iq8: item i of the grid -> source i / sub, sub-bin offset i % sub;
 //  sub_override > 0: that many instead of the engine's -- the parity probe wants exactly one)
-enum FwdKind { FWD_REAL, FWD_BITS, FWD_IQ8 };
+enum FwdKind { FWD_REAL, FWD_BITS, FWD_IQ8, FWD_REALMIX };
 static int run_forward(gpsacq_engine* e, FwdKind kind, const void* src, size_t src_stride, size_t n_src, cf* out,
                        size_t item_stride, long row, int off, bool conj_out, int sub_override = 0, const Capture* cap = nullptr) {
-    const int sub = kind == FWD_REAL ? 1 : (sub_override > 0 ? sub_override : e->sub);
+    const int sub = (kind == FWD_REAL || kind == FWD_REALMIX) ? 1 : (sub_override > 0 ? sub_override : e->sub);
     const size_t chunk = kFwdChunk / (size_t)sub;  // sources per launch
     for (size_t base = 0; base < n_src; base += chunk) {  // grid.y bound
         const size_t cnt = std::min(chunk, n_src - base) * (size_t)sub;
         FwdArgs fa{};
-        fa.src = kind == FWD_REAL ? (const void*)((const float*)src + base * src_stride) : (const void*)((const uint8_t*)src + base * src_stride);
+        fa.src = (kind == FWD_REAL || kind == FWD_REALMIX) ? (const void*)((const float*)src + base * src_stride) : (const void*)((const uint8_t*)src + base * src_stride);
+        fa.cos_mask = e->d_cos;
+        fa.sin_mask = e->d_sin;
         fa.src_stride = src_stride;
         if (kind == FWD_IQ8) {
             fa.iq = cap->iq;
@@ -193,6 +198,7 @@ static int run_forward(gpsacq_engine* e, FwdKind kind, const void* src, size_t s
         fa.conj_out = conj_out ? 1 : 0;
         if (kind == FWD_BITS) launch_fwd_bits(fa, (int)cnt, e->stream);
         else if (kind == FWD_IQ8) launch_fwd_iq8(fa, (int)cnt, e->stream);
+        else if (kind == FWD_REALMIX) launch_fwd_realmix(fa, (int)cnt, e->stream);
         else launch_fwd_real(fa, (int)cnt, e->stream);
     }
     HIPCHK(hipGetLastError());
@@ -205,7 +211,7 @@ extern "C" void gpsacq_destroy(gpsacq_engine* e) {
     if (!e) return;
     (void)hipSetDevice(e->p.device);
     if (e->stream) (void)hipStreamSynchronize(e->stream);
-    void* bufs[] = {e->d_t1, e->d_t2, e->d_bq, e->d_tn, e->d_rho, e->d_t1_8, e->d_t2_8, e->d_t3_8, e->d_bq8, e->d_cos, e->d_sin, e->d_cos_t, e->d_sin_t, e->d_code, e->d_patch_blocks, e->d_bits, e->d_iq, e->d_iqbits, e->d_sums, e->d_sats, e->d_gen, e->d_prof, e->d_rot8,
+    void* bufs[] = {e->d_t1, e->d_t2, e->d_bq, e->d_tn, e->d_rho, e->d_t1_8, e->d_t2_8, e->d_t3_8, e->d_bq8, e->d_cos, e->d_sin, e->d_cos_t, e->d_sin_t, e->d_code, e->d_patch_blocks, e->d_bits, e->d_iq, e->d_iqbits, e->d_fsamp, e->d_sums, e->d_sats, e->d_gen, e->d_prof, e->d_rot8,
                     e->d_dpp, e->d_parts, e->d_tasks, e->d_cells, e->d_peaks};
     for (void* b : bufs)
         if (b) (void)hipFree(b);
@@ -492,6 +498,10 @@ static int search_core(gpsacq_engine* e, const Capture& cap_in, size_t n_blocks,
     if (cap.iq8) {
         if (cap.stride % 16 != 0 || cap.stride < (size_t)USED_BYTES * 16) return fail(GPSACQ_ERR_ARG, "8-bit IQ blocks: stride %zu must be a multiple of 16 and >= 80000 bytes", cap.stride);
         if (((uintptr_t)cap.d_src & 15) != 0) return fail(GPSACQ_ERR_ARG, "IQ buffer must be 16-byte aligned");
+        if (cap.multibit) {
+            if (e->p.ref_quirks) return fail(GPSACQ_ERR_UNSUPPORTED, "ref_quirks is defined for the reference's 1-bit samples only");
+            if (e->sub > 1) return fail(GPSACQ_ERR_UNSUPPORTED, "the multi-bit sample path searches the whole-bin Doppler grid (gpsacq_set_doppler_step finer than a bin is 1-bit only)");
+        }
         if (e->p.ref_quirks) {
             // the quirk patch reads the 960 samples past each block from a 1-bit stream: convert first (same arithmetic,
             // iq_convert.hpp), then search the bits -- the un-fused route, kept for this one mode
@@ -522,7 +532,24 @@ static int search_core(gpsacq_engine* e, const Capture& cap_in, size_t n_blocks,
 
     hipEvent_t* ev = e->ev[e->searches % gpsacq_engine::kTimingRing];
     HIPCHK(hipEventRecord(ev[0], e->stream));
-    if (int rc = run_forward(e, cap.iq8 ? FWD_IQ8 : FWD_BITS, cap.d_src, stride, n_blocks, e->d_dpp, (size_t)NPOLY * M_SUB, M_SUB, 0, true, 0, &cap)) return rc;
+    if (cap.iq8 && cap.multibit) {
+        // multi-bit path: the real-IF value of every sample as a float (same arithmetic as the 1-bit converter, iq_convert.hpp),
+        // then the forward transform with the LO applied as signs
+        const size_t want = (n_blocks - 1) * (stride / 2) + (size_t)USED_BYTES * 8;
+        const size_t avail = cap.iq_total > cap.iq_first ? cap.iq_total - cap.iq_first : 0;
+        const size_t n_samples = std::min(want, avail);
+        if (n_samples < want) return fail(GPSACQ_ERR_ARG, "multi-bit path: the capture ends inside the batch (%zu of %zu samples)", n_samples, want);
+        if (int rc = grow(e->d_fsamp, e->fsamp_cap, want, e->stream)) return rc;
+        IqArgs ia{};
+        ia.iq = cap.d_src;
+        ia.bits = nullptr;
+        ia.n_samples = n_samples;
+        ia.first_sample = cap.iq_first;
+        ia.conv = cap.iq;
+        launch_iq_to_real(ia, e->d_fsamp, e->stream);
+        HIPCHK(hipGetLastError());
+        if (int rc = run_forward(e, FWD_REALMIX, e->d_fsamp, stride / 2, n_blocks, e->d_dpp, (size_t)NPOLY * M_SUB, M_SUB, 0, true)) return rc;
+    } else if (int rc = run_forward(e, cap.iq8 ? FWD_IQ8 : FWD_BITS, cap.d_src, stride, n_blocks, e->d_dpp, (size_t)NPOLY * M_SUB, M_SUB, 0, true, 0, &cap)) return rc;
     HIPCHK(hipEventRecord(ev[1], e->stream));
     // the block period in samples: what the code creeps over between accumulated blocks
     const double block_samples = cap.iq8 ? (double)stride / 2.0 : (double)stride * 8.0;
@@ -627,6 +654,7 @@ static int iq8_capture(const gpsacq_engine* e, const gpsacq_iq8_input* in, const
     c.iq.inv_fs = 1.0 / fs;
     c.iq_first = (size_t)in->first_sample;
     c.iq_total = in->total_samples ? (size_t)in->total_samples : ~(size_t)0;
+    c.multibit = in->multibit != 0;
     *out = c;
     return GPSACQ_OK;
 }

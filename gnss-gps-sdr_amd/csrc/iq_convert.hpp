@@ -19,28 +19,34 @@ struct IqConv {
     double inv_fs;       // 1/fs
 };
 
+// one sample (I in the low byte of `pair`, Q in the high byte), capture index n -> its real-IF value before the sign
+__device__ __forceinline__ double iq8_value(unsigned pair, size_t n, const IqConv& c) {
+#pragma clang fp contract(off)  // MATLAB / the numpy oracle round the two products before subtracting
+    double yi, yq;
+    if (c.is_signed) { yi = (double)(int8_t)(pair & 0xff); yq = (double)(int8_t)(pair >> 8); }
+    else { yi = (double)(int)(pair & 0xff) - 128.0; yq = (double)(int)(pair >> 8) - 128.0; }
+    yi -= c.mean_i;
+    yq -= c.mean_q;
+    double r = yi;
+    if (c.mix) {
+        // theta in the operation order of proc_rtl_bin_for_gps.m:41: ((((2*pi)*fc)*n)*(1/fs))
+        const double th = (c.two_pi_fc * (double)n) * c.inv_fs;
+        double sn, cs;
+        sincos(th, &sn, &cs);
+        r = yi * cs - yq * sn;
+    }
+    return r;
+}
+
 // 8 consecutive samples (16 bytes: I0 Q0 I1 Q1 ...) starting at capture sample n0 -> one byte of the 1-bit stream
 // (sample n0 + k in bit k).  Samples n >= n_samples (ragged tail) give 0 bits.
 __device__ __forceinline__ unsigned iq8_byte(const unsigned (&raw)[4], size_t n0, size_t n_samples, const IqConv& c) {
-#pragma clang fp contract(off)  // MATLAB / the numpy oracle round the two products before subtracting
     unsigned out = 0;
 #pragma unroll
     for (int k = 0; k < 8; ++k) {
         const size_t n = n0 + k;
         const unsigned pair = (raw[k >> 1] >> (16 * (k & 1))) & 0xffffu;
-        double yi, yq;
-        if (c.is_signed) { yi = (double)(int8_t)(pair & 0xff); yq = (double)(int8_t)(pair >> 8); }
-        else { yi = (double)(int)(pair & 0xff) - 128.0; yq = (double)(int)(pair >> 8) - 128.0; }
-        yi -= c.mean_i;
-        yq -= c.mean_q;
-        double r = yi;
-        if (c.mix) {
-            // theta in the operation order of proc_rtl_bin_for_gps.m:41: ((((2*pi)*fc)*n)*(1/fs))
-            const double th = (c.two_pi_fc * (double)n) * c.inv_fs;
-            double sn, cs;
-            sincos(th, &sn, &cs);
-            r = yi * cs - yq * sn;
-        }
+        const double r = iq8_value(pair, n, c);
         // (1 - sign(r)) / 2 written as ubit1: r > 0 -> 0, r < 0 -> 1, r == 0 -> 0.5 which fwrite rounds to 1
         const unsigned bit = (n < n_samples) ? (r > 0.0 ? 0u : 1u) : 0u;
         out |= bit << k;

@@ -74,6 +74,31 @@ __global__ __launch_bounds__(256) void k_iq_to_bits(IqArgs a) {
     a.bits[byte] = (uint8_t)out;
 }
 
+// multi-bit path (SURVEY.md section 8f.1 "direct float path"; no reference counterpart: gps_test only reads 1-bit files): the
+// same real-IF value, kept as a float instead of its sign.  One thread per 8 samples.
+__global__ __launch_bounds__(256) void k_iq_to_real(IqArgs a, float* __restrict__ out) {
+    const size_t g = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const size_t s0 = g * 8;
+    if (s0 >= a.n_samples) return;
+    unsigned raw[4] = {0, 0, 0, 0};
+    if (s0 + 8 <= a.n_samples) {
+        const uint4 v = reinterpret_cast<const uint4*>(a.iq)[g];
+        raw[0] = v.x; raw[1] = v.y; raw[2] = v.z; raw[3] = v.w;
+    } else {
+        for (size_t s = s0; s < a.n_samples; ++s) {
+            const unsigned pair = a.iq[2 * s] | ((unsigned)a.iq[2 * s + 1] << 8);
+            raw[(s - s0) >> 1] |= pair << (16 * ((s - s0) & 1));
+        }
+    }
+#pragma unroll
+    for (int k = 0; k < 8; ++k)
+        if (s0 + k < a.n_samples) out[s0 + k] = (float)iq8_value((raw[k >> 1] >> (16 * (k & 1))) & 0xffffu, a.first_sample + s0 + k, a.conv);
+}
+void launch_iq_to_real(const IqArgs& a, float* out, hipStream_t s) {
+    const size_t groups = (a.n_samples + 7) / 8;
+    hipLaunchKernelGGL(k_iq_to_real, dim3((unsigned)((groups + 255) / 256)), dim3(256), 0, s, a, out);
+}
+
 void launch_iq_sums(const uint8_t* iq, size_t n_samples, int is_signed, unsigned long long* sums, hipStream_t s) {
     hipLaunchKernelGGL(k_iq_sums, dim3(2048), dim3(256), 0, s, iq, n_samples, is_signed, sums);
 }

@@ -18,5 +18,6 @@ struct IqArgs {
 
 void launch_iq_sums(const uint8_t* iq, size_t n_samples, int is_signed, unsigned long long* sums, hipStream_t s);
 void launch_iq_to_bits(const IqArgs& a, hipStream_t s);
+void launch_iq_to_real(const IqArgs& a, float* out, hipStream_t s);  // a.bits unused
 
 }  // namespace acq

@@ -23,6 +23,8 @@
 //   GPSACQ_MIX_HZ=<f>       IQ input: mix the baseband capture up to this real IF first (proc_rtl_bin_for_gps.m:31-47,
 //                           fc = 0.62e6 there); 0 / unset: take the real part (:12-26).  FC should name the same IF.
 //   GPSACQ_IQ_KEEP_DC=1     IQ input: skip `y = y - mean(y)` (the scripts always remove it)
+//   GPSACQ_IQ_MULTIBIT=1    IQ input: keep the samples' amplitude instead of their sign (no reference counterpart: gps_test reads
+//                           1-bit files only); spares the 1-bit quantisation loss
 //   GPSACQ_TRACE=1          wall-clock split of SearchInit / SearchTask on stderr
 #include <chrono>
 #include <cstdio>
@@ -173,6 +175,7 @@ void SearchTask(char *filename_1bit_bin) {
         iqin.mix_hz = (mix && *mix) ? atof(mix) : 0.0;
         iqin.fs = FS;
         iqin.remove_dc = env_int("GPSACQ_IQ_KEEP_DC", 0) ? 0 : 1;
+        iqin.multibit = env_int("GPSACQ_IQ_MULTIBIT", 0) ? 1 : 0;
     }
     const size_t block_bytes = iq ? (size_t)GPSACQ_BLOCK_BYTES * 16 : (size_t)GPSACQ_BLOCK_BYTES;  // one Sample(): 40960 samples
     const size_t run_bytes = (size_t)GPSACQ_NUM_SATS * block_bytes;

@@ -52,7 +52,8 @@ class Handoff(ctypes.Structure):
 
 class Iq8Input(ctypes.Structure):
     _fields_ = [("format", ctypes.c_int32), ("remove_dc", ctypes.c_int32), ("mean_i", ctypes.c_double), ("mean_q", ctypes.c_double),
-                ("mix_hz", ctypes.c_double), ("fs", ctypes.c_double), ("first_sample", ctypes.c_uint64), ("total_samples", ctypes.c_uint64)]
+                ("mix_hz", ctypes.c_double), ("fs", ctypes.c_double), ("first_sample", ctypes.c_uint64), ("total_samples", ctypes.c_uint64),
+                ("multibit", ctypes.c_int32), ("reserved", ctypes.c_int32)]
 
 
 class Sat(ctypes.Structure):
@@ -294,9 +295,9 @@ class Engine:
 
     # ---- 8-bit IQ capture searched directly (no 1-bit intermediate) -------------------------
     @staticmethod
-    def iq8_input(signed=False, remove_dc=True, mean=(0.0, 0.0), mix_hz=0.0, fs=0.0, first_sample=0, total_samples=0):
+    def iq8_input(signed=False, remove_dc=True, mean=(0.0, 0.0), mix_hz=0.0, fs=0.0, first_sample=0, total_samples=0, multibit=False):
         return Iq8Input(1 if signed else 0, 1 if remove_dc else 0, float(mean[0]), float(mean[1]), float(mix_hz), float(fs),
-                        int(first_sample), int(total_samples))
+                        int(first_sample), int(total_samples), 1 if multibit else 0, 0)
 
     def iq8_mean(self, iq, signed=False, chunk_samples=1 << 22):
         """Complex mean of a whole 8-bit IQ capture as (mean_i, mean_q): exact integer sums on the device, in pieces."""

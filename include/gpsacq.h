@@ -258,6 +258,11 @@ typedef struct gpsacq_iq8_input {
     double fs;               /* sampling rate of the mixer phase; <= 0: the engine's */
     uint64_t first_sample;   /* capture sample index of the buffer's first sample: the mixer's n */
     uint64_t total_samples;  /* samples in the whole capture (bits beyond it read 0); 0: every block handed over is complete */
+    int32_t multibit;        /* 0: the sign of each sample, as the scripts write it and gps_test reads it.  1: the samples keep their
+                                amplitude ("direct float path"; no reference counterpart -- gps_test only takes 1-bit files): the
+                                real-IF value as a float, the quadrature LO of Sample() (:143-153) applied as signs; spares the
+                                1-bit quantisation loss.  Whole-bin Doppler grid only, not with ref_quirks. */
+    int32_t reserved;
 } gpsacq_iq8_input;
 GPSACQ_API int gpsacq_search_iq8(gpsacq_engine* e, const gpsacq_iq8_input* in, const void* iq, size_t n_blocks, size_t stride,
                       const gpsacq_task* tasks, size_t n_tasks, gpsacq_cell* cells, gpsacq_peak* peaks);

@@ -28,3 +28,43 @@ def iq8_to_bits(raw, signed=False, remove_dc=True, mix_hz=0.0, fs=2.8e6):
         r = y.real
     bits = np.where(r > 0, 0, 1).astype(np.uint8)
     return np.packbits(bits, bitorder="little")
+
+
+def iq8_to_real(raw, signed=False, remove_dc=True, mix_hz=0.0, fs=2.8e6):
+    """The same value before the sign: what the product's multi-bit path (gpsacq_iq8_input.multibit; SURVEY.md section 8f.1
+    "direct float path", no reference counterpart) feeds the forward transform, as float32."""
+    raw = np.asarray(raw).view(np.uint8).ravel()
+    y = raw.view(np.int8).astype(np.float64) if signed else raw.astype(np.float64) - 128.0
+    y = y[0::2] + 1j * y[1::2]
+    if remove_dc:
+        y = y - np.mean(y)
+    if mix_hz != 0.0:
+        n = np.arange(y.size, dtype=np.float64)
+        theta = (((2.0 * np.pi) * mix_hz) * n) * (1.0 / fs)
+        r = y.real * np.cos(theta) - y.imag * np.sin(theta)
+    else:
+        r = y.real
+    return r.astype(np.float32)
+
+
+def multibit_cells(r_block, lo_quadrant, code_replica, dmax, n_lags):
+    """Correlate() (c/search_offline.cpp:169-201) on a block of multi-bit samples, float64 numpy: the LO of Sample() (:143-153)
+    applied as signs (lo_cos = {0,1,1,0}, lo_sin = {1,1,0,0}; 1 <-> factor -1), then exactly the reference's search.
+    r_block: >= 40000 float samples; lo_quadrant: int(lo_phase) per sample; code_replica: SearchInit's 40000 floats.
+    Returns (max_pwr, max_i, tot_pwr) arrays over dop = -dmax..dmax."""
+    N = 40000
+    lo_sin = np.array([1, 1, 0, 0])
+    lo_cos = np.array([0, 1, 1, 0])
+    x = r_block[:N].astype(np.float64)
+    x = x * (1.0 - 2.0 * lo_cos[lo_quadrant[:N]]) + 1j * x * (1.0 - 2.0 * lo_sin[lo_quadrant[:N]])
+    D = np.fft.fft(x)
+    C = np.fft.fft(np.asarray(code_replica, dtype=np.float64))
+    mp, mi, tp = [], [], []
+    for d in range(-dmax, dmax + 1):
+        y = np.fft.ifft(np.conj(D) * np.roll(C, d)) * N
+        pwr = y[:n_lags].real ** 2 + y[:n_lags].imag ** 2
+        mp.append(pwr.max())
+        mi.append(int(pwr.argmax()))
+        tp.append(pwr.sum())
+    return np.array(mp), np.array(mi), np.array(tp)
+

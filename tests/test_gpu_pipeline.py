@@ -112,6 +112,38 @@ def test_fused_iq8_search_equals_convert_then_search(signed, mix, quirks):
         assert np.array_equal(c3, c1[[i for i, (b, _) in enumerate(tasks) if b >= off]])
 
 
+def test_multibit_samples_vs_numpy_restatement():
+    """gpsacq_iq8_input.multibit (SURVEY.md section 8f.1 "direct float path"): the 8-bit samples keep their amplitude.  Cells
+    against oracle/iq8_oracle.py's float64 restatement (LO applied as signs, then the reference's Correlate), and the point of
+    the mode: PRN 5's SNR is higher than through the 1-bit path (no quantisation loss)."""
+    import gpsacq
+    from iq8_oracle import iq8_to_real, multibit_cells
+    sys.path.insert(0, os.path.join(ROOT, "tests", "golden"))
+    from make_golden import lo_quadrants, code_replica
+    iq = _iq_capture(3, seed=21)
+    fc, fs = 0.62e6, 2.8e6
+    r = iq8_to_real(iq, remove_dc=True, mix_hz=fc, fs=fs)
+    quad = lo_quadrants(fc, fs, 40960)
+    with gpsacq.Engine(fc, fs, 5000.0) as eng:
+        mean = eng.iq8_mean(iq)
+        tasks = [(0, 4), (2, 4), (1, 0)]
+        inp = eng.iq8_input(remove_dc=True, mean=mean, mix_hz=fc, fs=fs, total_samples=iq.size // 2, multibit=True)
+        cells, peaks = eng.search_iq8(iq, inp, tasks=tasks)
+        inp1 = eng.iq8_input(remove_dc=True, mean=mean, mix_hz=fc, fs=fs, total_samples=iq.size // 2)
+        _, peaks1 = eng.search_iq8(iq, inp1, tasks=tasks)
+        for t, (b, sv) in enumerate(tasks):
+            mp, mi, tp = multibit_cells(r[b * 40960:], quad, code_replica(fs, sv), eng.dmax, eng.num_lags)
+            np.testing.assert_allclose(cells["max_pwr"][t], mp, rtol=2e-5)
+            np.testing.assert_allclose(cells["tot_pwr"][t], tp, rtol=2e-5)
+            assert (cells["max_i"][t] != mi).sum() <= 1
+        assert peaks["snr"][0] > 25 and peaks["lo_shift"][0] == peaks1["lo_shift"][0] and peaks["ca_shift"][0] == peaks1["ca_shift"][0]
+        assert peaks["snr"][0] > 1.1 * peaks1["snr"][0] and peaks["snr"][1] > 1.1 * peaks1["snr"][1]
+        # not with the reference quirk, not on a sub-bin Doppler grid
+        eng.set_doppler_step(20.0)
+        with pytest.raises(gpsacq.GpsAcqError):
+            eng.search_iq8(iq, inp, tasks=tasks)
+
+
 def test_cli_iq8_input_equals_preconverted_1bit(tmp_path):
     """README.md:83-115 as one command: gps_test on the rtl-sdr IQ file (GPSACQ_INPUT=iq_u8, GPSACQ_MIX_HZ) prints what
     gps_test prints on the 1-bit file made from it first -- two runs, the partial third discarded by both."""

@@ -35,6 +35,26 @@ def test_committed_bits_fixture_reproducible(golden_dir):
     assert np.array_equal(iq8_to_bits(raw, remove_dc=True, mix_hz=0.62e6, fs=2.8e6), want)
 
 
+def test_multibit_restatement_reduces_to_the_1bit_oracle(golden_dir):
+    """oracle/iq8_oracle.py::multibit_cells (float samples, LO applied as signs) on samples that are only their sign must
+    give the cells of the C oracle's Sample() + Correlate() on the same 1-bit block: pins the sign convention of the
+    multi-bit path to the reference's XOR mixer (c/search_offline.cpp:143-153)."""
+    sys.path.insert(0, os.path.join(ROOT, "tests", "golden"))
+    from iq8_oracle import multibit_cells
+    from make_golden import lo_quadrants, code_replica
+    from oracle_lib import Oracle
+    fc, fs = 0.62e6, 2.8e6
+    buf = open(os.path.join(golden_dir, "synth_rtl_fs2800.bin"), "rb").read()
+    blk = np.frombuffer(buf[7 * 5120:8 * 5120], np.uint8)
+    orc = Oracle(fc, fs, 5000.0)
+    cells, _ = orc.search_block(blk, 7)
+    r = (1.0 - 2.0 * np.unpackbits(blk, bitorder="little").astype(np.float64)).astype(np.float32)
+    mp, mi, tp = multibit_cells(r, lo_quadrants(fc, fs, 40960), code_replica(fs, 7), orc.dmax, orc.num_lags)
+    np.testing.assert_allclose(mp, cells["max_pwr"], rtol=2e-6)
+    np.testing.assert_allclose(tp, cells["tot_pwr"], rtol=1e-5)
+    assert np.array_equal(mi, cells["max_i"])
+
+
 @pytest.mark.gpu
 def test_device_conversion_matches_oracle(golden_dir):
     import gpsacq
