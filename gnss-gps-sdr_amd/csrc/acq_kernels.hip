@@ -32,7 +32,7 @@ hipError_t upload_wq(const cf* host) { return hipMemcpyToSymbol(HIP_SYMBOL(c_wq)
 // SRC_REAL: float code replicas (SearchInit).  SRC_BITS: the 1-bit capture gps_test reads.  SRC_IQ8: an 8-bit IQ capture
 // (rtl-sdr / HackRF) -- mean removal, mixer, sign and the bit transpose happen while the block is staged, so the 1-bit
 // stream the reference's MATLAB scripts write to disk (proc_rtl_bin_for_gps.m:22-26,43-47) is never materialised.
-enum { SRC_REAL = 0, SRC_BITS = 1, SRC_IQ8 = 2, SRC_REALMIX = 3 };  // SRC_REALMIX: multi-bit real-IF floats, LO applied as signs
+enum { SRC_REAL = 0, SRC_BITS = 1, SRC_IQ8 = 2, SRC_REALMIX = 3 };  // SRC_REALMIX: multi-bit samples, complex floats with the LO applied
 
 // iq8 staging, step 1: the block's first 5000 bytes of the 1-bit stream, made from the IQ bytes (one aligned 16-byte group
 // of 8 samples -> one byte; iq_convert.hpp) into a workgroup-local buffer -- the transform buffer, not yet in use.
@@ -81,11 +81,11 @@ __global__ __launch_bounds__(WG) void k_fwd(FwdArgs a) {
         const cf* tn_row = a.tn + ((size_t)r * NPOLY + kappa) * M_SUB;
         if (BITS) {
             fwd_build_lut(tid, a.rot8 + (r * NPOLY + kappa) * NPOLY, lut);
-            __syncthreads();  // table (and, first time, the staged bits) ready; previous row's copy-out finished
+            __syncthreads();  // table (and, first time, the staged bits) ready; previous row's pass-3 reads finished
             fwd_phase1(tid, kappa, BitsSrc{reinterpret_cast<const uint8_t*>(ib), reinterpret_cast<const uint8_t*>(qb), lut}, tn_row, w, lds);
         } else if (SRC == SRC_REALMIX) {
             __syncthreads();
-            fwd_phase1(tid, kappa, RealMixSrc{(const float*)a.src + (size_t)srci * a.src_stride, a.cos_mask, a.sin_mask}, tn_row, w, lds);
+            fwd_phase1(tid, kappa, CplxSrc{(const cf*)a.src + (size_t)srci * a.src_stride}, tn_row, w, lds);
         } else {
             __syncthreads();
             fwd_phase1(tid, kappa, RealSrc{(const float*)a.src + (size_t)srci * a.src_stride}, tn_row, w, lds);
@@ -95,11 +95,7 @@ __global__ __launch_bounds__(WG) void k_fwd(FwdArgs a) {
         __syncthreads();
         cf y[RC];
         fwd_phase3_load(tid, lds, y);
-        __syncthreads();
-        fwd_phase3_store(tid, a.conj_out != 0, y, lds);
-        __syncthreads();
-        cf* dst = a.out + (size_t)item * a.item_stride + (size_t)kappa * a.row + a.off;
-        for (int i = tid; i < M_SUB / 2; i += WG) reinterpret_cast<cf2*>(dst)[i] = reinterpret_cast<const cf2*>(lds)[i];
+        fwd_phase3_store(tid, a.conj_out != 0, y, a.out + (size_t)item * a.item_stride + (size_t)kappa * a.row + a.off);
     }
 }
 

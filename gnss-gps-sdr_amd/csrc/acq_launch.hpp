@@ -10,12 +10,12 @@
 namespace acq {
 
 struct FwdArgs {
-    const void* src;     // bits: packed capture bytes; iq8: interleaved 8-bit I,Q bytes (16-byte aligned); real: float replicas
-    size_t src_stride;   // per item: bytes (bits, iq8) or floats (real)
+    const void* src;     // bits: packed capture bytes; iq8: interleaved 8-bit I,Q bytes (16-byte aligned); real: float replicas;
+                         // realmix: complex floats (multi-bit samples with the LO applied)
+    size_t src_stride;   // per item: bytes (bits, iq8), floats (real) or complex floats (realmix)
     IqConv iq;           // iq8 source: format, mean, mixer
     size_t iq_first;     // iq8 source: capture sample index of src's first sample (the mixer's n, proc_rtl_bin_for_gps.m:41)
     size_t iq_total;     // iq8 source: samples of the whole capture (samples beyond it read as bit 0, like the converter's tail)
-    const uint8_t *cos_mask, *sin_mask;  // [5120] LO masks, plain bit order (multi-bit float source only)
     const uint64_t* cos_t;  // [625] bit-transposed LO masks (bits source only)
     const uint64_t* sin_t;
     const cf* t1;

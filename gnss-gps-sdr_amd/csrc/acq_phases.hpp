@@ -266,21 +266,14 @@ struct RealSrc {
     }
 };
 
-// multi-bit real-IF samples (8-bit IQ capture kept at full amplitude, SURVEY.md section 8f.1 "direct float path"): the
-// quadrature LO of Sample() (:143-153) applied as signs to the float sample instead of XOR-ed into a sign bit:
-// I = +-x by lo_cos, Q = +-x by lo_sin (mask bit 1 <-> factor -1, like Bipolar(bit ^ lo))
-struct RealMixSrc {
-    const float* x;           // [>= 40000] real-IF samples of the block
-    const uint8_t* cos_mask;  // [5000] LO masks of lo_masks(), bit i of byte i / 8 (LSB first)
-    const uint8_t* sin_mask;
+// multi-bit samples (8-bit IQ capture kept at full amplitude, SURVEY.md section 8f.1 "direct float path"): complex floats with the
+// quadrature LO already applied as signs (iq_kernels.hip::k_iq_to_mixed); plain pruned radix-8 like the code replicas
+struct CplxSrc {
+    const cf* x;  // [40000]
     ACQ_HD cf partial(int np, cf c4, cf c2, cf c1) const {
         cf v[NPOLY];
 #pragma unroll
-        for (int nu = 0; nu < NPOLY; ++nu) {
-            const int n = np + M_SUB * nu;
-            const float s = x[n];
-            v[nu] = mk(s * pm1((cos_mask[n >> 3] >> (n & 7)) & 1u), s * pm1((sin_mask[n >> 3] >> (n & 7)) & 1u));
-        }
+        for (int nu = 0; nu < NPOLY; ++nu) v[nu] = x[np + M_SUB * nu];
         return dft8_one(v, c4, c2, c1);
     }
 };
@@ -326,19 +319,21 @@ ACQ_HD void fwd_phase1(int tid, int kappa, const Src& src, const cf* __restrict_
 ACQ_HD void fwd_phase2(int tid, const cf* __restrict__ t2, cf* lds) {
     if (tid < NBF2) pass2_inplace<-1>(tid, t2, lds);
 }
-// pass 3 into registers (all threads must finish before fwd_phase3_store overwrites the LDS)
+// pass 3 into registers.  Thread tid owns the radix-20 butterfly rho = tid (identity map), so that output n of the 64 lanes of
+// a wave is 64 consecutive bins k' = 250 n + rho of the row:
 ACQ_HD void fwd_phase3_load(int tid, const cf* lds, cf* y) {
-    if (tid < NBF3) pass3_load<-1>(pass3_rho(tid), lds, y);
+    if (tid < NBF3) pass3_load<-1>(tid, lds, y);
 }
-// natural order k' = 250 n'' + rho; conjugated for block spectra (Correlate multiplies by conj(data), :183-184)
+// ... and leaves straight from the registers, one 512-byte segment per wave and output (round 3; rounds 1-2 staged the row in
+// LDS for 16-byte stores, at the price of two more barriers and an LDS round trip per row).
+// natural order k' = 250 n + rho; conjugated for block spectra (Correlate multiplies by conj(data), :183-184)
 ACQ_HD void fwd_phase3_store(int tid, bool conj_out, const cf* y, cf* dst) {
     if (tid >= NBF3) return;
-    const int rho = pass3_rho(tid);
 #pragma unroll
     for (int n = 0; n < RC; ++n) {
         cf v = y[n];
         if (conj_out) v.y = -v.y;
-        dst[NBF3 * n + rho] = v;
+        dst[NBF3 * n + tid] = v;
     }
 }
 

@@ -92,7 +92,7 @@ struct gpsacq_engine {
     size_t iq_cap = 0;
     uint8_t* d_iqbits = nullptr;
     size_t iqbits_cap = 0;
-    float* d_fsamp = nullptr;  // multi-bit path: real-IF float samples of the batch
+    float* d_fsamp = nullptr;  // multi-bit path: the batch's samples as complex floats, LO applied ([block][40000][2])
     size_t fsamp_cap = 0;
     unsigned long long* d_sums = nullptr;
     // capture generator scratch
@@ -175,9 +175,8 @@ static int run_forward(gpsacq_engine* e, FwdKind kind, const void* src, size_t s
     for (size_t base = 0; base < n_src; base += chunk) {  // grid.y bound
         const size_t cnt = std::min(chunk, n_src - base) * (size_t)sub;
         FwdArgs fa{};
-        fa.src = (kind == FWD_REAL || kind == FWD_REALMIX) ? (const void*)((const float*)src + base * src_stride) : (const void*)((const uint8_t*)src + base * src_stride);
-        fa.cos_mask = e->d_cos;
-        fa.sin_mask = e->d_sin;
+        fa.src = kind == FWD_REAL ? (const void*)((const float*)src + base * src_stride)
+                 : kind == FWD_REALMIX ? (const void*)((const cf*)src + base * src_stride) : (const void*)((const uint8_t*)src + base * src_stride);
         fa.src_stride = src_stride;
         if (kind == FWD_IQ8) {
             fa.iq = cap->iq;
@@ -539,16 +538,16 @@ static int search_core(gpsacq_engine* e, const Capture& cap_in, size_t n_blocks,
         const size_t avail = cap.iq_total > cap.iq_first ? cap.iq_total - cap.iq_first : 0;
         const size_t n_samples = std::min(want, avail);
         if (n_samples < want) return fail(GPSACQ_ERR_ARG, "multi-bit path: the capture ends inside the batch (%zu of %zu samples)", n_samples, want);
-        if (int rc = grow(e->d_fsamp, e->fsamp_cap, want, e->stream)) return rc;
+        if (int rc = grow(e->d_fsamp, e->fsamp_cap, n_blocks * (size_t)N_FFT * 2, e->stream)) return rc;  // [block][40000] complex
         IqArgs ia{};
         ia.iq = cap.d_src;
         ia.bits = nullptr;
         ia.n_samples = n_samples;
         ia.first_sample = cap.iq_first;
         ia.conv = cap.iq;
-        launch_iq_to_real(ia, e->d_fsamp, e->stream);
+        launch_iq_to_mixed(ia, stride / 2, n_blocks, e->d_cos, e->d_sin, e->d_fsamp, e->stream);
         HIPCHK(hipGetLastError());
-        if (int rc = run_forward(e, FWD_REALMIX, e->d_fsamp, stride / 2, n_blocks, e->d_dpp, (size_t)NPOLY * M_SUB, M_SUB, 0, true)) return rc;
+        if (int rc = run_forward(e, FWD_REALMIX, e->d_fsamp, N_FFT, n_blocks, e->d_dpp, (size_t)NPOLY * M_SUB, M_SUB, 0, true)) return rc;
     } else if (int rc = run_forward(e, cap.iq8 ? FWD_IQ8 : FWD_BITS, cap.d_src, stride, n_blocks, e->d_dpp, (size_t)NPOLY * M_SUB, M_SUB, 0, true, 0, &cap)) return rc;
     HIPCHK(hipEventRecord(ev[1], e->stream));
     // the block period in samples: what the code creeps over between accumulated blocks

@@ -75,28 +75,31 @@ __global__ __launch_bounds__(256) void k_iq_to_bits(IqArgs a) {
 }
 
 // multi-bit path (SURVEY.md section 8f.1 "direct float path"; no reference counterpart: gps_test only reads 1-bit files): the
-// same real-IF value, kept as a float instead of its sign.  One thread per 8 samples.
-__global__ __launch_bounds__(256) void k_iq_to_real(IqArgs a, float* __restrict__ out) {
-    const size_t g = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-    const size_t s0 = g * 8;
-    if (s0 >= a.n_samples) return;
+// same real-IF value kept as a float instead of its sign, with the quadrature LO of Sample() (:143-153) applied as signs
+// (I = +-x by lo_cos, Q = +-x by lo_sin; mask bit 1 <-> factor -1, like Bipolar(bit ^ lo); the LO phase restarts with every
+// block, :131).  One thread per 8 samples; out[block][40000] complex.
+__global__ __launch_bounds__(256) void k_iq_to_mixed(IqArgs a, size_t stride_samples, size_t n_blocks, const uint8_t* __restrict__ cos_mask,
+                                                     const uint8_t* __restrict__ sin_mask, float2* __restrict__ out) {
+    const size_t g = (size_t)blockIdx.x * blockDim.x + threadIdx.x;  // group of 8 samples inside a block: 5000 groups per block
+    const size_t blk = g / 5000;
+    const int grp = (int)(g - blk * 5000);
+    if (blk >= n_blocks) return;
+    const size_t s0 = blk * stride_samples + (size_t)grp * 8;  // sample index inside the batch (stride_samples is a multiple of 8)
     unsigned raw[4] = {0, 0, 0, 0};
     if (s0 + 8 <= a.n_samples) {
-        const uint4 v = reinterpret_cast<const uint4*>(a.iq)[g];
+        const uint4 v = reinterpret_cast<const uint4*>(a.iq)[s0 / 8];
         raw[0] = v.x; raw[1] = v.y; raw[2] = v.z; raw[3] = v.w;
-    } else {
-        for (size_t s = s0; s < a.n_samples; ++s) {
-            const unsigned pair = a.iq[2 * s] | ((unsigned)a.iq[2 * s + 1] << 8);
-            raw[(s - s0) >> 1] |= pair << (16 * ((s - s0) & 1));
-        }
     }
+    const unsigned cm = cos_mask[grp], sm = sin_mask[grp];
 #pragma unroll
-    for (int k = 0; k < 8; ++k)
-        if (s0 + k < a.n_samples) out[s0 + k] = (float)iq8_value((raw[k >> 1] >> (16 * (k & 1))) & 0xffffu, a.first_sample + s0 + k, a.conv);
+    for (int k = 0; k < 8; ++k) {
+        const float r = (s0 + k < a.n_samples) ? (float)iq8_value((raw[k >> 1] >> (16 * (k & 1))) & 0xffffu, a.first_sample + s0 + k, a.conv) : 0.f;
+        out[blk * 40000 + (size_t)grp * 8 + k] = make_float2(((cm >> k) & 1u) ? -r : r, ((sm >> k) & 1u) ? -r : r);
+    }
 }
-void launch_iq_to_real(const IqArgs& a, float* out, hipStream_t s) {
-    const size_t groups = (a.n_samples + 7) / 8;
-    hipLaunchKernelGGL(k_iq_to_real, dim3((unsigned)((groups + 255) / 256)), dim3(256), 0, s, a, out);
+void launch_iq_to_mixed(const IqArgs& a, size_t stride_samples, size_t n_blocks, const uint8_t* cos_mask, const uint8_t* sin_mask, void* out, hipStream_t s) {
+    const size_t groups = n_blocks * 5000;
+    hipLaunchKernelGGL(k_iq_to_mixed, dim3((unsigned)((groups + 255) / 256)), dim3(256), 0, s, a, stride_samples, n_blocks, cos_mask, sin_mask, (float2*)out);
 }
 
 void launch_iq_sums(const uint8_t* iq, size_t n_samples, int is_signed, unsigned long long* sums, hipStream_t s) {

@@ -32,8 +32,7 @@ static void emul_fwd_row(const Src& src, int kappa, bool conj_out, cf* row /*[50
     }
     for (int tid = 0; tid < WG; ++tid) fwd_phase2(tid, T.t2.data(), lds.data());
     for (int tid = 0; tid < WG; ++tid) fwd_phase3_load(tid, lds.data(), &regs[(size_t)tid * RC]);
-    for (int tid = 0; tid < WG; ++tid) fwd_phase3_store(tid, conj_out, &regs[(size_t)tid * RC], lds.data());
-    for (int i = 0; i < M_SUB; ++i) row[i] = lds[i];
+    for (int tid = 0; tid < WG; ++tid) fwd_phase3_store(tid, conj_out, &regs[(size_t)tid * RC], row);
 }
 
 template <class Src>
