@@ -174,12 +174,13 @@ def cpu_baseline_all_cores(cfg, bits, ndop, one_thread_rate, target_s=8.0):
     buf = np.ascontiguousarray(bits)
     nblk = buf.size // 5120
     el, used = ctypes.c_double(), ctypes.c_int()
-    cells = L.oracle_bench_omp(cfg["fc"], cfg["fs"], cfg["max_fo"], buf.ctypes.data, nblk, 5120, ncpu, target_s, ctypes.byref(el), ctypes.byref(used))
+    nthreads = ncpu if quota is None else max(1, min(ncpu, int(math.ceil(quota))))  # more threads than the quota only add switching
+    cells = L.oracle_bench_omp(cfg["fc"], cfg["fs"], cfg["max_fo"], buf.ctypes.data, nblk, 5120, nthreads, target_s, ctypes.byref(el), ctypes.byref(used))
     rate = cells / el.value
     return {"value": rate, "unit": "cells/s", "cores": used.value, "kind": "port",
             "sched_getaffinity_cores": ncpu, "os_cpu_count": os.cpu_count(), "cgroup_cpu_quota_cores": quota,
             "speedup_over_1_thread": rate / one_thread_rate if one_thread_rate else None,
-            "sample": f"OpenMP, {used.value} threads (sched_getaffinity: {ncpu} cores), blocks of the same {nblk}-block sample dealt "
+            "sample": f"OpenMP, {used.value} threads (sched_getaffinity: {ncpu} cores, cgroup cpu.max quota: {quota} cores), blocks of the same {nblk}-block sample dealt "
                       f"round-robin x {ndop} bins for {el.value:.1f} s = {cells} cells"}
 
 
