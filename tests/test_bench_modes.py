@@ -34,3 +34,24 @@ def test_configs4_line():
     j = _bench("--config", "4", "--doppler-step", "50", "--grid-blocks", "1")
     assert "4399 Doppler points" in j["config"]["workload"] and j["config"]["cells_per_step_job"] == 32 * 4399
     assert j["value"] > 0 and j["roofline"]["kernel"] == "k_corr<22>"
+
+
+def test_iq8_input_line():
+    """`bench.py --input iq8`: the capture is an 8-bit IQ stream converted inside the forward transform; the satellites
+    injected into the baseband capture are found after the engine's mixer, and the ingest stage is reported."""
+    j = _bench("--input", "iq8", "--blocks-total", "256", "--no-e2e")
+    assert "8-bit IQ" in j["config"]["input"] and j["config"]["cells_per_step_job"] == 256 * 73
+    ing = j["ingest"]
+    assert ing["kernel"] == "k_fwd<iq8>" and ing["bytes_read"] == 256 * 80000 and 0 < ing["frac_of_copy_ceiling"] < 1
+    assert j["roofline"]["traffic_stale"] is True  # the committed counters belong to the 1-bit line's kernel instance mix
+    assert set(j["detected_prns"]) >= set(j["injected_prns_all_ranks"])
+
+
+def test_default_line_carries_the_round3_fields():
+    j = _bench("--blocks-total", "640", "--weak-blocks", "0")
+    assert j["rccl_ranks_seen"] == 1 and j["blocks_per_rank"] == [640] and j["n_gpus"] == 1
+    r = j["roofline"]
+    assert isinstance(r["traffic_stale"], bool) and len(r["kernel_source_sha"]) == 16
+    e = j["e2e_cli"]
+    assert e["runs_reported"] == 20 and e["wall_s"] > 0 and e["hip_process_floor_s"] > 0 and "SearchTask" in e["split_ms"]
+
