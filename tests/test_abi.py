@@ -149,3 +149,5 @@ def test_c99_client_on_gpu(tmp_path):
     assert r.returncode == 0, r.stderr
     assert r.stdout.startswith("bins 49 lags 8184 best sv 7 snr 713.6 lo_shift 0 ca_shift 260 doppler 0.0 Hz")
     assert "half-bin grid: 97 points of 102.30 Hz; multi (1 device) block 7 sv 7 snr 713.6 lo_shift 0 ca_shift 260" in r.stdout
+    assert "pipeline: 16 + 16 peaks" in r.stdout and "multi blocks (2 engines on device 0): best sv 7 snr 713.6" in r.stdout
+    assert "iq8: block 0 sv 7 snr" in r.stdout

@@ -170,6 +170,18 @@ def test_cli_iq8_input_equals_preconverted_1bit(tmp_path):
     assert "satellite" in lines[0] and "    4 " in lines[0]
     r = subprocess.run([GPS_TEST, f_iq] + args, capture_output=True, text=True, env=dict(os.environ, GPSACQ_INPUT="wav"), timeout=120)
     assert r.returncode != 0 and "GPSACQ_INPUT" in r.stderr
+    # HackRF format (int8, proc_hackrf_bin_for_gps.m:7-19: the real part, no mixer) and the multi-bit switch
+    s8 = (iq.astype(np.int16) - 128).astype(np.int8)
+    f_s8, f_b8 = str(tmp_path / "cap_s8.bin"), str(tmp_path / "cap_s8_1bit.bin")
+    s8.tofile(f_s8)
+    with gpsacq.Engine(0.62e6, 2.8e6, 5000.0) as eng:
+        eng.iq8_to_bits(s8, signed=True, remove_dc=True, mix_hz=0.0, fs=2.8e6).tofile(f_b8)
+    a = subprocess.run([GPS_TEST, f_b8] + args, capture_output=True, text=True, timeout=300)
+    b = subprocess.run([GPS_TEST, f_s8] + args, capture_output=True, text=True, timeout=300, env=dict(os.environ, GPSACQ_INPUT="iq_s8"))
+    assert a.returncode == 0 and b.returncode == 0 and a.stdout == b.stdout and a.stdout.count("satellite:") == 2
+    m = subprocess.run([GPS_TEST, f_iq] + args, capture_output=True, text=True, timeout=300,
+                       env=dict(os.environ, GPSACQ_INPUT="iq_u8", GPSACQ_MIX_HZ="0.62e6", GPSACQ_IQ_MULTIBIT="1"))
+    assert m.returncode == 0 and m.stdout.count("satellite:") == 2 and "    4 " in m.stdout[len(BANNER):].split("\n")[0]
 
 
 def test_cli_streams_batches_of_growing_size(golden_dir):
