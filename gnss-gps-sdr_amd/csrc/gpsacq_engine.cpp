@@ -325,7 +325,14 @@ extern "C" int gpsacq_create(const gpsacq_params* params, gpsacq_engine** out) {
         for (auto& ev : set) HCK(hipEventCreate(&ev));
 
     const double ms_before_prep = lap();
-    std::unique_ptr<HostPrep> hp = prep_job.get();
+    std::unique_ptr<HostPrep> hp;
+    try {
+        hp = prep_job.get();
+    } catch (const std::exception& ex) {  // nothing may cross the C ABI as an exception
+        int rc_ = fail(GPSACQ_ERR_NOMEM, "host table preparation failed: %s", ex.what());
+        gpsacq_destroy(e);
+        return rc_;
+    }
     const Tables& T = hp->T;
     const double ms_prep_wait = lap() - ms_before_prep;
     HCK(hipMalloc((void**)&e->d_t1, T.t1.size() * sizeof(cf)));

@@ -156,7 +156,9 @@ GPSACQ_API int gpsacq_search_device(gpsacq_engine* e, const void* d_bits, size_t
 /*
  * Pipelined host-buffer searches on the reference schedule (task t = block t against PRN t % 32, the body of SearchTask()'s
  * loop :237-262).  A slot owns a pinned host staging buffer, a device copy and a pinned peak array:
- *   buf = gpsacq_pipe_buffer(e, slot, nbytes)      pinned buffer of >= nbytes (fread the batch straight into it); NULL on error
+ *   buf = gpsacq_pipe_buffer(e, slot, nbytes)      pinned buffer of >= nbytes (fread the batch straight into it); NULL on error.  A call
+ *                                                  that asks for more than the slot holds re-allocates it: pointers from earlier calls
+ *                                                  for that slot are then invalid (ask once for the largest batch)
  *   gpsacq_pipe_submit(e, slot, n_blocks, stride, iq)   upload on a second stream + search, returns at once (iq == NULL: 1-bit
  *                                                  blocks `stride` bytes apart; else 8-bit IQ, see gpsacq_search_iq8)
  *   gpsacq_pipe_collect(e, slot, &peaks, &n)       waits for THAT slot's search; peaks stay valid until its next submit
