@@ -379,6 +379,8 @@ def main():
     # GPSACQ_DIST_BACKEND=gloo lets several ranks share one GPU to exercise the N > 1 code path on a 1-GPU box
     # (collectives then run on CPU copies); the driver's runs use nccl (= RCCL).
     dev_index = local_rank % torch.cuda.device_count() if backend == "gloo" else local_rank
+    if dev_index >= torch.cuda.device_count():  # more ranks than GPUs on the RCCL backend: never share a device silently
+        raise SystemExit(f"rank {rank}: device {dev_index} not visible ({torch.cuda.device_count()} device(s), --gpus {args.gpus})")
     torch.cuda.set_device(dev_index)
     dist = None
     if world > 1:
