@@ -11,9 +11,13 @@ pytestmark = pytest.mark.gpu
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
-def _bench(*args):
+def _bench(*args, env=None):
+    e = dict(os.environ)
+    for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT"):
+        e.pop(k, None)
+    e.update(env or {})
     r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "1", "--warmup", "1", "--no-cpu-baseline", *args],
-                       capture_output=True, text=True, timeout=600)
+                       capture_output=True, text=True, timeout=600, env=e)
     assert r.returncode == 0, r.stderr[-2000:]
     lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
     assert len(lines) == 1, r.stdout
@@ -54,4 +58,13 @@ def test_default_line_carries_the_round3_fields():
     assert isinstance(r["traffic_stale"], bool) and len(r["kernel_source_sha"]) == 16
     e = j["e2e_cli"]
     assert e["runs_reported"] == 20 and e["wall_s"] > 0 and e["hip_process_floor_s"] > 0 and "SearchTask" in e["split_ms"]
+
+
+def test_two_self_spawned_ranks_share_the_capture():
+    """`bench.py --gpus 2` launched plainly: it starts its own two ranks (gloo here, both on the one GPU), splits the runs between
+    them and says so in the line."""
+    j = _bench("--gpus", "2", "--blocks-total", "640", "--weak-blocks", "0", "--no-e2e", env={"GPSACQ_DIST_BACKEND": "gloo"})
+    assert j["n_gpus"] == 2 and j["rccl_ranks_seen"] == 2 and j["dist_backend"] == "gloo"
+    assert j["blocks_per_rank"] == [320, 320] and j["config"]["cells_per_step_job"] == 640 * 73
+    assert set(j["detected_prns"]) >= set(j["injected_prns_all_ranks"])
 
