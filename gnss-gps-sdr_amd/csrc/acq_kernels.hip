@@ -165,12 +165,13 @@ template <class L> __device__ __forceinline__ int corr_rho(const CorrArgs& a, in
     if constexpr (L::REMAP) return (int)a.rho_map[t3];
     else return pass3_rho<L>(t3);
 }
-template <int MC, int WPS, int NB, bool NC, bool W1H = false, bool PROF = false, class L = ACQ_CORR_LAYOUT>
+// NCREG: non-coherent sums kept in registers (no creep re-alignment asked for: every lag stays with its thread)
+template <int MC, int WPS, int NB, bool NC, bool W1H = false, bool PROF = false, class L = ACQ_CORR_LAYOUT, bool NCREG = false>
 __global__ __launch_bounds__(WG, WPS) void k_corr(CorrArgs a) {
     __shared__ __attribute__((aligned(16))) cf lds[L::SIZE];  // transform buffer
     __shared__ cf t2s[NT2];    // the 500 pass-2 twiddles
     __shared__ float red[4 * (WG / 64)];
-    __shared__ float pws[NC ? MC * NBF3 : 1];  // non-coherent power per lag of this pass
+    __shared__ float pws[NC && !NCREG ? MC * NBF3 : 1];  // non-coherent power per lag of this pass
     const int tid = threadIdx.x;
     const int g = blockIdx.x, xcd = g & 7, slot = g >> 3;
     const int grp = slot / a.ndop, di = slot - grp * a.ndop;
@@ -203,9 +204,14 @@ __global__ __launch_bounds__(WG, WPS) void k_corr(CorrArgs a) {
 #pragma unroll
     for (int m = 0; m < MC; ++m) acc[m] = mk(0.f, 0.f);
 
-    if (NC && tid < NBF3) {
+    if (NC && !NCREG && tid < NBF3) {
 #pragma unroll
         for (int m = 0; m < MC; ++m) pws[NBF3 * m + tid] = 0.f;  // first read-modify-write is >= 3 barriers away
+    }
+    float pw[NCREG ? MC : 1];
+    if (NCREG) {
+#pragma unroll
+        for (int m = 0; m < MC; ++m) pw[m] = 0.f;
     }
     unsigned long long tprof[8] = {0, 0, 0, 0, 0, 0, 0, 0}, tm = PROF ? __builtin_amdgcn_s_memtime() : 0;
 #define ACQ_STAMP(k)                                                  \
@@ -244,7 +250,8 @@ __global__ __launch_bounds__(WG, WPS) void k_corr(CorrArgs a) {
             __syncthreads();
             ACQ_STAMP(6);
         }
-        if (NC) {
+        if (NC && NCREG) corr_accumulate_power_reg<MC>(tid, acc, pw);
+        else if (NC) {
             // every lag has one owner per block, so the scatter needs no atomics; successive blocks'
             // updates are separated by the barriers of the next 8 sub-transforms
             corr_accumulate_power<MC>(tid, rho, a.nlags, a.m0, __float2int_rn((float)k * a.creep * (float)(di + a.dop_first)), acc, pws);
@@ -253,7 +260,8 @@ __global__ __launch_bounds__(WG, WPS) void k_corr(CorrArgs a) {
 
     float mx, sum;
     int mi;
-    if (NC) {
+    if (NC && NCREG) corr_scan_power_reg<MC>(tid, rho, a.nlags, a.m0, pw, mx, mi, sum);
+    else if (NC) {
         __syncthreads();  // the last block's scatter
         corr_scan_power<MC>(tid, rho, a.nlags, a.m0, pws, mx, mi, sum);
     }
@@ -481,7 +489,10 @@ int launch_corr(const CorrArgs& a, int mc, hipStream_t s) {
     // faster at 3 per CU (14.4 vs 13.5 M cells/s; without W1H 116 bytes and slower: profiles/r02_experiments/i, r02j).
     switch (mc) {
         case 12:
-            if (a.n_acc > 1) hipLaunchKernelGGL((k_corr<12, 2, 2, true>), grid, block, 0, s, a);
+            // non-coherent: without creep re-alignment the per-lag sums stay in registers and three workgroups fit a CU (BASELINE
+            // configs[3]); with it they go through a per-lag LDS array (61 KB: two per CU)
+            if (a.n_acc > 1 && a.creep == 0.f) hipLaunchKernelGGL((k_corr<12, 3, 2, true, false, false, ACQ_CORR_LAYOUT, true>), grid, block, 0, s, a);
+            else if (a.n_acc > 1) hipLaunchKernelGGL((k_corr<12, 2, 2, true>), grid, block, 0, s, a);
             else hipLaunchKernelGGL((k_corr<12, 3, 2, false>), grid, block, 0, s, a);
             break;
         case 22:

@@ -201,6 +201,33 @@ ACQ_HD void corr_accumulate_power(int tid, int rho, int S, int m0, int shift, cf
         acc[m] = mk(0.f, 0.f);
     }
 }
+// non-coherent mode without lag re-alignment: every lag keeps its owner from block to block, so the sums can stay in registers
+// (no per-lag LDS array: the 12-column instance then fits three workgroups per CU like the coherent one)
+template <int MC>
+ACQ_HD void corr_accumulate_power_reg(int tid, cf* acc, float* pw) {
+    if (tid >= NBF3) return;
+#pragma unroll
+    for (int m = 0; m < MC; ++m) {
+        pw[m] += acc[m].x * acc[m].x + acc[m].y * acc[m].y;
+        acc[m] = mk(0.f, 0.f);
+    }
+}
+template <int MC>
+ACQ_HD void corr_scan_power_reg(int tid, int rho, int S, int m0, const float* pw, float& mx, int& mi, float& sum) {
+    mx = 0.f;
+    mi = 0;
+    sum = 0.f;
+    if (tid >= NBF3) return;
+#pragma unroll
+    for (int m = 0; m < MC; ++m) {
+        const int n = NBF3 * (m0 + m) + rho;
+        const float p = (n < S) ? pw[m] : 0.f;
+        const bool up = p > mx;
+        mx = up ? p : mx;
+        mi = up ? n : mi;
+        sum += p;
+    }
+}
 // same scan as corr_scan over the summed powers
 template <int MC>
 ACQ_HD void corr_scan_power(int tid, int rho, int S, int m0, const float* pws, float& mx, int& mi, float& sum) {
