@@ -161,6 +161,49 @@ __global__ __launch_bounds__(WG) void k_quirk_patch(QuirkArgs a) {
 #else
 #define ACQ_PHASE1_PRIO(level) __builtin_amdgcn_s_setprio(level)
 #endif
+// Peak / sum reduction over the 64 lanes of a wave: inside the four rows of 16 lanes by DPP row shifts (VALU latency), the four
+// row results through v_readlane -- instead of six rounds of ds_bpermute (each an LDS-crossbar round trip; -DACQ_NO_DPP_REDUCE
+// builds that form): -0.5 % kernel time (profiles/r03_experiments/g_dpp_reduction.log).
+// peak_merge is associative and commutative (larger power, ties to the lower lag), so the order of the merges is free.
+template <int CTRL> __device__ __forceinline__ int dpp_mov(int old, int v) { return __builtin_amdgcn_update_dpp(old, v, CTRL, 0xf, 0xf, false); }
+__device__ __forceinline__ void wave_reduce_peak(float& mx, int& mi, float& sum) {
+#ifndef ACQ_NO_DPP_REDUCE
+#define ACQ_DPP_STEP(CTRL)                                                          \
+    {                                                                               \
+        const float omx = __int_as_float(dpp_mov<CTRL>(0, __float_as_int(mx)));     \
+        const int omi = dpp_mov<CTRL>(0x7fffffff, mi);                              \
+        const float os = __int_as_float(dpp_mov<CTRL>(0, __float_as_int(sum)));     \
+        peak_merge(mx, mi, omx, omi);                                               \
+        sum += os;                                                                  \
+    }
+    ACQ_DPP_STEP(0x111)  // row_shr:1 -- lane i takes lane i-1 of its row (lanes without a source keep the neutral `old`)
+    ACQ_DPP_STEP(0x112)
+    ACQ_DPP_STEP(0x114)
+    ACQ_DPP_STEP(0x118)
+#undef ACQ_DPP_STEP
+    // lanes 15, 31, 47, 63 hold their rows' results
+    float rmx = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(mx), 15));
+    int rmi = __builtin_amdgcn_readlane(mi, 15);
+    float rs = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(sum), 15));
+#pragma unroll
+    for (int r = 1; r < 4; ++r) {
+        peak_merge(rmx, rmi, __int_as_float(__builtin_amdgcn_readlane(__float_as_int(mx), 16 * r + 15)), __builtin_amdgcn_readlane(mi, 16 * r + 15));
+        rs += __int_as_float(__builtin_amdgcn_readlane(__float_as_int(sum), 16 * r + 15));
+    }
+    mx = rmx;
+    mi = rmi;
+    sum = rs;
+#else
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) {
+        const float omx = __shfl_down(mx, off, 64);
+        const int omi = __shfl_down(mi, off, 64);
+        const float os = __shfl_down(sum, off, 64);
+        peak_merge(mx, mi, omx, omi);
+        sum += os;
+    }
+#endif
+}
 template <class L> __device__ __forceinline__ int corr_rho(const CorrArgs& a, int t3) {
     if constexpr (L::REMAP) return (int)a.rho_map[t3];
     else return pass3_rho<L>(t3);
@@ -267,14 +310,7 @@ __global__ __launch_bounds__(WG, WPS) void k_corr(CorrArgs a) {
     }
     else corr_scan<MC>(tid, rho, a.nlags, a.m0, acc, mx, mi, sum);
     // wave reduction (64 lanes), then across the 4 waves through LDS
-#pragma unroll
-    for (int off = 32; off > 0; off >>= 1) {
-        const float omx = __shfl_down(mx, off, 64);
-        const int omi = __shfl_down(mi, off, 64);
-        const float os = __shfl_down(sum, off, 64);
-        peak_merge(mx, mi, omx, omi);
-        sum += os;
-    }
+    wave_reduce_peak(mx, mi, sum);
     const int wave = tid >> 6;
     if ((tid & 63) == 0) {
         red[wave * 4 + 0] = mx;
@@ -365,14 +401,7 @@ __global__ __launch_bounds__(WG8, WPS) void k_corr8(CorrArgs a) {
     float mx, sum;
     int mi;
     corr8_scan<MC>(tid, a.nlags, acc, mx, mi, sum);
-#pragma unroll
-    for (int off = 32; off > 0; off >>= 1) {
-        const float omx = __shfl_down(mx, off, 64);
-        const int omi = __shfl_down(mi, off, 64);
-        const float os = __shfl_down(sum, off, 64);
-        peak_merge(mx, mi, omx, omi);
-        sum += os;
-    }
+    wave_reduce_peak(mx, mi, sum);
     const int wave = tid >> 6;
     if ((tid & 63) == 0) {
         red[wave * 4 + 0] = mx;
