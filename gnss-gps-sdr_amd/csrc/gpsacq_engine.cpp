@@ -128,7 +128,7 @@ struct Capture {
     size_t stride = 0;               // bytes per block in d_src
     IqConv iq{};
     size_t iq_first = 0, iq_total = ~(size_t)0;
-    bool multibit = false;  // 8-bit IQ kept at full amplitude (float samples) instead of its sign
+    int multibit = 0;  // 8-bit IQ kept at full amplitude (float samples) instead of its sign: 1 the real-IF value, 2 the complex sample
 };
 
 static const size_t kFwdChunk = 32768;  // blocks per forward-transform launch (grid.y bound)
@@ -540,7 +540,8 @@ static int search_core(gpsacq_engine* e, const Capture& cap_in, size_t n_blocks,
     HIPCHK(hipEventRecord(ev[0], e->stream));
     if (cap.iq8 && cap.multibit) {
         // multi-bit path: the real-IF value of every sample as a float (same arithmetic as the 1-bit converter, iq_convert.hpp),
-        // then the forward transform with the LO applied as signs
+        // then the forward transform with the LO applied as signs; or (multibit 2) the complex sample itself -- a capture that
+        // is at baseband already, no LO
         const size_t want = (n_blocks - 1) * (stride / 2) + (size_t)USED_BYTES * 8;
         const size_t avail = cap.iq_total > cap.iq_first ? cap.iq_total - cap.iq_first : 0;
         const size_t n_samples = std::min(want, avail);
@@ -552,7 +553,8 @@ static int search_core(gpsacq_engine* e, const Capture& cap_in, size_t n_blocks,
         ia.n_samples = n_samples;
         ia.first_sample = cap.iq_first;
         ia.conv = cap.iq;
-        launch_iq_to_mixed(ia, stride / 2, n_blocks, e->d_cos, e->d_sin, e->d_fsamp, e->stream);
+        if (cap.multibit == 2) launch_iq_to_complex(ia, stride / 2, n_blocks, e->d_fsamp, e->stream);
+        else launch_iq_to_mixed(ia, stride / 2, n_blocks, e->d_cos, e->d_sin, e->d_fsamp, e->stream);
         HIPCHK(hipGetLastError());
         if (int rc = run_forward(e, FWD_REALMIX, e->d_fsamp, N_FFT, n_blocks, e->d_dpp, (size_t)NPOLY * M_SUB, M_SUB, 0, true)) return rc;
     } else if (int rc = run_forward(e, cap.iq8 ? FWD_IQ8 : FWD_BITS, cap.d_src, stride, n_blocks, e->d_dpp, (size_t)NPOLY * M_SUB, M_SUB, 0, true, 0, &cap)) return rc;
@@ -647,6 +649,7 @@ static Capture bits_capture(const void* d_bits, size_t stride) {
 static int iq8_capture(const gpsacq_engine* e, const gpsacq_iq8_input* in, const void* d_iq, size_t stride, Capture* out) {
     if (!in) return fail(GPSACQ_ERR_ARG, "8-bit IQ search: null gpsacq_iq8_input");
     if (in->format != GPSACQ_IQ_U8 && in->format != GPSACQ_IQ_S8) return fail(GPSACQ_ERR_ARG, "unknown IQ format %d", in->format);
+    if (in->multibit < 0 || in->multibit > GPSACQ_SAMPLES_COMPLEX) return fail(GPSACQ_ERR_ARG, "gpsacq_iq8_input.multibit %d: 0 (sign), 1 (real IF) or 2 (complex baseband)", in->multibit);
     const double fs = in->fs > 0 ? in->fs : e->p.fs;
     Capture c;
     c.iq8 = true;
@@ -660,7 +663,7 @@ static int iq8_capture(const gpsacq_engine* e, const gpsacq_iq8_input* in, const
     c.iq.inv_fs = 1.0 / fs;
     c.iq_first = (size_t)in->first_sample;
     c.iq_total = in->total_samples ? (size_t)in->total_samples : ~(size_t)0;
-    c.multibit = in->multibit != 0;
+    c.multibit = in->multibit;
     *out = c;
     return GPSACQ_OK;
 }

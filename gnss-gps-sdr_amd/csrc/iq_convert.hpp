@@ -38,6 +38,25 @@ __device__ __forceinline__ double iq8_value(unsigned pair, size_t n, const IqCon
     return r;
 }
 
+// the same sample kept complex (the capture is at baseband already): (y - mean) * exp(i theta), theta as above
+__device__ __forceinline__ void iq8_complex(unsigned pair, size_t n, const IqConv& c, double& re, double& im) {
+#pragma clang fp contract(off)
+    double yi, yq;
+    if (c.is_signed) { yi = (double)(int8_t)(pair & 0xff); yq = (double)(int8_t)(pair >> 8); }
+    else { yi = (double)(int)(pair & 0xff) - 128.0; yq = (double)(int)(pair >> 8) - 128.0; }
+    yi -= c.mean_i;
+    yq -= c.mean_q;
+    re = yi;
+    im = yq;
+    if (c.mix) {
+        const double th = (c.two_pi_fc * (double)n) * c.inv_fs;
+        double sn, cs;
+        sincos(th, &sn, &cs);
+        re = yi * cs - yq * sn;
+        im = yi * sn + yq * cs;
+    }
+}
+
 // 8 consecutive samples (16 bytes: I0 Q0 I1 Q1 ...) starting at capture sample n0 -> one byte of the 1-bit stream
 // (sample n0 + k in bit k).  Samples n >= n_samples (ragged tail) give 0 bits.
 __device__ __forceinline__ unsigned iq8_byte(const unsigned (&raw)[4], size_t n0, size_t n_samples, const IqConv& c) {

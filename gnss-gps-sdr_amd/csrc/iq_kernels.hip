@@ -97,9 +97,35 @@ __global__ __launch_bounds__(256) void k_iq_to_mixed(IqArgs a, size_t stride_sam
         out[blk * 40000 + (size_t)grp * 8 + k] = make_float2(((cm >> k) & 1u) ? -r : r, ((sm >> k) & 1u) ? -r : r);
     }
 }
+// complex-baseband path: the capture already is what Sample() builds in fwd_buf -- I + jQ at IF 0, e.g. the int8 +-30 file the
+// reference's own converter writes for HackRF replay (c/conv_1bit_bin_to_hackrf_bin.cpp:61-80: I = Bipolar(bit ^ lo_sin),
+// Q = Bipolar(bit ^ lo_cos), the two components of fwd_buf, :149-150 of search_offline.cpp) -- so no LO here: the samples
+// (less their mean, turned by exp(i theta) when a residual IF is named) go to the forward transform as they are.
+__global__ __launch_bounds__(256) void k_iq_to_complex(IqArgs a, size_t stride_samples, size_t n_blocks, float2* __restrict__ out) {
+    const size_t g = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const size_t blk = g / 5000;
+    const int grp = (int)(g - blk * 5000);
+    if (blk >= n_blocks) return;
+    const size_t s0 = blk * stride_samples + (size_t)grp * 8;
+    unsigned raw[4] = {0, 0, 0, 0};
+    if (s0 + 8 <= a.n_samples) {
+        const uint4 v = reinterpret_cast<const uint4*>(a.iq)[s0 / 8];
+        raw[0] = v.x; raw[1] = v.y; raw[2] = v.z; raw[3] = v.w;
+    }
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+        double re = 0.0, im = 0.0;
+        if (s0 + k < a.n_samples) iq8_complex((raw[k >> 1] >> (16 * (k & 1))) & 0xffffu, a.first_sample + s0 + k, a.conv, re, im);
+        out[blk * 40000 + (size_t)grp * 8 + k] = make_float2((float)re, (float)im);
+    }
+}
 void launch_iq_to_mixed(const IqArgs& a, size_t stride_samples, size_t n_blocks, const uint8_t* cos_mask, const uint8_t* sin_mask, void* out, hipStream_t s) {
     const size_t groups = n_blocks * 5000;
     hipLaunchKernelGGL(k_iq_to_mixed, dim3((unsigned)((groups + 255) / 256)), dim3(256), 0, s, a, stride_samples, n_blocks, cos_mask, sin_mask, (float2*)out);
+}
+void launch_iq_to_complex(const IqArgs& a, size_t stride_samples, size_t n_blocks, void* out, hipStream_t s) {
+    const size_t groups = n_blocks * 5000;
+    hipLaunchKernelGGL(k_iq_to_complex, dim3((unsigned)((groups + 255) / 256)), dim3(256), 0, s, a, stride_samples, n_blocks, (float2*)out);
 }
 
 void launch_iq_sums(const uint8_t* iq, size_t n_samples, int is_signed, unsigned long long* sums, hipStream_t s) {

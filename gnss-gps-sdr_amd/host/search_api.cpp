@@ -25,6 +25,9 @@
 //   GPSACQ_IQ_KEEP_DC=1     IQ input: skip `y = y - mean(y)` (the scripts always remove it)
 //   GPSACQ_IQ_MULTIBIT=1    IQ input: keep the samples' amplitude instead of their sign (no reference counterpart: gps_test reads
 //                           1-bit files only); spares the 1-bit quantisation loss
+//   GPSACQ_IQ_COMPLEX=1     IQ input: the capture is at baseband already, I + jQ being what Sample() puts in fwd_buf -- the int8
+//                           file c/conv_1bit_bin_to_hackrf_bin.cpp writes (GPSACQ_INPUT=iq_s8 GPSACQ_IQ_KEEP_DC=1): transformed as it
+//                           is, no LO; FC is not used and GPSACQ_MIX_HZ, if set, turns the samples by that frequency first
 //   GPSACQ_TRACE=1          wall-clock split of SearchInit / SearchTask on stderr
 #include <chrono>
 #include <cstdio>
@@ -175,7 +178,7 @@ void SearchTask(char *filename_1bit_bin) {
         iqin.mix_hz = (mix && *mix) ? atof(mix) : 0.0;
         iqin.fs = FS;
         iqin.remove_dc = env_int("GPSACQ_IQ_KEEP_DC", 0) ? 0 : 1;
-        iqin.multibit = env_int("GPSACQ_IQ_MULTIBIT", 0) ? 1 : 0;
+        iqin.multibit = env_int("GPSACQ_IQ_COMPLEX", 0) ? GPSACQ_SAMPLES_COMPLEX : env_int("GPSACQ_IQ_MULTIBIT", 0) ? GPSACQ_SAMPLES_REAL : GPSACQ_SAMPLES_SIGN;
     }
     const size_t block_bytes = iq ? (size_t)GPSACQ_BLOCK_BYTES * 16 : (size_t)GPSACQ_BLOCK_BYTES;  // one Sample(): 40960 samples
     const size_t run_bytes = (size_t)GPSACQ_NUM_SATS * block_bytes;

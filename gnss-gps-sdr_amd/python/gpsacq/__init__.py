@@ -297,7 +297,7 @@ class Engine:
     @staticmethod
     def iq8_input(signed=False, remove_dc=True, mean=(0.0, 0.0), mix_hz=0.0, fs=0.0, first_sample=0, total_samples=0, multibit=False):
         return Iq8Input(1 if signed else 0, 1 if remove_dc else 0, float(mean[0]), float(mean[1]), float(mix_hz), float(fs),
-                        int(first_sample), int(total_samples), 1 if multibit else 0, 0)
+                        int(first_sample), int(total_samples), int(multibit), 0)  # multibit: False/0 sign, True/1 real IF, 2 complex baseband
 
     def iq8_mean(self, iq, signed=False, chunk_samples=1 << 22):
         """Complex mean of a whole 8-bit IQ capture as (mean_i, mean_q): exact integer sums on the device, in pieces."""

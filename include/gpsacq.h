@@ -251,6 +251,9 @@ GPSACQ_API int gpsacq_iq8_to_bits_device(gpsacq_engine* e, const void* d_iq, siz
  * first 40000 samples are transformed.  With ref_quirks the stream is converted to bits first (the patch needs samples
  * 40000..40959 as bits) -- same results, one more pass.
  */
+#define GPSACQ_SAMPLES_SIGN 0
+#define GPSACQ_SAMPLES_REAL 1
+#define GPSACQ_SAMPLES_COMPLEX 2
 typedef struct gpsacq_iq8_input {
     int32_t format;          /* GPSACQ_IQ_U8 / GPSACQ_IQ_S8 */
     int32_t remove_dc;       /* subtract (mean_i, mean_q) */
@@ -263,7 +266,12 @@ typedef struct gpsacq_iq8_input {
     int32_t multibit;        /* 0: the sign of each sample, as the scripts write it and gps_test reads it.  1: the samples keep their
                                 amplitude ("direct float path"; no reference counterpart -- gps_test only takes 1-bit files): the
                                 real-IF value as a float, the quadrature LO of Sample() (:143-153) applied as signs; spares the
-                                1-bit quantisation loss.  Whole-bin Doppler grid only, not with ref_quirks. */
+                                1-bit quantisation loss.  2 (GPSACQ_SAMPLES_COMPLEX): the capture is at baseband already -- I + jQ
+                                is what Sample() builds in fwd_buf (:149-150), e.g. the int8 +-30 file the reference's own
+                                c/conv_1bit_bin_to_hackrf_bin.cpp:61-80 writes for HackRF replay -- so no LO: the complex samples
+                                (less the mean, turned by exp(2 pi i mix_hz n / fs) when a residual IF is named) are transformed
+                                as they are; the engine's fc plays no part.  1 and 2: whole-bin Doppler grid only, not with
+                                ref_quirks. */
     int32_t reserved;
 } gpsacq_iq8_input;
 GPSACQ_API int gpsacq_search_iq8(gpsacq_engine* e, const gpsacq_iq8_input* in, const void* iq, size_t n_blocks, size_t stride,

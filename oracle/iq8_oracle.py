@@ -57,6 +57,46 @@ def multibit_cells(r_block, lo_quadrant, code_replica, dmax, n_lags):
     lo_cos = np.array([0, 1, 1, 0])
     x = r_block[:N].astype(np.float64)
     x = x * (1.0 - 2.0 * lo_cos[lo_quadrant[:N]]) + 1j * x * (1.0 - 2.0 * lo_sin[lo_quadrant[:N]])
+    return complex_cells(x, code_replica, dmax, n_lags)
+
+
+def iq8_to_complex(raw, signed=False, remove_dc=True, mix_hz=0.0, fs=2.8e6):
+    """The complex sample itself (gpsacq_iq8_input.multibit = 2: the capture is at baseband already): (y - mean(y)) turned by
+    exp(i theta), theta as in iq8_to_bits; complex64 like the device buffer."""
+    raw = np.asarray(raw).view(np.uint8).ravel()
+    y = raw.view(np.int8).astype(np.float64) if signed else raw.astype(np.float64) - 128.0
+    y = y[0::2] + 1j * y[1::2]
+    if remove_dc:
+        y = y - np.mean(y)
+    if mix_hz != 0.0:
+        n = np.arange(y.size, dtype=np.float64)
+        theta = (((2.0 * np.pi) * mix_hz) * n) * (1.0 / fs)
+        cs, sn = np.cos(theta), np.sin(theta)
+        y = (y.real * cs - y.imag * sn) + 1j * (y.real * sn + y.imag * cs)
+    return y.astype(np.complex64)
+
+
+def hackrf_replay_file(bits, lo_quadrant):
+    """c/conv_1bit_bin_to_hackrf_bin.cpp:18-20,30-31,61-80 restated: every 1-bit sample (LSB first) XOR-mixed with the converter's
+    OWN quadrature tables lo_sin = {1,1,0,0}, lo_cos = {1,0,0,1} (not Sample()'s: there lo_cos = {0,1,1,0} and the components are
+    swapped, search_offline.cpp:124-125,149-150 -- together a turn of the whole stream by +j, which no power notices), Bipolar = -30
+    for 1, +30 for 0, written I then Q as int8.  lo_quadrant: int(lo_phase) per sample of the WHOLE stream (the converter's NCO
+    runs on across blocks; oracle_lo_quadrants() with n = all samples).  The converter only handles whole 55.8 MB reads (:26,55-58);
+    this is its inner loop on a stream of any length."""
+    lo_sin = np.array([1, 1, 0, 0], dtype=np.uint8)
+    lo_cos = np.array([1, 0, 0, 1], dtype=np.uint8)
+    b = np.unpackbits(np.asarray(bits, dtype=np.uint8), bitorder="little")
+    q = np.asarray(lo_quadrant)[:b.size]
+    out = np.empty(2 * b.size, dtype=np.int8)
+    out[0::2] = np.where(b ^ lo_sin[q], -30, 30)
+    out[1::2] = np.where(b ^ lo_cos[q], -30, 30)
+    return out
+
+
+def complex_cells(x, code_replica, dmax, n_lags):
+    """Correlate() (c/search_offline.cpp:169-201) on 40000 complex samples (what Sample() would have left in fwd_buf), float64."""
+    N = 40000
+    x = np.asarray(x[:N], dtype=np.complex128)
     D = np.fft.fft(x)
     C = np.fft.fft(np.asarray(code_replica, dtype=np.float64))
     mp, mi, tp = [], [], []

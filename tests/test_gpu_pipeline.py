@@ -184,6 +184,29 @@ def test_cli_iq8_input_equals_preconverted_1bit(tmp_path):
     assert m.returncode == 0 and m.stdout.count("satellite:") == 2 and "    4 " in m.stdout[len(BANNER):].split("\n")[0]
 
 
+def test_cli_searches_the_converters_hackrf_file_like_the_1bit_capture(golden_dir, tmp_path):
+    """The reference has two files for one capture: the 1-bit stream gps_test reads and the int8 IQ file
+    c/conv_1bit_bin_to_hackrf_bin.cpp makes of it for HackRF replay (already mixed to baseband by the same XOR LO).
+    GPSACQ_INPUT=iq_s8 GPSACQ_IQ_COMPLEX=1 searches the second directly: same report as the first, all 12 runs."""
+    from test_host import GPS_TEST
+    from oracle_lib import lib, _p
+    sys.path.insert(0, os.path.join(ROOT, "oracle"))
+    from iq8_oracle import hackrf_replay_file
+    path = os.path.join(golden_dir, "gps_sig_tmp.bin")
+    fc, fs = 2.046e6, 8.184e6
+    bits = np.fromfile(path, dtype=np.uint8)
+    quad = np.zeros(bits.size * 8, np.uint8)
+    lib().oracle_lo_quadrants(fc, fs, quad.size, _p(quad))
+    f_iq = str(tmp_path / "replay_s8.bin")
+    hackrf_replay_file(bits, quad).tofile(f_iq)
+    args = ["2.046e6", "8.184e6", "5000"]
+    a = subprocess.run([GPS_TEST, path] + args, capture_output=True, text=True, timeout=300)
+    b = subprocess.run([GPS_TEST, f_iq] + args, capture_output=True, text=True, timeout=300,
+                       env=dict(os.environ, GPSACQ_INPUT="iq_s8", GPSACQ_IQ_COMPLEX="1", GPSACQ_IQ_KEEP_DC="1"))
+    assert a.returncode == 0 and b.returncode == 0, a.stderr + b.stderr
+    assert a.stdout.count("satellite:") == 12 and a.stdout == b.stdout
+
+
 def test_cli_streams_batches_of_growing_size(golden_dir):
     """The front end's output does not depend on how the file is cut into batches (1, 2, 4 ... runs; capped)."""
     from test_host import GPS_TEST

@@ -9,6 +9,8 @@ import pytest
 
 from oracle_lib import Oracle, lib, _p
 
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
 
 def test_dft_matches_numpy():
     L = lib("f64")
@@ -151,3 +153,24 @@ def test_f32_port_close_to_f64(golden_dir):
     cb, pb = b.search_block(buf[20 * 5120:21 * 5120], 20)
     np.testing.assert_allclose(ca["max_pwr"], cb["max_pwr"], rtol=2e-4)
     assert pa["ca_shift"] == pb["ca_shift"] and pa["lo_shift"] == pb["lo_shift"]
+
+
+@pytest.mark.parametrize("real", ["double", "float"])
+def test_oracle_is_clean_under_asan_and_ubsan(golden_dir, tmp_path, real):
+    """the reference overruns fwd_buf (c/search_offline.cpp:135-157); the restatement emulates that
+    explicitly and is itself free of it.  tests/c/oracle_san.c walks every entry point of oracle/gpsacq_oracle.c (both quirk
+    modes, a short and a missing file, a report buffer that is too small) under -fsanitize=address,undefined."""
+    import shutil
+    import subprocess
+    if not shutil.which("gcc"):
+        pytest.skip("no gcc")
+    exe = str(tmp_path / "oracle_san")
+    cmd = ["gcc", "-O1", "-g", "-std=c11", "-fsanitize=address,undefined", "-fno-sanitize-recover=undefined",
+           "-DORACLE_REAL=" + real] + (["-fopenmp"] if real == "float" else []) + ["-o", exe, os.path.join(ROOT, "tests", "c", "oracle_san.c"), "-lm"]
+    b = subprocess.run(cmd, capture_output=True, text=True)
+    if b.returncode != 0 and "sanitize" in b.stderr + b.stdout and ("cannot find" in b.stderr or "not supported" in b.stderr):
+        pytest.skip("sanitizer runtime not installed")
+    assert b.returncode == 0, b.stderr
+    r = subprocess.run([exe, os.path.join(golden_dir, "gps_sig_tmp.bin"), "2.046e6", "8.184e6"], capture_output=True, text=True, timeout=300,
+                       env=dict(os.environ, ASAN_OPTIONS="detect_leaks=1", UBSAN_OPTIONS="print_stacktrace=1"))
+    assert r.returncode == 0 and "oracle_san: ok" in r.stdout, r.stdout + r.stderr
