@@ -506,7 +506,6 @@ static int search_core(gpsacq_engine* e, const Capture& cap_in, size_t n_blocks,
         if (((uintptr_t)cap.d_src & 15) != 0) return fail(GPSACQ_ERR_ARG, "IQ buffer must be 16-byte aligned");
         if (cap.multibit) {
             if (e->p.ref_quirks) return fail(GPSACQ_ERR_UNSUPPORTED, "ref_quirks is defined for the reference's 1-bit samples only");
-            if (e->sub > 1) return fail(GPSACQ_ERR_UNSUPPORTED, "the multi-bit sample path searches the whole-bin Doppler grid (gpsacq_set_doppler_step finer than a bin is 1-bit only)");
         }
         if (e->p.ref_quirks) {
             // the quirk patch reads the 960 samples past each block from a 1-bit stream: convert first (same arithmetic,
@@ -546,17 +545,18 @@ static int search_core(gpsacq_engine* e, const Capture& cap_in, size_t n_blocks,
         const size_t avail = cap.iq_total > cap.iq_first ? cap.iq_total - cap.iq_first : 0;
         const size_t n_samples = std::min(want, avail);
         if (n_samples < want) return fail(GPSACQ_ERR_ARG, "multi-bit path: the capture ends inside the batch (%zu of %zu samples)", n_samples, want);
-        if (int rc = grow(e->d_fsamp, e->fsamp_cap, n_blocks * (size_t)N_FFT * 2, e->stream)) return rc;  // [block][40000] complex
+        if (int rc = grow(e->d_fsamp, e->fsamp_cap, n_blocks * (size_t)e->sub * N_FFT * 2, e->stream)) return rc;  // [block][sub-bin copy][40000] complex
         IqArgs ia{};
         ia.iq = cap.d_src;
         ia.bits = nullptr;
         ia.n_samples = n_samples;
         ia.first_sample = cap.iq_first;
         ia.conv = cap.iq;
-        if (cap.multibit == 2) launch_iq_to_complex(ia, stride / 2, n_blocks, e->d_fsamp, e->stream);
-        else launch_iq_to_mixed(ia, stride / 2, n_blocks, e->d_cos, e->d_sin, e->d_fsamp, e->stream);
+        if (cap.multibit == 2) launch_iq_to_complex(ia, stride / 2, n_blocks, e->sub, e->d_fsamp, e->stream);
+        else launch_iq_to_mixed(ia, stride / 2, n_blocks, e->sub, e->d_cos, e->d_sin, e->d_fsamp, e->stream);
         HIPCHK(hipGetLastError());
-        if (int rc = run_forward(e, FWD_REALMIX, e->d_fsamp, N_FFT, n_blocks, e->d_dpp, (size_t)NPOLY * M_SUB, M_SUB, 0, true)) return rc;
+        // the sub-bin copies are sources of their own here (the turn is in the samples, not in the transform's twiddles)
+        if (int rc = run_forward(e, FWD_REALMIX, e->d_fsamp, N_FFT, n_blocks * (size_t)e->sub, e->d_dpp, (size_t)NPOLY * M_SUB, M_SUB, 0, true)) return rc;
     } else if (int rc = run_forward(e, cap.iq8 ? FWD_IQ8 : FWD_BITS, cap.d_src, stride, n_blocks, e->d_dpp, (size_t)NPOLY * M_SUB, M_SUB, 0, true, 0, &cap)) return rc;
     HIPCHK(hipEventRecord(ev[1], e->stream));
     // the block period in samples: what the code creeps over between accumulated blocks

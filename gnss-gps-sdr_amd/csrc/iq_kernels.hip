@@ -78,11 +78,26 @@ __global__ __launch_bounds__(256) void k_iq_to_bits(IqArgs a) {
 // same real-IF value kept as a float instead of its sign, with the quadrature LO of Sample() (:143-153) applied as signs
 // (I = +-x by lo_cos, Q = +-x by lo_sin; mask bit 1 <-> factor -1, like Bipolar(bit ^ lo); the LO phase restarts with every
 // block, :131).  One thread per 8 samples; out[block][40000] complex.
-__global__ __launch_bounds__(256) void k_iq_to_mixed(IqArgs a, size_t stride_samples, size_t n_blocks, const uint8_t* __restrict__ cos_mask,
+// sub > 1 (Doppler grid finer than a bin, gpsacq_set_doppler_step): every block is written sub times, copy r turned by
+// exp(-2 pi i (r / sub) n / 40000) -- the carrier offset of r / sub bins that oracle_sample_ramped() applies to the mixed samples
+// (ramp in double, product rounded to float) -- in the order [block][r] of the block spectra.
+__device__ __forceinline__ float2 sub_bin_turn(double re, double im, int r, int sub, int n) {
+    if (r != 0) {
+        const double th = 6.283185307179586476925286766559 * ((double)r / (double)sub) * (double)n / 40000.0;
+        double sn, cs;
+        sincos(th, &sn, &cs);
+        const double a = re * cs + im * sn, b = im * cs - re * sn;
+        re = a;
+        im = b;
+    }
+    return make_float2((float)re, (float)im);
+}
+
+__global__ __launch_bounds__(256) void k_iq_to_mixed(IqArgs a, size_t stride_samples, size_t n_blocks, int sub, const uint8_t* __restrict__ cos_mask,
                                                      const uint8_t* __restrict__ sin_mask, float2* __restrict__ out) {
-    const size_t g = (size_t)blockIdx.x * blockDim.x + threadIdx.x;  // group of 8 samples inside a block: 5000 groups per block
-    const size_t blk = g / 5000;
-    const int grp = (int)(g - blk * 5000);
+    const size_t g = (size_t)blockIdx.x * blockDim.x + threadIdx.x;  // group of 8 samples inside a copy of a block: 5000 groups each
+    const size_t item = g / 5000, blk = item / (size_t)sub;
+    const int grp = (int)(g - item * 5000), r = (int)(item - blk * (size_t)sub);
     if (blk >= n_blocks) return;
     const size_t s0 = blk * stride_samples + (size_t)grp * 8;  // sample index inside the batch (stride_samples is a multiple of 8)
     unsigned raw[4] = {0, 0, 0, 0};
@@ -93,18 +108,18 @@ __global__ __launch_bounds__(256) void k_iq_to_mixed(IqArgs a, size_t stride_sam
     const unsigned cm = cos_mask[grp], sm = sin_mask[grp];
 #pragma unroll
     for (int k = 0; k < 8; ++k) {
-        const float r = (s0 + k < a.n_samples) ? (float)iq8_value((raw[k >> 1] >> (16 * (k & 1))) & 0xffffu, a.first_sample + s0 + k, a.conv) : 0.f;
-        out[blk * 40000 + (size_t)grp * 8 + k] = make_float2(((cm >> k) & 1u) ? -r : r, ((sm >> k) & 1u) ? -r : r);
+        const float v = (s0 + k < a.n_samples) ? (float)iq8_value((raw[k >> 1] >> (16 * (k & 1))) & 0xffffu, a.first_sample + s0 + k, a.conv) : 0.f;
+        out[item * 40000 + (size_t)grp * 8 + k] = sub_bin_turn(((cm >> k) & 1u) ? -(double)v : (double)v, ((sm >> k) & 1u) ? -(double)v : (double)v, r, sub, grp * 8 + k);
     }
 }
 // complex-baseband path: the capture already is what Sample() builds in fwd_buf -- I + jQ at IF 0, e.g. the int8 +-30 file the
 // reference's own converter writes for HackRF replay (c/conv_1bit_bin_to_hackrf_bin.cpp:61-80: I = Bipolar(bit ^ lo_sin),
 // Q = Bipolar(bit ^ lo_cos), the two components of fwd_buf, :149-150 of search_offline.cpp) -- so no LO here: the samples
 // (less their mean, turned by exp(i theta) when a residual IF is named) go to the forward transform as they are.
-__global__ __launch_bounds__(256) void k_iq_to_complex(IqArgs a, size_t stride_samples, size_t n_blocks, float2* __restrict__ out) {
+__global__ __launch_bounds__(256) void k_iq_to_complex(IqArgs a, size_t stride_samples, size_t n_blocks, int sub, float2* __restrict__ out) {
     const size_t g = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-    const size_t blk = g / 5000;
-    const int grp = (int)(g - blk * 5000);
+    const size_t item = g / 5000, blk = item / (size_t)sub;
+    const int grp = (int)(g - item * 5000), r = (int)(item - blk * (size_t)sub);
     if (blk >= n_blocks) return;
     const size_t s0 = blk * stride_samples + (size_t)grp * 8;
     unsigned raw[4] = {0, 0, 0, 0};
@@ -116,16 +131,17 @@ __global__ __launch_bounds__(256) void k_iq_to_complex(IqArgs a, size_t stride_s
     for (int k = 0; k < 8; ++k) {
         double re = 0.0, im = 0.0;
         if (s0 + k < a.n_samples) iq8_complex((raw[k >> 1] >> (16 * (k & 1))) & 0xffffu, a.first_sample + s0 + k, a.conv, re, im);
-        out[blk * 40000 + (size_t)grp * 8 + k] = make_float2((float)re, (float)im);
+        // the sample as the float buffer of the whole-bin path holds it, then the turn
+        out[item * 40000 + (size_t)grp * 8 + k] = sub_bin_turn((double)(float)re, (double)(float)im, r, sub, grp * 8 + k);
     }
 }
-void launch_iq_to_mixed(const IqArgs& a, size_t stride_samples, size_t n_blocks, const uint8_t* cos_mask, const uint8_t* sin_mask, void* out, hipStream_t s) {
-    const size_t groups = n_blocks * 5000;
-    hipLaunchKernelGGL(k_iq_to_mixed, dim3((unsigned)((groups + 255) / 256)), dim3(256), 0, s, a, stride_samples, n_blocks, cos_mask, sin_mask, (float2*)out);
+void launch_iq_to_mixed(const IqArgs& a, size_t stride_samples, size_t n_blocks, int sub, const uint8_t* cos_mask, const uint8_t* sin_mask, void* out, hipStream_t s) {
+    const size_t groups = n_blocks * (size_t)sub * 5000;
+    hipLaunchKernelGGL(k_iq_to_mixed, dim3((unsigned)((groups + 255) / 256)), dim3(256), 0, s, a, stride_samples, n_blocks, sub, cos_mask, sin_mask, (float2*)out);
 }
-void launch_iq_to_complex(const IqArgs& a, size_t stride_samples, size_t n_blocks, void* out, hipStream_t s) {
-    const size_t groups = n_blocks * 5000;
-    hipLaunchKernelGGL(k_iq_to_complex, dim3((unsigned)((groups + 255) / 256)), dim3(256), 0, s, a, stride_samples, n_blocks, (float2*)out);
+void launch_iq_to_complex(const IqArgs& a, size_t stride_samples, size_t n_blocks, int sub, void* out, hipStream_t s) {
+    const size_t groups = n_blocks * (size_t)sub * 5000;
+    hipLaunchKernelGGL(k_iq_to_complex, dim3((unsigned)((groups + 255) / 256)), dim3(256), 0, s, a, stride_samples, n_blocks, sub, (float2*)out);
 }
 
 void launch_iq_sums(const uint8_t* iq, size_t n_samples, int is_signed, unsigned long long* sums, hipStream_t s) {

@@ -19,7 +19,7 @@ struct IqArgs {
 void launch_iq_sums(const uint8_t* iq, size_t n_samples, int is_signed, unsigned long long* sums, hipStream_t s);
 void launch_iq_to_bits(const IqArgs& a, hipStream_t s);
 // multi-bit path: out[block][40000] complex floats, LO applied as signs (a.bits unused)
-void launch_iq_to_mixed(const IqArgs& a, size_t stride_samples, size_t n_blocks, const uint8_t* cos_mask, const uint8_t* sin_mask, void* out, hipStream_t s);
-void launch_iq_to_complex(const IqArgs& a, size_t stride_samples, size_t n_blocks, void* out, hipStream_t s);
+void launch_iq_to_mixed(const IqArgs& a, size_t stride_samples, size_t n_blocks, int sub, const uint8_t* cos_mask, const uint8_t* sin_mask, void* out, hipStream_t s);
+void launch_iq_to_complex(const IqArgs& a, size_t stride_samples, size_t n_blocks, int sub, void* out, hipStream_t s);
 
 }  // namespace acq

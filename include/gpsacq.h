@@ -270,8 +270,8 @@ typedef struct gpsacq_iq8_input {
                                 is what Sample() builds in fwd_buf (:149-150), e.g. the int8 +-30 file the reference's own
                                 c/conv_1bit_bin_to_hackrf_bin.cpp:61-80 writes for HackRF replay -- so no LO: the complex samples
                                 (less the mean, turned by exp(2 pi i mix_hz n / fs) when a residual IF is named) are transformed
-                                as they are; the engine's fc plays no part.  1 and 2: whole-bin Doppler grid only, not with
-                                ref_quirks. */
+                                as they are; the engine's fc plays no part.  1 and 2: not with ref_quirks; on a Doppler grid finer
+                                than a bin the sub-bin turn is applied to the float samples (one copy per sub-bin offset). */
     int32_t reserved;
 } gpsacq_iq8_input;
 GPSACQ_API int gpsacq_search_iq8(gpsacq_engine* e, const gpsacq_iq8_input* in, const void* iq, size_t n_blocks, size_t stride,

@@ -47,7 +47,7 @@ def iq8_to_real(raw, signed=False, remove_dc=True, mix_hz=0.0, fs=2.8e6):
     return r.astype(np.float32)
 
 
-def multibit_cells(r_block, lo_quadrant, code_replica, dmax, n_lags):
+def multibit_cells(r_block, lo_quadrant, code_replica, dmax, n_lags, eps=0.0, dops=None):
     """Correlate() (c/search_offline.cpp:169-201) on a block of multi-bit samples, float64 numpy: the LO of Sample() (:143-153)
     applied as signs (lo_cos = {0,1,1,0}, lo_sin = {1,1,0,0}; 1 <-> factor -1), then exactly the reference's search.
     r_block: >= 40000 float samples; lo_quadrant: int(lo_phase) per sample; code_replica: SearchInit's 40000 floats.
@@ -57,7 +57,23 @@ def multibit_cells(r_block, lo_quadrant, code_replica, dmax, n_lags):
     lo_cos = np.array([0, 1, 1, 0])
     x = r_block[:N].astype(np.float64)
     x = x * (1.0 - 2.0 * lo_cos[lo_quadrant[:N]]) + 1j * x * (1.0 - 2.0 * lo_sin[lo_quadrant[:N]])
-    return complex_cells(x, code_replica, dmax, n_lags)
+    return complex_cells(x, code_replica, dmax, n_lags, eps, dops)
+
+
+def multibit_pwr(r_block, lo_quadrant, code_replica, dmax, n_lags):
+    """The per-lag powers behind multibit_cells, [2 dmax + 1][n_lags] (what the non-coherent mode sums over blocks)."""
+    N = 40000
+    lo_sin = np.array([1, 1, 0, 0])
+    lo_cos = np.array([0, 1, 1, 0])
+    x = r_block[:N].astype(np.float64)
+    x = x * (1.0 - 2.0 * lo_cos[lo_quadrant[:N]]) + 1j * x * (1.0 - 2.0 * lo_sin[lo_quadrant[:N]])
+    D = np.fft.fft(x)
+    C = np.fft.fft(np.asarray(code_replica, dtype=np.float64))
+    out = np.empty((2 * dmax + 1, n_lags))
+    for d in range(-dmax, dmax + 1):
+        y = np.fft.ifft(np.conj(D) * np.roll(C, d)) * N
+        out[d + dmax] = y[:n_lags].real ** 2 + y[:n_lags].imag ** 2
+    return out
 
 
 def iq8_to_complex(raw, signed=False, remove_dc=True, mix_hz=0.0, fs=2.8e6):
@@ -93,14 +109,18 @@ def hackrf_replay_file(bits, lo_quadrant):
     return out
 
 
-def complex_cells(x, code_replica, dmax, n_lags):
-    """Correlate() (c/search_offline.cpp:169-201) on 40000 complex samples (what Sample() would have left in fwd_buf), float64."""
+def complex_cells(x, code_replica, dmax, n_lags, eps=0.0, dops=None):
+    """Correlate() (c/search_offline.cpp:169-201) on 40000 complex samples (what Sample() would have left in fwd_buf), float64.
+    eps: the samples (as floats) turned by exp(-2 pi i eps n / N) first, the sub-bin carrier offset of
+    gpsacq_oracle.c::oracle_sample_ramped (product rounded to float); dops: the whole-bin shifts to evaluate (default -dmax..dmax)."""
     N = 40000
-    x = np.asarray(x[:N], dtype=np.complex128)
+    x = np.asarray(x[:N], dtype=np.complex64).astype(np.complex128)
+    if eps != 0.0:
+        x = (x * np.exp(-2j * np.pi * eps * np.arange(N) / N)).astype(np.complex64).astype(np.complex128)
     D = np.fft.fft(x)
     C = np.fft.fft(np.asarray(code_replica, dtype=np.float64))
     mp, mi, tp = [], [], []
-    for d in range(-dmax, dmax + 1):
+    for d in (range(-dmax, dmax + 1) if dops is None else dops):
         y = np.fft.ifft(np.conj(D) * np.roll(C, d)) * N
         pwr = y[:n_lags].real ** 2 + y[:n_lags].imag ** 2
         mp.append(pwr.max())

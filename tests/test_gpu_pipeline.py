@@ -117,12 +117,12 @@ def test_multibit_samples_vs_numpy_restatement():
     against oracle/iq8_oracle.py's float64 restatement (LO applied as signs, then the reference's Correlate), and the point of
     the mode: PRN 5's SNR is higher than through the 1-bit path (no quantisation loss)."""
     import gpsacq
-    from iq8_oracle import iq8_to_real, multibit_cells
+    from iq8_oracle import iq8_to_real, multibit_cells, multibit_pwr
     sys.path.insert(0, os.path.join(ROOT, "tests", "golden"))
     from make_golden import lo_quadrants, code_replica
     iq = _iq_capture(3, seed=21)
     fc, fs = 0.62e6, 2.8e6
-    r = iq8_to_real(iq, remove_dc=True, mix_hz=fc, fs=fs)
+    r = r_ = iq8_to_real(iq, remove_dc=True, mix_hz=fc, fs=fs)
     quad = lo_quadrants(fc, fs, 40960)
     with gpsacq.Engine(fc, fs, 5000.0) as eng:
         mean = eng.iq8_mean(iq)
@@ -138,8 +138,38 @@ def test_multibit_samples_vs_numpy_restatement():
             assert (cells["max_i"][t] != mi).sum() <= 1
         assert peaks["snr"][0] > 25 and peaks["lo_shift"][0] == peaks1["lo_shift"][0] and peaks["ca_shift"][0] == peaks1["ca_shift"][0]
         assert peaks["snr"][0] > 1.1 * peaks1["snr"][0] and peaks["snr"][1] > 1.1 * peaks1["snr"][1]
-        # not with the reference quirk, not on a sub-bin Doppler grid
-        eng.set_doppler_step(20.0)
+        # a Doppler grid finer than a bin (70 Hz bins, 30 Hz asked -> 3 sub-bin copies of the float samples, 23.3 Hz): points against the
+        # restatement with the sub-bin turn of oracle_sample_ramped applied to the samples; whole-bin points equal the bin grid's cells
+        eng.set_doppler_step(30.0)
+        assert eng.doppler_sub == 3
+        K = eng.kmax
+        cg, pg = eng.search_iq8(iq, inp, tasks=tasks)
+        assert cg.shape == (3, 2 * K + 1)
+        ks = np.arange(-K, K + 1)
+        for t in range(3):
+            assert np.array_equal(cg[t][ks % 3 == 0], cells[t][ks[ks % 3 == 0] // 3 + eng.dmax])
+        for t, (b, sv) in enumerate(tasks[:2]):
+            for r in (1, 2):
+                pts = [k for k in (-K, -K + 1, -7, -5, -2, -1, 1, 2, 4, 8, K - 1, K) if k % 3 == r]
+                mp, mi, tp = multibit_cells(r_[b * 40960:], quad, code_replica(fs, sv), eng.dmax, eng.num_lags, eps=r / 3.0, dops=[(k - r) // 3 for k in pts])
+                got = cg[t][np.array(pts) + K]
+                np.testing.assert_allclose(got["max_pwr"], mp, rtol=2e-5)
+                np.testing.assert_allclose(got["tot_pwr"], tp, rtol=2e-5)
+                assert (got["max_i"] != mi).sum() <= 1
+            assert pg["snr"][t] >= peaks["snr"][t] and abs(pg["lo_shift"][t] / 3.0 - peaks["lo_shift"][t]) <= 1.0 and pg["ca_shift"][t] == peaks["ca_shift"][t]
+        eng.set_doppler_step(0.0)
+        # non-coherent accumulation over the float samples: two blocks' powers summed (plain sum: creep re-alignment off)
+        eng.set_noncoherent(2, 1)
+        eng.set_creep_compensation(False)
+        ca, pa = eng.search_iq8(iq, inp, tasks=[(0, 4)])
+        acc = [multibit_pwr(r_[b * 40960:], quad, code_replica(fs, 4), eng.dmax, eng.num_lags) for b in (0, 1)]
+        pw = acc[0] + acc[1]
+        np.testing.assert_allclose(ca["max_pwr"][0], pw.max(axis=1), rtol=2e-5)
+        np.testing.assert_allclose(ca["tot_pwr"][0], pw.sum(axis=1), rtol=2e-5)
+        assert (ca["max_i"][0] != pw.argmax(axis=1)).sum() <= 1  # (the blocks are 40960 samples apart, not whole code periods: parity only)
+        eng.set_noncoherent(1, 1)
+    # not with the reference quirk
+    with gpsacq.Engine(fc, fs, 5000.0, ref_quirks=True) as eng:
         with pytest.raises(gpsacq.GpsAcqError):
             eng.search_iq8(iq, inp, tasks=tasks)
 

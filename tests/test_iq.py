@@ -147,6 +147,17 @@ def test_complex_baseband_search_of_the_converters_file_equals_the_1bit_search(g
             assert peaks["lo_shift"][t] == p1["lo_shift"][t] and peaks["ca_shift"][t] == p1["ca_shift"][t] and peaks["snr"][t] > 25
         with pytest.raises(gpsacq.GpsAcqError):
             eng.search_iq8(iq2, eng.iq8_input(signed=True, multibit=3))
+        # the complex path on a Doppler grid finer than a bin: again 900 x the 1-bit search of the same grid (whose sub-bin turn is
+        # in the transform's twiddles; here it is applied to the samples)
+        eng.set_doppler_step(80.0)
+        assert eng.doppler_sub == 3
+        inp = eng.iq8_input(signed=True, remove_dc=False, total_samples=iq.size // 2, multibit=2)
+        cg, pg = eng.search_iq8(iq, inp, tasks=[(0, 7), (1, 3)])
+        cb, pb = eng.search(bits, tasks=[(0, 7), (1, 3)])
+        np.testing.assert_allclose(cg["max_pwr"] / 900.0, cb["max_pwr"], rtol=5e-6)
+        np.testing.assert_allclose(cg["tot_pwr"] / 900.0, cb["tot_pwr"], rtol=5e-6)
+        assert (cg["max_i"] != cb["max_i"]).sum() <= 1
+        assert pg["lo_shift"][0] == pb["lo_shift"][0] and pg["ca_shift"][0] == pb["ca_shift"][0]
 
 
 @pytest.mark.gpu
