@@ -204,6 +204,25 @@ __device__ __forceinline__ void wave_reduce_peak(float& mx, int& mi, float& sum)
     }
 #endif
 }
+// Non-coherent mode, creep re-alignment, more lags than one pass covers (fs > 10 MHz): a lag's re-aligned destination can lie in
+// another pass's column window, so the per-lag sums live in device memory instead of this pass's LDS array.  One writer per
+// (cell, lag, block); the hardware float add at L2 keeps the read-modify-writes of different waves coherent.
+template <int MC>
+__device__ __forceinline__ void corr_dump_power(int tid, int rho, int S, int m0, int shift, cf* acc, float* __restrict__ cell_pwr) {
+    if (tid >= NBF3) return;
+    int sh = shift % S;
+    if (sh < 0) sh += S;
+#pragma unroll
+    for (int m = 0; m < MC; ++m) {
+        const int n = NBF3 * (m0 + m) + rho;
+        if (n < S) {
+            int j = n - sh;
+            if (j < 0) j += S;
+            unsafeAtomicAdd(cell_pwr + j, acc[m].x * acc[m].x + acc[m].y * acc[m].y);
+        }
+        acc[m] = mk(0.f, 0.f);
+    }
+}
 template <class L> __device__ __forceinline__ int corr_rho(const CorrArgs& a, int t3) {
     if constexpr (L::REMAP) return (int)a.rho_map[t3];
     else return pass3_rho<L>(t3);
@@ -297,9 +316,12 @@ __global__ __launch_bounds__(WG, WPS) void k_corr(CorrArgs a) {
         else if (NC) {
             // every lag has one owner per block, so the scatter needs no atomics; successive blocks'
             // updates are separated by the barriers of the next 8 sub-transforms
-            corr_accumulate_power<MC>(tid, rho, a.nlags, a.m0, __float2int_rn((float)k * a.creep * (float)(di + a.dop_first)), acc, pws);
+            const int shift = __float2int_rn((float)k * a.creep * (float)(di + a.dop_first));
+            if (a.pdump) corr_dump_power<MC>(tid, rho, a.nlags, a.m0, shift, acc, a.pdump + ((size_t)task * a.ndop + di) * a.nlags);
+            else corr_accumulate_power<MC>(tid, rho, a.nlags, a.m0, shift, acc, pws);
         }
     }
+    if (NC && !NCREG && a.pdump) return;  // this pass's powers are in a.pdump; launch_scan_power makes the cells
 
     float mx, sum;
     int mi;
@@ -440,6 +462,42 @@ __global__ void k_merge_cells(const Cell* parts, Cell* cells, size_t n_cells, in
     cells[i] = c;
 }
 
+// The reference's scan (:190-196) over a cell's per-lag power sums in device memory (corr_dump_power): one workgroup per cell,
+// thread t scans lags t, t + 256, ... ascending with a strict '>', the partial results merge with "higher power, ties to the
+// lower lag" -- the first maximum, like the serial scan.
+__global__ __launch_bounds__(256) void k_scan_power(const float* __restrict__ pdump, Cell* cells, int nlags) {
+    const float* p = pdump + (size_t)blockIdx.x * nlags;
+    float mx = 0.f, sum = 0.f;
+    int mi = 0;
+    for (int n = threadIdx.x; n < nlags; n += 256) {
+        const float v = p[n];
+        if (v > mx) { mx = v; mi = n; }
+        sum += v;
+    }
+    wave_reduce_peak(mx, mi, sum);
+    __shared__ float red[4 * 4];
+    const int wave = threadIdx.x >> 6;
+    if ((threadIdx.x & 63) == 0) {
+        red[wave * 4 + 0] = mx;
+        red[wave * 4 + 1] = __int_as_float(mi);
+        red[wave * 4 + 2] = sum;
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        for (int w = 1; w < 4; ++w) {
+            peak_merge(mx, mi, red[w * 4 + 0], __float_as_int(red[w * 4 + 1]));
+            sum += red[w * 4 + 2];
+        }
+        Cell c;
+        c.max_pwr = mx;
+        c.max_i = mi;
+        c.tot_pwr = sum;
+        const float ave = sum / (float)nlags;
+        c.snr = (sum > 0.f) ? mx / ave : 0.f;
+        cells[blockIdx.x] = c;
+    }
+}
+
 // Best SNR over the Doppler bins of each task: the reference scans dop ascending with a strict '>'
 // (:196-198), i.e. the largest SNR wins and ties go to the lowest bin.  One wavefront per task: lane l
 // scans bins l, l + 64, ... (ascending, strict '>'), then the lanes merge with the same rule.
@@ -567,6 +625,9 @@ int launch_corr8(const CorrArgs& a, int mc8, int wgs_per_cu, hipStream_t s) {
     }
 #undef K8
     return 0;
+}
+void launch_scan_power(const float* pdump, Cell* cells, size_t n_cells, int nlags, hipStream_t s) {
+    hipLaunchKernelGGL(k_scan_power, dim3((unsigned)n_cells), dim3(256), 0, s, pdump, cells, nlags);
 }
 void launch_merge_cells(const Cell* parts, Cell* cells, size_t n_cells, int n_parts, int nlags, hipStream_t s) {
     hipLaunchKernelGGL(k_merge_cells, dim3((unsigned)((n_cells + 255) / 256)), dim3(256), 0, s, parts, cells, n_cells, n_parts, nlags);

@@ -55,6 +55,8 @@ struct CorrArgs {
     int n_spec, n_code;   // rows of dpp / cpp: tasks pointing outside get an empty cell (max_i = -1)
     int sub, dstride;     // Doppler grid (acq_phases.hpp grid_point): dop_first/ndop count grid points; spectrum of (block, r) at row block*sub + r
     const cf *t1_8, *t2_8, *t3_8, *bq8;  // tables of the 8-wave correlator (acq_corr8.hpp, Tables8)
+    float* pdump;      // non-coherent mode with creep re-alignment over several column passes (fs > 10 MHz): per-lag power sums in
+                       // device memory, [n_tasks * ndop][nlags], zeroed by the caller; the cells then come from launch_scan_power.  Else NULL
     unsigned long long* prof;  // k_corr<..., PROF>: [1024][16] accumulated s_memtime deltas per segment (bucket = workgroup % 1024) (GPSACQ_PROF=1 diagnostic), else NULL
 };
 
@@ -73,6 +75,7 @@ int launch_corr(const CorrArgs& a, int mc, hipStream_t s);
 int corr8_columns(int nlags);  // accumulator columns of the smallest k_corr8 instance that covers nlags, 0 if none
 int launch_corr8(const CorrArgs& a, int mc8, int wgs_per_cu, hipStream_t s);
 hipError_t upload_wq8(const cf* host);
+void launch_scan_power(const float* pdump, Cell* cells, size_t n_cells, int nlags, hipStream_t s);
 void launch_merge_cells(const Cell* parts, Cell* cells, size_t n_cells, int n_parts, int nlags, hipStream_t s);
 void launch_pack_keys(const Peak* peaks, unsigned long long* keys, int n, int kmax, hipStream_t s);
 void launch_prn_best(const unsigned long long* keys, const Peak* peaks, int n_tasks, unsigned long long* best, float* best_pwr, hipStream_t s);

@@ -92,6 +92,8 @@ struct gpsacq_engine {
     size_t iq_cap = 0;
     uint8_t* d_iqbits = nullptr;
     size_t iqbits_cap = 0;
+    float* d_pdump = nullptr;  // non-coherent + creep re-alignment at fs > 10 MHz: per-lag power sums, [cell][nlags]
+    size_t pdump_cap = 0;
     float* d_fsamp = nullptr;  // multi-bit path: the batch's samples as complex floats, LO applied ([block][40000][2])
     size_t fsamp_cap = 0;
     unsigned long long* d_sums = nullptr;
@@ -210,7 +212,7 @@ extern "C" void gpsacq_destroy(gpsacq_engine* e) {
     if (!e) return;
     (void)hipSetDevice(e->p.device);
     if (e->stream) (void)hipStreamSynchronize(e->stream);
-    void* bufs[] = {e->d_t1, e->d_t2, e->d_bq, e->d_tn, e->d_rho, e->d_t1_8, e->d_t2_8, e->d_t3_8, e->d_bq8, e->d_cos, e->d_sin, e->d_cos_t, e->d_sin_t, e->d_code, e->d_patch_blocks, e->d_bits, e->d_iq, e->d_iqbits, e->d_fsamp, e->d_sums, e->d_sats, e->d_gen, e->d_prof, e->d_rot8,
+    void* bufs[] = {e->d_t1, e->d_t2, e->d_bq, e->d_tn, e->d_rho, e->d_t1_8, e->d_t2_8, e->d_t3_8, e->d_bq8, e->d_cos, e->d_sin, e->d_cos_t, e->d_sin_t, e->d_code, e->d_patch_blocks, e->d_bits, e->d_iq, e->d_iqbits, e->d_fsamp, e->d_pdump, e->d_sums, e->d_sats, e->d_gen, e->d_prof, e->d_rot8,
                     e->d_dpp, e->d_parts, e->d_tasks, e->d_cells, e->d_peaks};
     for (void* b : bufs)
         if (b) (void)hipFree(b);
@@ -603,6 +605,19 @@ static int search_core(gpsacq_engine* e, const Capture& cap_in, size_t n_blocks,
         if (e->corr8 >= 2 && e->n_acc == 1 && mc8 > 0) {
             if (launch_corr8(ca, mc8, e->corr8, e->stream) != 0) return fail(GPSACQ_ERR_UNSUPPORTED, "no 8-wave correlate kernel for %d columns", mc8);
         } else if (launch_corr(ca, e->mc, e->stream) != 0) return fail(GPSACQ_ERR_UNSUPPORTED, "no correlate kernel for %d columns", e->mc);
+    } else if (e->creep_comp && e->n_acc > 1) {
+        // re-aligned lags cross the passes' column windows: the per-lag sums of every cell go to device memory (nlags floats per
+        // cell), every pass adds its window's powers at their re-aligned lags, one scan per cell at the end
+        const size_t n_cells = n_tasks * (size_t)e->ndop;
+        if (int rc = grow(e->d_pdump, e->pdump_cap, n_cells * (size_t)e->nlags, e->stream)) return rc;
+        HIPCHK(hipMemsetAsync(e->d_pdump, 0, n_cells * (size_t)e->nlags * sizeof(float), e->stream));
+        ca.creep = (float)((double)e->acc_step * block_samples * (e->p.fs / N_FFT * e->dstride / e->sub) / 1575.42e6);
+        ca.pdump = e->d_pdump;
+        for (int p = 0; p < n_pass; ++p) {
+            ca.m0 = p * MC_MAX;
+            if (launch_corr(ca, MC_MAX, e->stream) != 0) return fail(GPSACQ_ERR_UNSUPPORTED, "no correlate kernel for %d columns", MC_MAX);
+        }
+        launch_scan_power(e->d_pdump, d_cells, n_cells, e->nlags, e->stream);
     } else {
         const size_t n_cells = n_tasks * (size_t)e->ndop;
         if (int rc = grow(e->d_parts, e->parts_cap, n_cells * (size_t)n_pass, e->stream)) return rc;

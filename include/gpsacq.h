@@ -211,8 +211,8 @@ GPSACQ_API int gpsacq_set_noncoherent(gpsacq_engine* e, int n_acc, int block_ste
  * accumulated blocks = block_step * stride * 8): 1.07 samples per block at 40 kHz and fs = 2.8 MHz.
  * With compensation on, block k's powers are moved back by round(k * c * bin) whole samples (modulo
  * the fs/1000 lags) before they are summed, c = T * (fs/40000) / 1575.42e6 in float, bin = the cell's
- * Doppler bin; ca_shift then refers to block 0.  Ignored (plain sum) when fs > 10 MHz (more than
- * 10000 lags are searched in several passes).
+ * Doppler bin; ca_shift then refers to block 0.  At fs > 10 MHz (more than 10000 lags, searched in
+ * several passes of 40 columns) the per-lag sums are kept in device memory -- 4 * fs/1000 bytes per cell of the batch.
  */
 GPSACQ_API int gpsacq_set_creep_compensation(gpsacq_engine* e, int on);
 GPSACQ_API int gpsacq_aligned_stride(const gpsacq_engine* e);

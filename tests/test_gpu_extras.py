@@ -320,6 +320,47 @@ def test_noncoherent_creep_compensation():
         assert np.array_equal(a, b)
 
 
+def test_noncoherent_creep_compensation_beyond_10000_lags():
+    """fs = 16.368 MHz: 16 368 lags are searched in two passes of 40 columns, and a lag's re-aligned destination can lie in the
+    other pass's window -- the per-lag sums then live in device memory (k_corr's corr_dump_power + k_scan_power).  A satellite at
+    a large carrier offset lines up over five blocks; compensated sums against the oracle's restatement, including the bins whose
+    shift wraps around the code period; tot_pwr is a permutation of the uncompensated search's."""
+    import gpsacq
+    from oracle_lib import Oracle
+    fc, fs = 4.092e6, 16.368e6
+    with gpsacq.Engine(fc, fs, 100000.0) as eng:
+        stride = eng.aligned_stride()
+        assert stride == 6138 and eng.num_lags == 16368  # three code periods of 2046 bytes
+        bin_hz = fs / 40000
+        fd = 215 * bin_hz  # 87.98 kHz: the code creeps 2.7 samples per accumulated block of 49 104 samples
+        bits = eng.generate(5 * stride + 5120, [(9, 0.075, fd, 9990.3, 0.3)], noise_sigma=1.0, seed=7)
+        eng.set_doppler_window(190, 50)
+        eng.set_noncoherent(5, 1)
+        tasks = [(0, 8), (0, 30)]
+        c_off, p_off = eng.search(bits, tasks=tasks, stride=stride)
+        eng.set_creep_compensation(True)
+        c_on, p_on = eng.search(bits, tasks=tasks, stride=stride)
+        assert eng.last_timing()["correlate_launches"] == 2
+        assert int(p_on["lo_shift"][0]) == 215 and abs(int(p_on["ca_shift"][0]) - 9990) <= 1  # next to the 10000-lag pass boundary
+        # (a chip is 16 samples wide here: the 11 samples crept over the five blocks cost less than at 2.8 MHz)
+        assert p_on["snr"][0] > 1.1 * p_off["snr"][0], (p_on["snr"], p_off["snr"])
+        assert p_on["snr"][0] > 2.0 * p_on["snr"][1]
+        assert np.allclose(c_on["tot_pwr"], c_off["tot_pwr"], rtol=1e-5)
+        orc = Oracle(fc, fs, 100000.0)
+        want = orc.search_noncoherent(bits, stride, 0, 8, 5, 1, first_bin=205, n_bins=20, creep=True)
+        got = c_on[0][15:35]
+        np.testing.assert_allclose(got["max_pwr"], want["max_pwr"], rtol=2e-5)
+        np.testing.assert_allclose(got["tot_pwr"], want["tot_pwr"], rtol=2e-5)
+        assert (got["max_i"] != want["max_i"]).sum() <= 1
+        # negative offsets: the shift has the other sign and wraps below lag 0
+        eng.set_doppler_window(-230, 12)
+        c_neg, _ = eng.search(bits, tasks=[(0, 30)], stride=stride)
+        want = orc.search_noncoherent(bits, stride, 0, 30, 5, 1, first_bin=-230, n_bins=12, creep=True)
+        np.testing.assert_allclose(c_neg["max_pwr"][0], want["max_pwr"], rtol=2e-5)
+        np.testing.assert_allclose(c_neg["tot_pwr"][0], want["tot_pwr"], rtol=2e-5)
+        assert (c_neg["max_i"][0] != want["max_i"]).sum() <= 1
+
+
 @pytest.mark.parametrize("fc,fs,cols", [(2.046e6, 8.184e6, 33), (2.6e6, 10e6, 40)])
 def test_noncoherent_wide_instances(golden_dir, fc, fs, cols):
     """The 33- and 40-column non-coherent instances (the only users of the 40 KB LDS slot map in k_corr: their per-lag
