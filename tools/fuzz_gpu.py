@@ -98,6 +98,83 @@ def iq_case(seed, rng, fs, fc, max_fo, mode):
     return desc, worst
 
 
+def plumbing_case(seed, rng, fs, fc, max_fo):
+    """The ways a batch reaches the kernels must not change a bit of the result: the pipeline (random cuts into slots, 1-bit or 8-bit
+    IQ), several engines sharing the GPU (Doppler slabs with a random grid; whole runs), against one plain search."""
+    kind = str(rng.choice(["pipe_bits", "pipe_iq", "multi_grid", "multi_blocks"]))
+    desc = f"seed {seed}: fs {fs / 1e6:.4f} MHz fc {fc / 1e6:.4f} max_fo {max_fo:.0f} mode {kind}"
+    bin_hz = fs / 40000.0
+    if kind.startswith("pipe"):
+        iq = kind == "pipe_iq"
+        nblk = int(rng.integers(3, 40))
+        per = 81920 if iq else int(rng.choice([5120, 5120, 5456, 6000]))
+        with gpsacq.Engine(fc, fs, max_fo) as eng:
+            if iq:
+                raw = rng.integers(0, 256, size=nblk * per, dtype=np.uint8)
+                mean = eng.iq8_mean(raw)
+                inp = eng.iq8_input(remove_dc=True, mean=mean, mix_hz=fc, fs=fs, total_samples=raw.size // 2)
+                _, want = eng.search_iq8(raw, inp)
+            else:
+                raw = rng.integers(0, 256, size=(nblk - 1) * per + 5120, dtype=np.uint8)
+                _, want = eng.search(raw, stride=per, want_cells=False)
+            got, b0, inflight = [], 0, []
+            while b0 < nblk or inflight:
+                while b0 < nblk and len(inflight) < 3:
+                    n = int(min(nblk - b0, rng.integers(1, 12)))
+                    slot = [s_ for s_ in range(3) if s_ not in [i[0] for i in inflight]][0]
+                    nbytes = n * per if iq else (n - 1) * per + 5120
+                    buf = eng.pipe_buffer(slot, max(nbytes, 12 * 81920 if iq else 12 * 6000))
+                    buf[:nbytes] = raw[b0 * per:b0 * per + nbytes]
+                    if iq:
+                        sub = eng.iq8_input(remove_dc=True, mean=mean, mix_hz=fc, fs=fs, first_sample=b0 * 40960, total_samples=raw.size // 2)
+                        eng.pipe_submit(slot, n, per, iq=sub)
+                    else:
+                        eng.pipe_submit(slot, n, per)
+                    inflight.append((slot, b0, n))
+                    b0 += n
+                slot, first, n = inflight.pop(0)
+                pk = eng.pipe_collect(slot)
+                got.append((first, n, pk))
+            # the pipeline's schedule is "task t = block t of the batch against PRN t % 32": the same tasks through the plain entry
+            for first, n, pk in got:
+                tasks = [(first + t, t % 32) for t in range(n)]
+                _, ref = eng.search_iq8(raw, inp, tasks=tasks) if iq else eng.search(raw, tasks=tasks, stride=per)
+                if pk.tobytes() != ref.tobytes():
+                    raise AssertionError(f"pipeline peaks of blocks {first}..{first + n - 1} differ from the plain search")
+                if first % 32 == 0 and pk.tobytes() != want[first:first + n].tobytes():
+                    raise AssertionError("pipeline differs from the reference schedule")
+        return desc + f" blocks {nblk} batches {len(got)}", 0.0
+    ndev = int(rng.integers(2, 6))
+    if kind == "multi_grid":
+        step = float(rng.choice([0.0, bin_hz / 2, bin_hz / 3, 2.0 * bin_hz]))
+        bits = rng.integers(0, 256, size=3 * 5120, dtype=np.uint8)
+        tasks = [(int(rng.integers(0, 3)), int(rng.integers(0, 32))) for _ in range(int(rng.integers(1, 9)))]
+        with gpsacq.Engine(fc, fs, max_fo) as eng:
+            eng.set_doppler_step(step)
+            _, want = eng.search(bits, tasks=tasks)
+        with gpsacq.MultiEngine(fc, fs, max_fo, devices=(0,) * ndev) as me:
+            me.set_doppler_step(step)
+            got = me.search_grid(bits, tasks)
+        for k in ("snr", "lo_shift", "ca_shift"):
+            if not np.array_equal(got[k], want[k]):
+                raise AssertionError(f"multi grid {k} differs with {ndev} engines")
+        return desc + f" engines {ndev} step {step:.2f} tasks {len(tasks)}", 0.0
+    runs = int(rng.integers(1, 5))
+    bits = rng.integers(0, 256, size=runs * 32 * 5120, dtype=np.uint8)
+    with gpsacq.Engine(fc, fs, max_fo) as eng:
+        _, want = eng.search(bits, want_cells=False)
+    with gpsacq.MultiEngine(fc, fs, max_fo, devices=(0,) * ndev) as me:
+        peaks, best = me.search_blocks(bits)
+    if not np.array_equal(peaks, want):
+        raise AssertionError(f"multi blocks peaks differ with {ndev} engines")
+    for sv in range(32):
+        cand = want[sv::32]
+        k = max((float(p["snr"]), -int(p["lo_shift"]), int(p["ca_shift"])) for p in cand)
+        if (float(best["snr"][sv]), -int(best["lo_shift"][sv]), int(best["ca_shift"][sv])) != k:
+            raise AssertionError(f"multi blocks best of PRN index {sv} differs")
+    return desc + f" engines {ndev} runs {runs}", 0.0
+
+
 def one(seed):
     rng = np.random.default_rng(50000 + seed)
     fs = float(rng.choice([rng.uniform(1.2e6, 4e6), rng.uniform(4e6, 10e6), rng.uniform(10e6, 20e6)]))
@@ -107,6 +184,8 @@ def one(seed):
     mode = str(rng.choice(["coherent", "coherent", "quirks", "noncoh", "noncoh_creep", "window", "stride", "iq8", "iq8", "multibit", "complex"]))
     if mode in ("iq8", "multibit", "complex"):
         return iq_case(seed, rng, fs, fc, max_fo, mode)
+    if seed % 5 == 4:
+        return plumbing_case(seed, rng, fs, fc, max_fo)
     step = 0.0 if mode in ("quirks",) else float(rng.choice([0.0, bin_hz / 2, bin_hz / 3, bin_hz / 7, 2.0 * bin_hz, 3.3 * bin_hz]))
     nblk = 6
     bits = rng.integers(0, 256, size=nblk * 5120 + 4096, dtype=np.uint8)
