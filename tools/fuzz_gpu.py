@@ -182,9 +182,9 @@ def one(seed):
     bin_hz = fs / 40000.0
     max_fo = float(rng.uniform(2 * bin_hz, min(60 * bin_hz, 25000.0)))
     mode = str(rng.choice(["coherent", "coherent", "quirks", "noncoh", "noncoh_creep", "window", "stride", "iq8", "iq8", "multibit", "complex"]))
-    if mode in ("iq8", "multibit", "complex"):
+    if mode in ("iq8", "multibit", "complex") and not os.environ.get("FUZZ_PLUMBING"):
         return iq_case(seed, rng, fs, fc, max_fo, mode)
-    if seed % 5 == 4:
+    if seed % 5 == 4 or os.environ.get("FUZZ_PLUMBING"):  # FUZZ_PLUMBING=1: plumbing cases only
         return plumbing_case(seed, rng, fs, fc, max_fo)
     step = 0.0 if mode in ("quirks",) else float(rng.choice([0.0, bin_hz / 2, bin_hz / 3, bin_hz / 7, 2.0 * bin_hz, 3.3 * bin_hz]))
     nblk = 6
