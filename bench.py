@@ -314,8 +314,9 @@ class Leg:
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=10)
-    ap.add_argument("--warmup", type=int, default=2)
+    # 100 steps x 45 ms: a GPU leg long enough for a 5-second SMI sampler to see it (the two CPU baselines take 20 s beside it)
+    ap.add_argument("--steps", type=int, default=100)
+    ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--config", type=int, choices=[1, 2, 3, 4], default=1)
     ap.add_argument("--blocks-total", type=int, default=10880,
                     help="blocks of the whole capture (all ranks together; whole runs of 32): 10880 = the Nottingham capture")
