@@ -32,6 +32,7 @@ with gpsacq.Engine(4.092e6, 5.456e6, 5000.0) as eng:
     for _ in range(8):
         eng.search_device(d_bits.data_ptr(), nblk, d_peaks.data_ptr())
         ms.append(eng.last_timing()["ms_correlate"])
+    out["ms_fwd"] = eng.last_timing()["ms_sample"]
     out["ms_avg"] = sum(ms) / len(ms)
     out["ms_min"] = min(ms)
     out["mcells_s"] = nblk * eng.num_doppler / out["ms_avg"] / 1e3
