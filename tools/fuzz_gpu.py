@@ -98,6 +98,50 @@ def iq_case(seed, rng, fs, fc, max_fo, mode):
     return desc, worst
 
 
+def cli_case(seed, rng, fs, fc):
+    """gps_test on a random file (any length: whole runs, a partial run, a partial block, nothing), random batch size, one to three
+    engines on the GPU, reference quirk on or off, 1-bit or 8-bit IQ: stdout must be the banner, format_report of the engine's own
+    peaks for the whole runs, and the reference's end-of-file line."""
+    import subprocess
+    import tempfile
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    from test_host import BANNER, GPS_TEST
+    iq = bool(rng.integers(0, 3) == 0)
+    quirks = bool(rng.integers(0, 2))
+    per = 81920 if iq else 5120
+    n_bytes = int(rng.integers(0, 5 * 32 * per)) if rng.integers(0, 4) else int(rng.integers(0, 6)) * 32 * per
+    raw = rng.integers(0, 256, size=n_bytes, dtype=np.uint8)
+    env = dict(os.environ, GPSACQ_BATCH_RUNS=str(int(rng.choice([1, 2, 3, 64]))), GPSACQ_REF_QUIRKS="1" if quirks else "0",
+               GPSACQ_DEVICES=",".join(["0"] * int(rng.integers(1, 4))))
+    mix = float(rng.choice([0.0, fc]))
+    if iq:
+        env.update(GPSACQ_INPUT="iq_u8", GPSACQ_MIX_HZ=repr(mix))
+    desc = f"seed {seed}: fs {fs / 1e6:.4f} MHz fc {fc / 1e6:.4f} mode cli bytes {n_bytes} iq {iq} quirks {quirks} batch {env['GPSACQ_BATCH_RUNS']} devices {env['GPSACQ_DEVICES']}"
+    n_runs = n_bytes // (32 * per)
+    with tempfile.NamedTemporaryFile(suffix=".bin", dir="/dev/shm" if os.path.isdir("/dev/shm") else None) as f:
+        raw.tofile(f)
+        f.flush()
+        r = subprocess.run([GPS_TEST, f.name, repr(fc), repr(fs), "5000"], capture_output=True, text=True, env=env, timeout=300)
+    if r.returncode != 0:
+        raise AssertionError(f"gps_test exit {r.returncode}: {r.stderr[-300:]}")
+    want = BANNER
+    if n_runs > 0:
+        with gpsacq.Engine(fc, fs, 5000.0, ref_quirks=quirks) as eng:
+            if iq:
+                mean = eng.iq8_mean(raw)
+                inp = eng.iq8_input(remove_dc=True, mean=mean, mix_hz=mix, fs=fs, total_samples=raw.size // 2)
+                _, peaks = eng.search_iq8(raw[:n_runs * 32 * per], inp)
+            else:
+                _, peaks = eng.search(raw[:n_runs * 32 * per], want_cells=False)
+        want += gpsacq.format_report(peaks)
+    want += "run out of file!\n"
+    if r.stdout != want:
+        a, b = r.stdout.split("\n"), want.split("\n")
+        i = next((k for k in range(min(len(a), len(b))) if a[k] != b[k]), min(len(a), len(b)))
+        raise AssertionError(f"stdout differs at line {i}: {a[i:i + 1]} vs {b[i:i + 1]} ({len(a)} vs {len(b)} lines)")
+    return desc + f" runs {n_runs}", 0.0
+
+
 def plumbing_case(seed, rng, fs, fc, max_fo):
     """The ways a batch reaches the kernels must not change a bit of the result: the pipeline (random cuts into slots, 1-bit or 8-bit
     IQ), several engines sharing the GPU (Doppler slabs with a random grid; whole runs), against one plain search."""
@@ -182,8 +226,10 @@ def one(seed):
     bin_hz = fs / 40000.0
     max_fo = float(rng.uniform(2 * bin_hz, min(60 * bin_hz, 25000.0)))
     mode = str(rng.choice(["coherent", "coherent", "quirks", "noncoh", "noncoh_creep", "window", "stride", "iq8", "iq8", "multibit", "complex"]))
-    if mode in ("iq8", "multibit", "complex") and not os.environ.get("FUZZ_PLUMBING"):
+    if mode in ("iq8", "multibit", "complex") and not os.environ.get("FUZZ_PLUMBING") and not os.environ.get("FUZZ_CLI"):
         return iq_case(seed, rng, fs, fc, max_fo, mode)
+    if os.environ.get("FUZZ_CLI"):  # FUZZ_CLI=1: front-end cases only
+        return cli_case(seed, rng, fs, fc)
     if seed % 5 == 4 or os.environ.get("FUZZ_PLUMBING"):  # FUZZ_PLUMBING=1: plumbing cases only
         return plumbing_case(seed, rng, fs, fc, max_fo)
     step = 0.0 if mode in ("quirks",) else float(rng.choice([0.0, bin_hz / 2, bin_hz / 3, bin_hz / 7, 2.0 * bin_hz, 3.3 * bin_hz]))
