@@ -172,6 +172,23 @@ ACQ_HD void corr_scan(int tid, int rho, int S, int m0, const cf* acc, float& mx,
     mi = 0;
     sum = 0.f;
     if (tid >= NBF3) return;
+    if (NBF3 * (m0 + MC - 1) <= S) {
+        // the instance fits the lag count (uniform test; true for every BASELINE rate): only the last column can reach past S.
+        // Six vector instructions per column instead of nine: no bound test, and the winning column is tracked, not its lag
+        int mb = -1;
+#pragma unroll
+        for (int m = 0; m < MC; ++m) {
+#pragma clang fp contract(off)  // two products and a sum, like the general path below compiles: the same bits either way
+            float p = acc[m].x * acc[m].x + acc[m].y * acc[m].y;
+            if (m == MC - 1) p = (NBF3 * (m0 + m) + rho < S) ? p : 0.f;
+            const bool up = p > mx;
+            mx = up ? p : mx;
+            mb = up ? m : mb;
+            sum += p;
+        }
+        mi = mb >= 0 ? NBF3 * (m0 + mb) + rho : 0;
+        return;
+    }
 #pragma unroll
     for (int m = 0; m < MC; ++m) {  // branch-free: lags beyond S contribute a power of 0
         const int n = NBF3 * (m0 + m) + rho;
