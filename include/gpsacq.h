@@ -268,7 +268,7 @@ typedef struct gpsacq_iq8_input {
                                 real-IF value as a float, the quadrature LO of Sample() (:143-153) applied as signs; spares the
                                 1-bit quantisation loss.  2 (GPSACQ_SAMPLES_COMPLEX): the capture is at baseband already -- I + jQ
                                 is what Sample() builds in fwd_buf (:149-150), e.g. the int8 +-30 file the reference's own
-                                c/conv_1bit_bin_to_hackrf_bin.cpp:61-80 writes for HackRF replay -- so no LO: the complex samples
+                                c/conv_1bit_bin_to_hackrf_bin.cpp:61-80 writes for HackRF replay, or gps_bin1bit_log2bin.m's +-100 one -- so no LO: the complex samples
                                 (less the mean, turned by exp(2 pi i mix_hz n / fs) when a residual IF is named) are transformed
                                 as they are; the engine's fc plays no part.  1 and 2: not with ref_quirks; on a Doppler grid finer
                                 than a bin the sub-bin turn is applied to the float samples (one copy per sub-bin offset). */

@@ -109,6 +109,22 @@ def hackrf_replay_file(bits, lo_quadrant):
     return out
 
 
+def hackrf_baseband_file_matlab(bits):
+    """gps_bin1bit_log2bin.m:15-32 restated: the 1-bit capture (ubit1, LSB first) as +-1, times the fs/4 LO lo_real = [1 0 -1 0 ...],
+    lo_imag = [0 1 0 -1 ...] running from the start of the file, times 100, interleaved I,Q as int8 --
+    `gps.samples.8bit.IQ.fs5456.baseband.bin`, the Nottingham capture made ready for HackRF replay.  For IF = 3/4 fs this is Sample()'s
+    XOR mixer (c/search_offline.cpp:143-153: quadrants 0,3,2,1 -> (1-j, 1+j, -1+j, -1-j) s) up to the constant 100 / (1-j)."""
+    b = np.unpackbits(np.asarray(bits, dtype=np.uint8), bitorder="little").astype(np.int16)
+    y = 1 - 2 * b
+    n = np.arange(y.size) % 4
+    lo_real = np.array([1, 0, -1, 0], dtype=np.int16)[n]
+    lo_imag = np.array([0, 1, 0, -1], dtype=np.int16)[n]
+    out = np.empty(2 * y.size, dtype=np.int8)
+    out[0::2] = y * lo_real * 100
+    out[1::2] = y * lo_imag * 100
+    return out
+
+
 def complex_cells(x, code_replica, dmax, n_lags, eps=0.0, dops=None):
     """Correlate() (c/search_offline.cpp:169-201) on 40000 complex samples (what Sample() would have left in fwd_buf), float64.
     eps: the samples (as floats) turned by exp(-2 pi i eps n / N) first, the sub-bin carrier offset of

@@ -93,6 +93,22 @@ def test_converter_restatement_is_samples_fwd_buf_turned_by_j(golden_dir):
         assert np.array_equal(mi, cells["max_i"])
 
 
+def test_matlab_converter_restatement_is_samples_fwd_buf_up_to_a_constant(golden_dir):
+    """gps_bin1bit_log2bin.m's int8 baseband file of a fs 5.456 MHz / IF 4.092 MHz capture: (1 - j) x its I + jQ = 100 x the C
+    oracle's Sample() buffer, sample for sample."""
+    from iq8_oracle import hackrf_baseband_file_matlab
+    from oracle_lib import lib, _p
+    bits = np.fromfile(os.path.join(golden_dir, "synth_nott_fs5456.bin"), dtype=np.uint8)[:3 * 5120]
+    iq = hackrf_baseband_file_matlab(bits)
+    z = iq[0::2].astype(np.float64) + 1j * iq[1::2].astype(np.float64)
+    quad = _quadrants(4.092e6, 5.456e6, 40960)
+    for b in range(3):
+        blk = np.ascontiguousarray(bits[b * 5120:(b + 1) * 5120])
+        mixed = np.zeros(2 * 40960, np.float32)
+        lib().oracle_mix_block(_p(blk), _p(quad), _p(mixed))
+        assert np.array_equal(z[b * 40960:(b + 1) * 40960] * (1 - 1j), 100.0 * mixed.view(np.complex64).astype(np.complex128))
+
+
 @pytest.mark.gpu
 def test_complex_baseband_search_of_the_converters_file_equals_the_1bit_search(golden_dir):
     """gpsacq_iq8_input.multibit = 2 (GPSACQ_SAMPLES_COMPLEX) on the file the reference's own converter would write from the
@@ -125,6 +141,22 @@ def test_complex_baseband_search_of_the_converters_file_equals_the_1bit_search(g
         assert hit.any()
         assert np.array_equal(p1["lo_shift"][hit], p2["lo_shift"][hit]) and np.array_equal(p1["ca_shift"][hit], p2["ca_shift"][hit])
         np.testing.assert_allclose(p2["snr"], p1["snr"], rtol=5e-6)
+    # the MATLAB converter of the Nottingham capture (gps_bin1bit_log2bin.m: +-100 and 0, fs/4 LO): for IF = 3/4 fs the same
+    # baseband stream up to the constant 100 / (1 - j), so every power is 100^2 / 2 = 5000 x the 1-bit search's
+    from iq8_oracle import hackrf_baseband_file_matlab
+    fc, fs = 4.092e6, 5.456e6
+    bits = np.fromfile(os.path.join(golden_dir, "synth_nott_fs5456.bin"), dtype=np.uint8)
+    bits = bits[:(bits.size // 5120) * 5120]
+    iqm = hackrf_baseband_file_matlab(bits)
+    assert set(np.unique(iqm)) == {-100, 0, 100}
+    with gpsacq.Engine(fc, fs, 5000.0) as eng:
+        c1, p1 = eng.search(bits)
+        c2, p2 = eng.search_iq8(iqm, eng.iq8_input(signed=True, remove_dc=False, total_samples=iqm.size // 2, multibit=2))
+    np.testing.assert_allclose(c2["max_pwr"] / 5000.0, c1["max_pwr"], rtol=3e-6)
+    np.testing.assert_allclose(c2["tot_pwr"] / 5000.0, c1["tot_pwr"], rtol=3e-6)
+    assert (c1["max_i"] != c2["max_i"]).mean() < 1e-3
+    hit = p1["snr"] >= 25
+    assert hit.sum() >= 5 and np.array_equal(p1["lo_shift"][hit], p2["lo_shift"][hit]) and np.array_equal(p1["ca_shift"][hit], p2["ca_shift"][hit])
     # a residual IF: the converter's file turned down by 700 Hz is searched with mix_hz = +700 (and the mean removed, to cover it)
     fc, fs = 2.046e6, 8.184e6
     bits = np.fromfile(os.path.join(golden_dir, "gps_sig_tmp.bin"), dtype=np.uint8)[7 * 5120:9 * 5120]
