@@ -676,6 +676,8 @@ static int iq8_capture(const gpsacq_engine* e, const gpsacq_iq8_input* in, const
     c.iq.mean_q = in->remove_dc ? in->mean_q : 0.0;
     c.iq.two_pi_fc = (2.0 * 3.141592653589793) * in->mix_hz;  // ((1i*2)*pi)*fc, left to right
     c.iq.inv_fs = 1.0 / fs;
+    c.iq.fc = in->mix_hz;
+    c.iq.fs = fs;
     c.iq_first = (size_t)in->first_sample;
     c.iq_total = in->total_samples ? (size_t)in->total_samples : ~(size_t)0;
     c.multibit = in->multibit;
@@ -1073,6 +1075,8 @@ extern "C" int gpsacq_iq8_to_bits_device(gpsacq_engine* e, const void* d_iq, siz
     c.mix = mix_hz != 0.0;
     c.two_pi_fc = (2.0 * 3.141592653589793) * mix_hz;  // ((1i*2)*pi)*fc, left to right
     c.inv_fs = 1.0 / fs;
+    c.fc = mix_hz;
+    c.fs = fs;
     if (remove_dc) {
         long long h[2] = {0, 0};
         if (int rc = iq8_sums_device(e, (const uint8_t*)d_iq, n_samples, c.is_signed != 0, h)) return rc;

@@ -17,7 +17,17 @@ struct IqConv {
     double mean_i, mean_q;
     double two_pi_fc;    // (2*pi)*fc
     double inv_fs;       // 1/fs
+    double fc, fs;       // the same two numbers unrounded, for the HackRF script's operation order
 };
+
+// The mixer phase of capture sample n, in the operation order of the script that handles the format (MATLAB evaluates left to
+// right in double): proc_rtl_bin_for_gps.m:41  1i.*2.*pi.*fc.*(0:n-1).*(1./fs)  ->  (((2 pi) fc) n) (1 / fs);
+// proc_hackrf_bin_for_gps.m:14  1i.*(0:n-1).*2.6e6.*2.*pi./10e6  ->  (((n fc) 2) pi) / fs.
+__device__ __forceinline__ double iq8_theta(size_t n, const IqConv& c) {
+#pragma clang fp contract(off)
+    if (c.is_signed) return ((((double)n * c.fc) * 2.0) * 3.141592653589793) / c.fs;
+    return (c.two_pi_fc * (double)n) * c.inv_fs;
+}
 
 // one sample (I in the low byte of `pair`, Q in the high byte), capture index n -> its real-IF value before the sign
 __device__ __forceinline__ double iq8_value(unsigned pair, size_t n, const IqConv& c) {
@@ -29,8 +39,7 @@ __device__ __forceinline__ double iq8_value(unsigned pair, size_t n, const IqCon
     yq -= c.mean_q;
     double r = yi;
     if (c.mix) {
-        // theta in the operation order of proc_rtl_bin_for_gps.m:41: ((((2*pi)*fc)*n)*(1/fs))
-        const double th = (c.two_pi_fc * (double)n) * c.inv_fs;
+        const double th = iq8_theta(n, c);
         double sn, cs;
         sincos(th, &sn, &cs);
         r = yi * cs - yq * sn;
@@ -49,7 +58,7 @@ __device__ __forceinline__ void iq8_complex(unsigned pair, size_t n, const IqCon
     re = yi;
     im = yq;
     if (c.mix) {
-        const double th = (c.two_pi_fc * (double)n) * c.inv_fs;
+        const double th = iq8_theta(n, c);
         double sn, cs;
         sincos(th, &sn, &cs);
         re = yi * cs - yq * sn;

@@ -4,14 +4,24 @@ that turns an 8-bit IQ capture into gps_test's 1-bit input.  TEST INFRASTRUCTURE
 Restates, operation by operation:
   proc_rtl_bin_for_gps.m:12-26   uint8 -> y-128 -> I + 1i*Q -> y - mean(y) -> real(y) -> (1-sign)/2 -> ubit1
   proc_rtl_bin_for_gps.m:31-47   same, with y = real(y.' .* exp(1i.*2.*pi.*fc.*(0:n-1).*(1./fs)))
-  proc_hackrf_bin_for_gps.m:7-19 int8 input, no offset
-MATLAB evaluates `1i.*2.*pi.*fc.*n.*(1./fs)` left to right in double: theta = (((2*pi)*fc)*n)*(1/fs).
+  proc_hackrf_bin_for_gps.m:7-19 int8 input, no offset; its mixer phase is written 1i.*(0:n-1).*fc.*2.*pi./fs
+MATLAB evaluates these left to right in double: theta = (((2*pi)*fc)*n)*(1/fs) for the rtl script, (((n*fc)*2)*pi)/fs for the
+HackRF one (mixer_phase below; the two differ by an ulp of theta now and then).
 fwrite(..., 'ubit1') rounds the value 0.5 that (1-sign(0))/2 produces to 1 and packs LSB first
 (the bit order Sample() unpacks, c/search_offline.cpp:143-146).
 PIN STATUS: unpinned -- neither MATLAB nor Octave exists in this image and the reference ships no
 converted file; this is a restatement of the script text only.
 """
 import numpy as np
+
+
+def mixer_phase(n, fc, fs, signed):
+    """The mixer phase as the script of the format evaluates it, left to right in double:
+    proc_rtl_bin_for_gps.m:41     exp(1i.*2.*pi.*fc.*(0:n-1).*(1./fs))   -> (((2 pi) fc) n) (1 / fs)
+    proc_hackrf_bin_for_gps.m:14  exp(1i.*(0:n-1).*2.6e6.*2.*pi./10e6)    -> (((n fc) 2) pi) / fs"""
+    if signed:
+        return (((n * fc) * 2.0) * np.pi) / fs
+    return (((2.0 * np.pi) * fc) * n) * (1.0 / fs)
 
 
 def iq8_to_bits(raw, signed=False, remove_dc=True, mix_hz=0.0, fs=2.8e6):
@@ -22,7 +32,7 @@ def iq8_to_bits(raw, signed=False, remove_dc=True, mix_hz=0.0, fs=2.8e6):
         y = y - np.mean(y)
     if mix_hz != 0.0:
         n = np.arange(y.size, dtype=np.float64)
-        theta = (((2.0 * np.pi) * mix_hz) * n) * (1.0 / fs)
+        theta = mixer_phase(n, mix_hz, fs, signed)
         r = y.real * np.cos(theta) - y.imag * np.sin(theta)
     else:
         r = y.real
@@ -40,7 +50,7 @@ def iq8_to_real(raw, signed=False, remove_dc=True, mix_hz=0.0, fs=2.8e6):
         y = y - np.mean(y)
     if mix_hz != 0.0:
         n = np.arange(y.size, dtype=np.float64)
-        theta = (((2.0 * np.pi) * mix_hz) * n) * (1.0 / fs)
+        theta = mixer_phase(n, mix_hz, fs, signed)
         r = y.real * np.cos(theta) - y.imag * np.sin(theta)
     else:
         r = y.real
@@ -86,7 +96,7 @@ def iq8_to_complex(raw, signed=False, remove_dc=True, mix_hz=0.0, fs=2.8e6):
         y = y - np.mean(y)
     if mix_hz != 0.0:
         n = np.arange(y.size, dtype=np.float64)
-        theta = (((2.0 * np.pi) * mix_hz) * n) * (1.0 / fs)
+        theta = mixer_phase(n, mix_hz, fs, signed)
         cs, sn = np.cos(theta), np.sin(theta)
         y = (y.real * cs - y.imag * sn) + 1j * (y.real * sn + y.imag * cs)
     return y.astype(np.complex64)
