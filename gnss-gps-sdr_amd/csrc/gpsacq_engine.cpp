@@ -499,6 +499,13 @@ static int prepare_tasks(gpsacq_engine* e, const gpsacq_task* h_tasks, const voi
 
 static int iq8_to_bits_enqueue(gpsacq_engine* e, const uint8_t* d_iq, size_t n_samples, const IqConv& conv, size_t first_sample, uint8_t* d_bits);
 
+// columns of pass p when the lags need several passes (fs > 10 MHz): 40 per pass, the last one the smallest instance that covers
+// what is left (16.368 MHz: 66 columns = 40 + 28-column instance; round 2 ran 40 + 40)
+static int pass_columns(int n_cols, int p) {
+    const int left = n_cols - p * MC_MAX;
+    return left >= MC_MAX ? MC_MAX : corr_columns(left * NBF3);
+}
+
 static int search_core(gpsacq_engine* e, const Capture& cap_in, size_t n_blocks, const gpsacq_task* h_tasks,
                        const void* d_user_tasks, size_t n_tasks, Cell* d_cells, Peak* d_peaks) {
     Capture cap = cap_in;
@@ -615,7 +622,8 @@ static int search_core(gpsacq_engine* e, const Capture& cap_in, size_t n_blocks,
         ca.pdump = e->d_pdump;
         for (int p = 0; p < n_pass; ++p) {
             ca.m0 = p * MC_MAX;
-            if (launch_corr(ca, MC_MAX, e->stream) != 0) return fail(GPSACQ_ERR_UNSUPPORTED, "no correlate kernel for %d columns", MC_MAX);
+            const int mc = pass_columns(n_cols, p);
+            if (launch_corr(ca, mc, e->stream) != 0) return fail(GPSACQ_ERR_UNSUPPORTED, "no correlate kernel for %d columns", mc);
         }
         launch_scan_power(e->d_pdump, d_cells, n_cells, e->nlags, e->stream);
     } else {
@@ -624,7 +632,8 @@ static int search_core(gpsacq_engine* e, const Capture& cap_in, size_t n_blocks,
         for (int p = 0; p < n_pass; ++p) {
             ca.m0 = p * MC_MAX;
             ca.cells = e->d_parts + (size_t)p * n_cells;
-            if (launch_corr(ca, MC_MAX, e->stream) != 0) return fail(GPSACQ_ERR_UNSUPPORTED, "no correlate kernel for %d columns", MC_MAX);
+            const int mc = pass_columns(n_cols, p);
+            if (launch_corr(ca, mc, e->stream) != 0) return fail(GPSACQ_ERR_UNSUPPORTED, "no correlate kernel for %d columns", mc);
         }
         launch_merge_cells(e->d_parts, d_cells, n_cells, n_pass, e->nlags, e->stream);
     }

@@ -10,7 +10,7 @@ import torch  # noqa: E402
 import gpsacq  # noqa: E402
 
 for fc, fs, max_fo, nblk in [(4.092e6, 5.456e6, 5000.0, 2048), (0.62e6, 2.8e6, 5000.0, 1024), (1.7e6, 6.8e6, 5000.0, 2048), (2.046e6, 8.184e6, 5000.0, 2048),
-                             (2.6e6, 10e6, 5000.0, 2048), (4.0e6, 16.368e6, 5000.0, 1024)]:
+                             (2.6e6, 10e6, 5000.0, 2048), (3.0e6, 12e6, 5000.0, 1024), (4.0e6, 16.368e6, 5000.0, 1024)]:
     with gpsacq.Engine(fc, fs, max_fo) as eng:
         d_bits = torch.randint(0, 256, (nblk * 5120,), dtype=torch.uint8, device="cuda")
         d_peaks = torch.zeros(nblk * 4, dtype=torch.int32, device="cuda")
