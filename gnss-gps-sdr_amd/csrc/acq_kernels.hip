@@ -141,7 +141,8 @@ __global__ __launch_bounds__(WG) void k_quirk_patch(QuirkArgs a) {
 // NC = true: non-coherent mode (no reference equivalent): the powers |y[n]|^2 of a.n_acc
 // consecutive block spectra (a.acc_step apart) are summed in an LDS array indexed by lag, so that block k's lags can be
 // re-aligned by the whole samples the code has crept since block 0 at this cell's Doppler (a.creep samples per block per
-// grid point; 0 = plain sum): power of lag n goes to lag (n - round(k * creep * point)) mod S.
+// grid point; 0 = plain sum) and by the code phase between block starts that are not whole code periods apart (a.lag_step samples
+// per block; 0 = none): power of lag n goes to lag (n - round(k * creep * point) - k * lag_step) mod S.
 // W1H: half of the pass-1 twiddles derived instead of held (acq_math.hpp): 18 registers for 18 packed multiplies.
 // PROF: s_memtime stamps per segment, summed over the launch into a.prof[1024][16] (GPSACQ_PROF=1; costs a few per cent).
 // L: LDS slot map and lane map (acq_math.hpp): LayC (LayB's slots, conflict-free lane assignment) everywhere except the two
@@ -316,7 +317,8 @@ __global__ __launch_bounds__(WG, WPS) void k_corr(CorrArgs a) {
         else if (NC) {
             // every lag has one owner per block, so the scatter needs no atomics; successive blocks'
             // updates are separated by the barriers of the next 8 sub-transforms
-            const int shift = __float2int_rn((float)k * a.creep * (float)(di + a.dop_first));
+            // block k's peak sits later by what the code has crept at this cell's Doppler, and by the code phase its start is ahead of block 0's
+            const int shift = __float2int_rn((float)k * a.creep * (float)(di + a.dop_first)) + k * a.lag_step;
             if (a.pdump) corr_dump_power<MC>(tid, rho, a.nlags, a.m0, shift, acc, a.pdump + ((size_t)task * a.ndop + di) * a.nlags);
             else corr_accumulate_power<MC>(tid, rho, a.nlags, a.m0, shift, acc, pws);
         }
@@ -578,7 +580,7 @@ int launch_corr(const CorrArgs& a, int mc, hipStream_t s) {
         case 12:
             // non-coherent: without creep re-alignment the per-lag sums stay in registers and three workgroups fit a CU (BASELINE
             // configs[3]); with it they go through a per-lag LDS array (61 KB: two per CU)
-            if (a.n_acc > 1 && a.creep == 0.f) hipLaunchKernelGGL((k_corr<12, 3, 2, true, false, false, ACQ_CORR_LAYOUT, true>), grid, block, 0, s, a);
+            if (a.n_acc > 1 && a.creep == 0.f && a.lag_step == 0) hipLaunchKernelGGL((k_corr<12, 3, 2, true, false, false, ACQ_CORR_LAYOUT, true>), grid, block, 0, s, a);
             else if (a.n_acc > 1) hipLaunchKernelGGL((k_corr<12, 2, 2, true>), grid, block, 0, s, a);
             else hipLaunchKernelGGL((k_corr<12, 3, 2, false>), grid, block, 0, s, a);
             break;

@@ -52,6 +52,8 @@ struct CorrArgs {
     int m0;               // first accumulator column of this pass (multiple of 40; 0 unless fs > 10 MHz)
     int n_acc, acc_step;  // non-coherent mode: spectra tk.spec + k*acc_step, k < n_acc (n_acc = 1: coherent)
     float creep;          // non-coherent mode: code creep in samples per accumulated block per Doppler bin (0 = off)
+    int lag_step;         // non-coherent mode: whole samples of code phase between the starts of accumulated blocks, (block_step *
+                          // block samples) mod S, when the blocks are not whole code periods apart and re-alignment is asked for (0 = off)
     int n_spec, n_code;   // rows of dpp / cpp: tasks pointing outside get an empty cell (max_i = -1)
     int sub, dstride;     // Doppler grid (acq_phases.hpp grid_point): dop_first/ndop count grid points; spectrum of (block, r) at row block*sub + r
     const cf *t1_8, *t2_8, *t3_8, *bq8;  // tables of the 8-wave correlator (acq_corr8.hpp, Tables8)

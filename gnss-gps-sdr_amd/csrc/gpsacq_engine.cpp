@@ -57,6 +57,7 @@ struct gpsacq_engine {
     int sub = 1, dstride = 1, kmax = 0;
     cf* d_rot8 = nullptr;
     bool creep_comp = false;      // re-align accumulated blocks by the code creep of each Doppler bin
+    bool block_align = false;     // re-align accumulated blocks by the code phase between their starts (any stride)
     int cus = 0;
     char name[64] = {0};
     hipStream_t stream = nullptr;
@@ -601,6 +602,12 @@ static int search_core(gpsacq_engine* e, const Capture& cap_in, size_t n_blocks,
         HIPCHK(hipMemsetAsync(e->d_prof, 0, 1024 * 16 * sizeof(unsigned long long), e->stream));
         ca.prof = e->d_prof;
     }
+    if (e->block_align && e->n_acc > 1) {
+        if ((double)e->nlags * 1000.0 != e->p.fs) return fail(GPSACQ_ERR_UNSUPPORTED, "block alignment needs a whole number of samples per code period (fs = %g Hz)", e->p.fs);
+        const long long t = (long long)e->acc_step * (long long)block_samples;
+        ca.lag_step = (int)(t % e->nlags);
+    }
+    const bool realign = e->n_acc > 1 && (e->creep_comp || ca.lag_step != 0);
     const int n_cols = (e->nlags + NBF3 - 1) / NBF3;
     const int n_pass = (n_cols + MC_MAX - 1) / MC_MAX;  // 1 up to 10000 lags (fs <= 10 MHz)
     if (n_pass == 1) {
@@ -612,13 +619,13 @@ static int search_core(gpsacq_engine* e, const Capture& cap_in, size_t n_blocks,
         if (e->corr8 >= 2 && e->n_acc == 1 && mc8 > 0) {
             if (launch_corr8(ca, mc8, e->corr8, e->stream) != 0) return fail(GPSACQ_ERR_UNSUPPORTED, "no 8-wave correlate kernel for %d columns", mc8);
         } else if (launch_corr(ca, e->mc, e->stream) != 0) return fail(GPSACQ_ERR_UNSUPPORTED, "no correlate kernel for %d columns", e->mc);
-    } else if (e->creep_comp && e->n_acc > 1) {
+    } else if (realign) {
         // re-aligned lags cross the passes' column windows: the per-lag sums of every cell go to device memory (nlags floats per
         // cell), every pass adds its window's powers at their re-aligned lags, one scan per cell at the end
         const size_t n_cells = n_tasks * (size_t)e->ndop;
         if (int rc = grow(e->d_pdump, e->pdump_cap, n_cells * (size_t)e->nlags, e->stream)) return rc;
         HIPCHK(hipMemsetAsync(e->d_pdump, 0, n_cells * (size_t)e->nlags * sizeof(float), e->stream));
-        ca.creep = (float)((double)e->acc_step * block_samples * (e->p.fs / N_FFT * e->dstride / e->sub) / 1575.42e6);
+        if (e->creep_comp) ca.creep = (float)((double)e->acc_step * block_samples * (e->p.fs / N_FFT * e->dstride / e->sub) / 1575.42e6);
         ca.pdump = e->d_pdump;
         for (int p = 0; p < n_pass; ++p) {
             ca.m0 = p * MC_MAX;
@@ -882,6 +889,12 @@ extern "C" int gpsacq_set_noncoherent(gpsacq_engine* e, int n_acc, int block_ste
 extern "C" int gpsacq_set_creep_compensation(gpsacq_engine* e, int on) {
     if (!e) return fail(GPSACQ_ERR_ARG, "gpsacq_set_creep_compensation: null engine");
     e->creep_comp = on != 0;
+    return GPSACQ_OK;
+}
+
+extern "C" int gpsacq_set_block_alignment(gpsacq_engine* e, int on) {
+    if (!e) return fail(GPSACQ_ERR_ARG, "gpsacq_set_block_alignment: null engine");
+    e->block_align = on != 0;
     return GPSACQ_OK;
 }
 

@@ -62,7 +62,7 @@ class Sat(ctypes.Structure):
 
 
 EXPORTS = ["gpsacq_generate", "gpsacq_generate_device", "gpsacq_generate_sig", "gpsacq_sig_bytes", "gpsacq_handoff", "gpsacq_iq8_to_bits", "gpsacq_iq8_to_bits_device", "gpsacq_create", "gpsacq_destroy", "gpsacq_last_error", "gpsacq_get_info", "gpsacq_search",
-           "gpsacq_search_device", "gpsacq_set_doppler_window", "gpsacq_set_doppler_step", "gpsacq_set_noncoherent", "gpsacq_set_creep_compensation", "gpsacq_aligned_stride", "gpsacq_synchronize", "gpsacq_last_timing", "gpsacq_timing_ago", "gpsacq_stream", "gpsacq_search_code",
+           "gpsacq_search_device", "gpsacq_set_doppler_window", "gpsacq_set_doppler_step", "gpsacq_set_noncoherent", "gpsacq_set_creep_compensation", "gpsacq_set_block_alignment", "gpsacq_aligned_stride", "gpsacq_synchronize", "gpsacq_last_timing", "gpsacq_timing_ago", "gpsacq_stream", "gpsacq_search_code",
            "gpsacq_sample_spectrum", "gpsacq_code_spectrum", "gpsacq_multi_create", "gpsacq_multi_destroy",
            "gpsacq_multi_set_doppler_step", "gpsacq_multi_get_info", "gpsacq_multi_search_grid", "gpsacq_multi_search_blocks",
            "gpsacq_pipe_buffer", "gpsacq_pipe_submit", "gpsacq_pipe_collect", "gpsacq_search_iq8", "gpsacq_search_iq8_device",
@@ -128,6 +128,8 @@ def load_library(path=None):
     lib.gpsacq_last_timing.restype = ctypes.c_int
     lib.gpsacq_set_creep_compensation.argtypes = [vp, ctypes.c_int]
     lib.gpsacq_set_creep_compensation.restype = ctypes.c_int
+    lib.gpsacq_set_block_alignment.argtypes = [vp, ctypes.c_int]
+    lib.gpsacq_set_block_alignment.restype = ctypes.c_int
     lib.gpsacq_timing_ago.argtypes = [vp, ctypes.c_int, ctypes.POINTER(Timing)]
     lib.gpsacq_timing_ago.restype = ctypes.c_int
     lib.gpsacq_stream.argtypes = [vp]
@@ -263,6 +265,10 @@ class Engine:
     def set_creep_compensation(self, on=True):
         """Non-coherent mode: re-align each accumulated block by the code creep of the cell's Doppler bin."""
         _check(self._lib, self._lib.gpsacq_set_creep_compensation(self._h, 1 if on else 0))
+
+    def set_block_alignment(self, on=True):
+        """Non-coherent mode: re-align each accumulated block by the code phase between block starts (any stride)."""
+        _check(self._lib, self._lib.gpsacq_set_block_alignment(self._h, 1 if on else 0))
 
     def aligned_stride(self):
         """Bytes between block starts that keep lags aligned for non-coherent sums (whole C/A periods)."""

@@ -215,6 +215,15 @@ GPSACQ_API int gpsacq_set_noncoherent(gpsacq_engine* e, int n_acc, int block_ste
  * several passes of 40 columns) the per-lag sums are kept in device memory -- 4 * fs/1000 bytes per cell of the batch.
  */
 GPSACQ_API int gpsacq_set_creep_compensation(gpsacq_engine* e, int on);
+/*
+ * Block alignment for the non-coherent mode (off by default; SURVEY.md section 8d, configs[3]: "per-block lag re-alignment").
+ * Accumulated blocks whose starts are T = block_step * stride * 8 samples apart (stride / 2 for an 8-bit IQ capture) see the
+ * code T mod (fs/1000) samples further on each time; with alignment on, block k's powers are moved back by k * (T mod S)
+ * samples (modulo the S = fs/1000 lags) before they are summed, so any stride -- the file's own 5120-byte blocks, an IQ
+ * capture's 81920 -- accumulates in phase and ca_shift refers to block 0.  gpsacq_aligned_stride() remains the layout that needs
+ * no re-alignment (and lets the sums stay in registers).  Needs fs to be a whole number of samples per code period (fs = 1000 S).
+ */
+GPSACQ_API int gpsacq_set_block_alignment(gpsacq_engine* e, int on);
 GPSACQ_API int gpsacq_aligned_stride(const gpsacq_engine* e);
 GPSACQ_API int gpsacq_synchronize(gpsacq_engine* e);
 /* stage times of the most recent search (waits for it to finish) ... */

@@ -121,9 +121,10 @@ class Oracle:
                 cells[i] = one[0]
         return cells, ks
 
-    def search_noncoherent(self, bits, stride, first_block, sv, n_acc, block_step, first_bin=None, n_bins=None, creep=False):
+    def search_noncoherent(self, bits, stride, first_block, sv, n_acc, block_step, first_bin=None, n_bins=None, creep=False, align=False):
         """Restatement of the non-coherent extension: per Doppler bin, sum |IFFT|^2 per lag over
-        n_acc blocks, then the reference's scan (:190-196) over the sum.  creep: block k's powers are
+        n_acc blocks, then the reference's scan (:190-196) over the sum.  align: block k's powers are first moved back by
+        k * ((block_step * stride * 8) mod S) samples (blocks that are not whole code periods apart).  creep: block k's powers are
         first moved back by round(k * c * bin) samples modulo the S lags, c = float32(samples between
         accumulated blocks * (fs / 40000) / L1) -- the product's code-creep compensation."""
         buf = np.frombuffer(bits, dtype=np.uint8)
@@ -142,6 +143,8 @@ class Oracle:
             for d in range(first_bin, first_bin + n_bins):
                 self.L.oracle_cell_power(self.h, sv, d, _p(tmp))
                 shift = int(np.rint(np.float32(k) * c * np.float32(d))) if creep else 0
+                if align:  # gpsacq_set_block_alignment: the code phase between block starts that are not whole periods apart
+                    shift += k * ((block_step * stride * 8) % S)
                 power[d - first_bin] += np.roll(tmp, -shift)  # lag n -> (n - shift) mod S
         cells = np.zeros(n_bins, CELL_DTYPE)
         cells["max_pwr"] = power.max(axis=1)

@@ -320,6 +320,67 @@ def test_noncoherent_creep_compensation():
         assert np.array_equal(a, b)
 
 
+def test_noncoherent_block_alignment_any_stride(golden_dir):
+    """gpsacq_set_block_alignment (SURVEY.md section 8d configs[3], "per-block lag re-alignment"): the file's own contiguous
+    5120-byte blocks are 40960 samples apart -- 40960 mod 5456 = 2768 samples of code phase -- so a plain non-coherent sum smears the
+    peak over five lags; with alignment on the weak PRN 12 stands out as with the aligned layout, the sums equal the oracle's
+    restatement, and the code phase refers to block 0.  Also together with creep re-alignment, at a rate with two column passes, and
+    on an 8-bit IQ capture (81920-byte blocks)."""
+    import gpsacq
+    from oracle_lib import Oracle
+    fc, fs = 4.092e6, 5.456e6
+    orc = Oracle(fc, fs, 5000.0)
+    with gpsacq.Engine(fc, fs, 5000.0) as eng:
+        # the same signal parameters as the weak-signal fixture, generated contiguously
+        bits = eng.generate(6 * 5120, [(12, 0.06, 4 * fs / 40000, 1000.0, 0.1), (3, 0.2, -11 * fs / 40000, 3333.0, 0.7)], noise_sigma=1.0, seed=5)
+        tasks = [(0, 11), (0, 2), (0, 20)]
+        eng.set_noncoherent(5, 1)
+        c_plain, p_plain = eng.search(bits, tasks=tasks)
+        eng.set_block_alignment(True)
+        c_al, p_al = eng.search(bits, tasks=tasks)
+        for t, (b, sv) in enumerate(tasks):
+            want = orc.search_noncoherent(bits, 5120, b, sv, 5, 1, align=True)
+            np.testing.assert_allclose(c_al["max_pwr"][t], want["max_pwr"], rtol=2e-5)
+            np.testing.assert_allclose(c_al["tot_pwr"][t], want["tot_pwr"], rtol=2e-5)
+            assert (c_al["max_i"][t] != want["max_i"]).sum() <= 1
+        assert np.allclose(c_al["tot_pwr"], c_plain["tot_pwr"], rtol=1e-5)  # a permutation of the same powers
+        assert int(p_al["lo_shift"][0]) == 4 and abs(int(p_al["ca_shift"][0]) - 1000) <= 1
+        assert int(p_al["lo_shift"][1]) == -11 and int(p_al["ca_shift"][1]) == 3333
+        assert p_al["snr"][0] > 2.0 * p_al["snr"][2] and p_al["snr"][0] > 1.5 * p_plain["snr"][0], (p_al["snr"], p_plain["snr"])
+        # with the creep re-alignment on top, every second block
+        eng.set_noncoherent(3, 2)
+        eng.set_creep_compensation(True)
+        c2, _ = eng.search(bits, tasks=[(0, 2)])
+        want = orc.search_noncoherent(bits, 5120, 0, 2, 3, 2, creep=True, align=True)
+        np.testing.assert_allclose(c2["max_pwr"][0], want["max_pwr"], rtol=2e-5)
+        assert (c2["max_i"][0] != want["max_i"]).sum() <= 1
+        # off again: the plain sums, bit for bit
+        eng.set_creep_compensation(False)
+        eng.set_block_alignment(False)
+        eng.set_noncoherent(5, 1)
+        c3, _ = eng.search(bits, tasks=tasks)
+        assert np.array_equal(c3, c_plain)
+    # 12 MHz: 12000 lags in two column passes (per-lag sums in device memory), blocks 40960 samples = 3.41 periods apart
+    fc, fs = 3.0e6, 12.0e6
+    orc = Oracle(fc, fs, 3000.0)
+    with gpsacq.Engine(fc, fs, 3000.0) as eng:
+        bits = eng.generate(4 * 5120, [(7, 0.08, 2 * fs / 40000, 11990.0, 0.2)], noise_sigma=1.0, seed=9)
+        eng.set_noncoherent(4, 1)
+        eng.set_block_alignment(True)
+        c, p = eng.search(bits, tasks=[(0, 6), (0, 19)])
+        want = orc.search_noncoherent(bits, 5120, 0, 6, 4, 1, align=True)
+        np.testing.assert_allclose(c["max_pwr"][0], want["max_pwr"], rtol=2e-5)
+        np.testing.assert_allclose(c["tot_pwr"][0], want["tot_pwr"], rtol=2e-5)
+        assert (c["max_i"][0] != want["max_i"]).sum() <= 1
+        assert int(p["lo_shift"][0]) == 2 and abs(int(p["ca_shift"][0]) - 11990) <= 1 and p["snr"][0] > 2.0 * p["snr"][1]
+    # a rate whose code period is not a whole number of samples is refused
+    with gpsacq.Engine(1.0e6, 4.0005e6, 3000.0) as eng:
+        eng.set_noncoherent(2, 1)
+        eng.set_block_alignment(True)
+        with pytest.raises(gpsacq.GpsAcqError):
+            eng.search(np.zeros(3 * 5120, np.uint8))
+
+
 def test_noncoherent_creep_compensation_beyond_10000_lags():
     """fs = 16.368 MHz: 16 368 lags are searched in two passes of 40 columns, and a lag's re-aligned destination can lie in the
     other pass's window -- the per-lag sums then live in device memory (k_corr's corr_dump_power + k_scan_power).  A satellite at

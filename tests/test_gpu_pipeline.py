@@ -167,6 +167,20 @@ def test_multibit_samples_vs_numpy_restatement():
         np.testing.assert_allclose(ca["max_pwr"][0], pw.max(axis=1), rtol=2e-5)
         np.testing.assert_allclose(ca["tot_pwr"][0], pw.sum(axis=1), rtol=2e-5)
         assert (ca["max_i"][0] != pw.argmax(axis=1)).sum() <= 1  # (the blocks are 40960 samples apart, not whole code periods: parity only)
+        # ... and with gpsacq_set_block_alignment: block 1 moved back by 40960 mod 2800 = 1760 samples of code phase -- PRN 5 adds up
+        eng.set_block_alignment(True)
+        cb, pb = eng.search_iq8(iq, inp, tasks=[(0, 4)])
+        pw = acc[0] + np.roll(acc[1], -(40960 % 2800), axis=1)
+        np.testing.assert_allclose(cb["max_pwr"][0], pw.max(axis=1), rtol=2e-5)
+        np.testing.assert_allclose(cb["tot_pwr"][0], pw.sum(axis=1), rtol=2e-5)
+        assert (cb["max_i"][0] != pw.argmax(axis=1)).sum() <= 1
+        assert pb["snr"][0] > 25 and pb["snr"][0] > pa["snr"][0] and pb["ca_shift"][0] == peaks["ca_shift"][0]
+        # the sign path of the same capture through the same switch equals the search of the converted bits
+        inp_sign = eng.iq8_input(remove_dc=True, mean=mean, mix_hz=fc, fs=fs, total_samples=iq.size // 2)
+        c_iq, _ = eng.search_iq8(iq, inp_sign, tasks=[(0, 4)])
+        c_bits, _ = eng.search(eng.iq8_to_bits(iq, remove_dc=True, mix_hz=fc, fs=fs), tasks=[(0, 4)])
+        assert np.array_equal(c_iq, c_bits)
+        eng.set_block_alignment(False)
         eng.set_noncoherent(1, 1)
     # not with the reference quirk
     with gpsacq.Engine(fc, fs, 5000.0, ref_quirks=True) as eng:

@@ -232,6 +232,9 @@ def one(seed):
         return cli_case(seed, rng, fs, fc)
     if seed % 5 == 4 or os.environ.get("FUZZ_PLUMBING"):  # FUZZ_PLUMBING=1: plumbing cases only
         return plumbing_case(seed, rng, fs, fc, max_fo)
+    if mode in ("noncoh", "noncoh_creep") and rng.integers(0, 2):
+        fs = float(round(fs / 1000.0) * 1000.0)  # a whole number of samples per code period: block alignment is defined
+        bin_hz = fs / 40000.0
     step = 0.0 if mode in ("quirks",) else float(rng.choice([0.0, bin_hz / 2, bin_hz / 3, bin_hz / 7, 2.0 * bin_hz, 3.3 * bin_hz]))
     nblk = 6
     bits = rng.integers(0, 256, size=nblk * 5120 + 4096, dtype=np.uint8)
@@ -251,14 +254,16 @@ def one(seed):
             stride = 5120
             eng.set_noncoherent(n_acc, bstep)
             eng.set_creep_compensation(mode == "noncoh_creep")
+            align = bool(rng.integers(0, 2)) and float(eng.num_lags) * 1000.0 == fs  # whole samples per code period only
+            eng.set_block_alignment(align)
             tasks = [(0, int(rng.integers(0, 32))), (int(rng.integers(0, nblk - (n_acc - 1) * bstep)), int(rng.integers(0, 32)))]
             cells, peaks = eng.search(bits.tobytes(), tasks=tasks, stride=stride)
             for t, (b, sv) in enumerate(tasks):
-                want = orc.search_noncoherent(bits.tobytes(), stride, b, sv, n_acc, bstep, creep=(mode == "noncoh_creep"))
+                want = orc.search_noncoherent(bits.tobytes(), stride, b, sv, n_acc, bstep, creep=(mode == "noncoh_creep"), align=align)
                 worst = max(worst, close(cells["max_pwr"][t], want["max_pwr"], "nc max_pwr"), close(cells["tot_pwr"][t], want["tot_pwr"], "nc tot_pwr"))
                 if (cells["max_i"][t] != want["max_i"]).sum() > 1:
                     raise AssertionError("nc argmax")
-            return desc + f" n_acc {n_acc} step {bstep}", worst
+            return desc + f" n_acc {n_acc} step {bstep} align {align}", worst
         if mode == "window":
             first = int(rng.integers(-kmax, kmax + 1))
             n = int(rng.integers(1, kmax - first + 2))
