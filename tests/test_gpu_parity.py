@@ -7,11 +7,13 @@ cell are closer than 1e-5 relative (a float-rounding tie).
 """
 import json
 import os
+import sys
 
 import numpy as np
 import pytest
 
 pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 REL = 2e-5
 
@@ -85,6 +87,50 @@ def test_code_and_sample_spectra(gpsacq_mod, golden_dir, name):
             g, o = eng.sample_spectrum(blk), orc.sample_spectrum(blk)
             scale = np.abs(o).max()
             assert np.abs(g - o).max() / scale < 2e-6, f"sample spectrum block {b}"
+
+
+@pytest.mark.parametrize("name", ["nott", "sigtmp", "rtl"])
+def test_cells_vs_torch_fp32_reference(gpsacq_mod, golden_dir, name):
+    """The whole cell computation against a plain float32 restatement on the device whose transforms are the vendor library's
+    (torch.fft = rocFFT, complex64): Sample()'s XOR-mixed samples (from the oracle's mixer, exact +-1 values) -> fft ->
+    conj(data) * shifted code spectrum -> ifft * N -> |.|^2 over the first S lags -> max / argmax / sum (c/search_offline.cpp:161,
+    176-196).  The reference's own transforms are FFTW in float, which this image does not have; a second, independent
+    single-precision FFT is the nearest thing available here, and north_star's bar for the FFTW path (magnitudes within 1e-4
+    relative) is met against it with a factor of ten to spare."""
+    import torch
+    from oracle_lib import lib, _p
+    sys.path.insert(0, os.path.join(ROOT, "tests", "golden"))
+    from make_golden import code_replica
+    cfg = CONFIGS[name]
+    fc, fs = cfg["fc"], cfg["fs"]
+    buf = np.frombuffer(open(os.path.join(golden_dir, cfg["file"]), "rb").read(), dtype=np.uint8)
+    quad = np.zeros(40960, np.uint8)
+    lib().oracle_lo_quadrants(fc, fs, 40960, _p(quad))
+    tasks = [(0, 0), (1, 20), (2, 7), (3, 31), (4, 28)]
+    N = 40000
+    with gpsacq_mod.Engine(fc, fs, 5000.0) as eng:
+        cells, _ = eng.search(buf[:5 * 5120], tasks=tasks)
+        S, dmax = eng.num_lags, eng.dmax
+    worst = 0.0
+    for t, (b, sv) in enumerate(tasks):
+        blk = np.ascontiguousarray(buf[b * 5120:(b + 1) * 5120])
+        mixed = np.zeros(2 * 40960, np.float32)
+        lib().oracle_mix_block(_p(blk), _p(quad), _p(mixed))
+        x = torch.from_numpy(mixed.view(np.complex64)[:N].copy()).cuda()
+        D = torch.fft.fft(x)
+        C = torch.fft.fft(torch.from_numpy(np.asarray(code_replica(fs, sv), dtype=np.float32)).cuda().to(torch.complex64))
+        assert D.dtype == torch.complex64 and C.dtype == torch.complex64
+        for d in range(-dmax, dmax + 1):
+            y = torch.fft.ifft(torch.conj(D) * torch.roll(C, d)) * N  # rev_buf[i] = conj(data[i]) * code[(i - dop) mod N]; backward, unnormalised
+            pwr = (y.real * y.real + y.imag * y.imag)[:S]
+            got = cells[t][d + dmax]
+            mx, mi = float(pwr.max()), int(pwr.argmax())
+            tot = float(pwr.sum(dtype=torch.float64))
+            worst = max(worst, abs(got["max_pwr"] / mx - 1.0), abs(got["tot_pwr"] / tot - 1.0))
+            if got["max_i"] != mi:  # two lags within float rounding of each other
+                assert abs(float(pwr[got["max_i"]]) / mx - 1.0) < 1e-5, (t, d, got["max_i"], mi)
+    print(f"worst relative difference to the rocFFT float32 restatement ({name}): {worst:.2e}")
+    assert worst < 1e-5, worst
 
 
 @pytest.mark.parametrize("name", ["nott", "sigtmp", "rtl"])
