@@ -2,6 +2,7 @@
 outputs recorded in BASELINE.md, the bundled capture, and an independent float64 numpy
 restatement (tests/golden/make_golden.py)."""
 import json
+import sys
 import os
 
 import numpy as np
@@ -174,3 +175,37 @@ def test_oracle_is_clean_under_asan_and_ubsan(golden_dir, tmp_path, real):
     r = subprocess.run([exe, os.path.join(golden_dir, "gps_sig_tmp.bin"), "2.046e6", "8.184e6"], capture_output=True, text=True, timeout=300,
                        env=dict(os.environ, ASAN_OPTIONS="detect_leaks=1", UBSAN_OPTIONS="print_stacktrace=1"))
     assert r.returncode == 0 and "oracle_san: ok" in r.stdout, r.stdout + r.stderr
+
+
+def test_oracle_cells_against_an_independent_float32_fft(golden_dir):
+    """How far can float rounding of the transforms move a cell?  The reference runs FFTW in single precision (absent here); the
+    checker transforms in double.  The same cells with every transform done by a third implementation in float32 (scipy's
+    pocketfft on complex64) differ from the checker's by < 3e-6 relative in max_pwr and tot_pwr with the same argmax -- thirty
+    times inside north_star's 1e-4 -- and the SNR that decides the threshold-25 hit list moves by < 3e-6 too."""
+    import scipy.fft
+    sys.path.insert(0, os.path.join(ROOT, "tests", "golden"))
+    from make_golden import code_replica
+    N = 40000
+    for name, fc, fs, picks in (("gps_sig_tmp.bin", 2.046e6, 8.184e6, [(7, 7), (0, 0), (40, 8)]), ("synth_nott_fs5456.bin", 4.092e6, 5.456e6, [(0, 0), (20, 20)])):
+        buf = np.fromfile(os.path.join(golden_dir, name), dtype=np.uint8)
+        orc = Oracle(fc, fs, 5000.0)
+        quad = np.zeros(40960, np.uint8)
+        lib().oracle_lo_quadrants(fc, fs, 40960, _p(quad))
+        for b, sv in picks:
+            blk = np.ascontiguousarray(buf[b * 5120:(b + 1) * 5120])
+            cells, _ = orc.search_block(blk, sv)
+            mixed = np.zeros(2 * 40960, np.float32)
+            lib().oracle_mix_block(_p(blk), _p(quad), _p(mixed))
+            D = scipy.fft.fft(mixed.view(np.complex64)[:N])
+            C = scipy.fft.fft(np.asarray(code_replica(fs, sv), dtype=np.float32).astype(np.complex64))
+            assert D.dtype == np.complex64 and C.dtype == np.complex64
+            for d in range(-orc.dmax, orc.dmax + 1):
+                y = scipy.fft.ifft((np.conj(D) * np.roll(C, d)).astype(np.complex64)) * np.float32(N)
+                assert y.dtype == np.complex64
+                pwr = (y.real * y.real + y.imag * y.imag)[:orc.num_lags]
+                c = cells[d + orc.dmax]
+                tot = np.cumsum(pwr, dtype=np.float32)[-1]  # the reference's own float accumulation, lag by lag (:193)
+                assert abs(pwr.max() / c["max_pwr"] - 1) < 3e-6 and abs(float(tot) / c["tot_pwr"] - 1) < 3e-6
+                snr = pwr.max() / (tot / np.float32(orc.num_lags))
+                assert abs(snr / c["snr"] - 1) < 3e-6
+                assert int(pwr.argmax()) == c["max_i"] or abs(pwr[c["max_i"]] / pwr.max() - 1) < 1e-5
