@@ -208,6 +208,12 @@ def test_cli_iq8_input_equals_preconverted_1bit(tmp_path):
         assert a.returncode == 0 and b.returncode == 0, a.stderr + b.stderr
         assert a.stdout == b.stdout
         assert a.stdout.startswith(BANNER) and a.stdout.count("satellite:") == 2 and a.stdout.endswith("run out of file!\n")
+        # the capture's mean from the host threads (default) and from the GPU pass are the same integers
+        c = subprocess.run([GPS_TEST, f_iq] + args, capture_output=True, text=True, timeout=300,
+                           env=dict(env, GPSACQ_INPUT="iq_u8", GPSACQ_MIX_HZ="0.62e6", GPSACQ_SUMS_ON_GPU="1"))
+        d = subprocess.run([GPS_TEST, f_iq] + args, capture_output=True, text=True, timeout=300,
+                           env=dict(env, GPSACQ_INPUT="iq_u8", GPSACQ_MIX_HZ="0.62e6", GPSACQ_SUM_THREADS="3"))
+        assert c.returncode == 0 and d.returncode == 0 and c.stdout == b.stdout and d.stdout == b.stdout
         assert "gpsacq trace" in b.stderr and "input iq_u8" in b.stderr
     # PRN 5 (index 4) is a hit in both runs
     lines = a.stdout[len(BANNER):].split("\n")
