@@ -30,6 +30,8 @@
 //                           is, no LO; FC is not used and GPSACQ_MIX_HZ, if set, turns the samples by that frequency first
 //   GPSACQ_SUM_THREADS=<n>  IQ input: host threads that sum the capture for its mean (default 8, at most the cores present);
 //   GPSACQ_SUMS_ON_GPU=1    ... or read the file through a buffer and sum it on the GPU (the fallback when it cannot be mapped)
+//   GPSACQ_NO_MMAP=1        read the capture with fread only (what happens anyway when it is not a regular file); by default it is
+//                           mapped and the batches are copied into the staging buffers by GPSACQ_SUM_THREADS threads
 //   GPSACQ_TRACE=1          wall-clock split of SearchInit / SearchTask on stderr
 #include <sys/mman.h>
 
@@ -172,19 +174,35 @@ __attribute__((optimize("O3", "tree-vectorize"))) static void iq_sums_range(cons
     out[0] = si;
     out[1] = sq;
 }
-static bool iq_sums_mapped(FILE *fp, uint64_t n_pairs, int is_signed, int64_t sums[2]) {
-    const size_t len = (size_t)n_pairs * 2;
-    void *map = mmap(NULL, len, PROT_READ, MAP_SHARED, fileno(fp), 0);
-    if (map == MAP_FAILED) return false;
-    (void)madvise(map, len, MADV_SEQUENTIAL);
+static int host_threads(uint64_t items_of_work) {
     unsigned hw = std::thread::hardware_concurrency();
     const int want = env_int("GPSACQ_SUM_THREADS", 8);
     int nt = want < 1 ? 1 : want;
     if (hw > 0 && (unsigned)nt > hw) nt = (int)hw;
-    if ((uint64_t)nt > n_pairs / 65536 + 1) nt = (int)(n_pairs / 65536 + 1);
+    if ((uint64_t)nt > items_of_work + 1) nt = (int)(items_of_work + 1);
+    return nt;
+}
+// a batch of an 8-bit IQ file is tens of megabytes: copied from the mapped file into the pinned staging buffer by a few threads
+// (one thread's fread moves ~9 GB/s, which left the GPU waiting for the file)
+static void copy_parallel(unsigned char *dst, const unsigned char *src, size_t n) {
+    const int nt = host_threads(n >> 22);  // a thread per 4 MB at least
+    if (nt <= 1) {
+        memcpy(dst, src, n);
+        return;
+    }
+    std::vector<std::thread> workers;
+    for (int t = 1; t < nt; t++)
+        workers.emplace_back([=] {
+            const size_t a = n * (size_t)t / (size_t)nt, b = n * (size_t)(t + 1) / (size_t)nt;
+            memcpy(dst + a, src + a, b - a);
+        });
+    memcpy(dst, src, n / (size_t)nt);
+    for (std::thread &w : workers) w.join();
+}
+static bool iq_sums_mapped(const unsigned char *base, uint64_t n_pairs, int is_signed, int64_t sums[2]) {
+    const int nt = host_threads(n_pairs / 65536);
     std::vector<int64_t> part((size_t)nt * 2, 0);
     std::vector<std::thread> workers;
-    const unsigned char *base = (const unsigned char *)map;
     for (int t = 1; t < nt; t++)
         workers.emplace_back([&, t] {
             const uint64_t a = n_pairs * (uint64_t)t / (uint64_t)nt, b = n_pairs * (uint64_t)(t + 1) / (uint64_t)nt;
@@ -197,7 +215,6 @@ static bool iq_sums_mapped(FILE *fp, uint64_t n_pairs, int is_signed, int64_t su
         sums[0] += part[(size_t)t * 2];
         sums[1] += part[(size_t)t * 2 + 1];
     }
-    munmap(map, len);
     return true;
 }
 
@@ -217,6 +234,30 @@ void SearchTask(char *filename_1bit_bin) {
     }
     const bool trace = env_int("GPSACQ_TRACE", 0) != 0;
     double ms_sums = 0, ms_read = 0, ms_submit = 0, ms_wait = 0, ms_print = 0;
+    // the capture mapped read-only when it can be (a regular file): the IQ mean and the batch copies then run on several threads;
+    // otherwise (a pipe, GPSACQ_NO_MMAP=1) everything goes through fread as before
+    struct Mapping {  // unmapped on every way out of this function
+        const unsigned char *p = NULL;
+        size_t len = 0;
+        ~Mapping() {
+            if (p) munmap((void *)p, len);
+        }
+    } mapping;
+    size_t map_pos = 0;
+    if (env_int("GPSACQ_NO_MMAP", 0) == 0 && fseek(fp, 0, SEEK_END) == 0) {
+        const long long fsize = ftell(fp);
+        fseek(fp, 0, SEEK_SET);
+        if (fsize > 0) {
+            void *m = mmap(NULL, (size_t)fsize, PROT_READ, MAP_SHARED, fileno(fp), 0);
+            if (m != MAP_FAILED) {
+                mapping.p = (const unsigned char *)m;
+                mapping.len = (size_t)fsize;
+                (void)madvise(m, mapping.len, MADV_SEQUENTIAL);
+            }
+        }
+    }
+    const unsigned char *const map = mapping.p;
+    const size_t map_len = mapping.len;
 
     // ---- input format -------------------------------------------------------------------------------------------
     const char *fmt = getenv("GPSACQ_INPUT");
@@ -255,7 +296,7 @@ void SearchTask(char *filename_1bit_bin) {
         iqin.total_samples = (uint64_t)(fsize / 2);
         if (iqin.remove_dc && iqin.total_samples > 0) {
             int64_t sums[2] = {0, 0};
-            const bool mapped = env_int("GPSACQ_SUMS_ON_GPU", 0) == 0 && iq_sums_mapped(fp, iqin.total_samples, iqin.format == GPSACQ_IQ_S8, sums);
+            const bool mapped = map && env_int("GPSACQ_SUMS_ON_GPU", 0) == 0 && iq_sums_mapped(map, iqin.total_samples, iqin.format == GPSACQ_IQ_S8, sums);
             std::vector<unsigned char> chunk(mapped ? 0 : (size_t)64 << 20);
             uint64_t left = mapped ? 0 : iqin.total_samples;
             while (left > 0) {
@@ -333,7 +374,14 @@ void SearchTask(char *filename_1bit_bin) {
                 break;
             }
             Clock::time_point t0 = Clock::now();
-            const size_t got = read_fully(fp, buf, want);
+            size_t got;
+            if (map) {
+                got = map_len - map_pos < want ? map_len - map_pos : want;
+                copy_parallel(buf, map + map_pos, got);
+                map_pos += got;
+            } else {
+                got = read_fully(fp, buf, want);
+            }
             ms_read += ms_since(t0);
             if (got < want) eof = true;
             // a run is complete when all 32 of its Sample() calls got their 10 x 512 bytes (:135-140,239-244)

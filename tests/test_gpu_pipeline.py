@@ -214,6 +214,10 @@ def test_cli_iq8_input_equals_preconverted_1bit(tmp_path):
         d = subprocess.run([GPS_TEST, f_iq] + args, capture_output=True, text=True, timeout=300,
                            env=dict(env, GPSACQ_INPUT="iq_u8", GPSACQ_MIX_HZ="0.62e6", GPSACQ_SUM_THREADS="3"))
         assert c.returncode == 0 and d.returncode == 0 and c.stdout == b.stdout and d.stdout == b.stdout
+        # ... and the capture read with fread only (no mapping) gives the same report, IQ and 1-bit
+        for f_in, extra, ref in ((f_iq, dict(GPSACQ_INPUT="iq_u8", GPSACQ_MIX_HZ="0.62e6"), b), (f_bits, {}, a)):
+            n = subprocess.run([GPS_TEST, f_in] + args, capture_output=True, text=True, timeout=300, env=dict(env, GPSACQ_NO_MMAP="1", **extra))
+            assert n.returncode == 0 and n.stdout == ref.stdout
         assert "gpsacq trace" in b.stderr and "input iq_u8" in b.stderr
     # PRN 5 (index 4) is a hit in both runs
     lines = a.stdout[len(BANNER):].split("\n")
