@@ -27,6 +27,15 @@ Other configurations (the default line stays the one the driver records):
   --capture F  search the 1-bit capture file F (e.g. gps.samples.1bit.I.fs5456.if4092.bin) instead of
                synthetic data: whole runs of the file, same schedule, and the SearchTask report's hit list
 
+At N = 1 the process still joins a ONE-RANK `nccl` (= RCCL) process group by default, so the collective code of the N > 1
+runs -- the per-step all-reduce(MAX) of the packed keys on torch's stream, `dist.barrier()` in the fences, the device-side
+all-reduce of the elapsed time -- executes on every run of this file (`dist_backend: "nccl"`, `rccl_ranks_seen: 1`);
+`--no-dist` skips it, `--force-dist` makes a failure to create the group fatal instead of falling back.
+
+After the K timed steps a `soak` leg repeats the same step until >= 6 s of GPU time have passed (reported separately; `steps`
+and `ms_per_step` are untouched) with one sclk / package-power sample taken in mid-leg, so that a coarse SMI sampler beside
+the run sees the GPU busy at the rate the line claims.
+
 `--gpus N` with N > 1 and no WORLD_SIZE in the environment re-launches itself under torch.distributed.run with N ranks
 (so a plain `python bench.py --gpus 8` cannot silently measure one GPU); fewer than N visible devices is an error.
 """
@@ -97,6 +106,59 @@ def hbm_copy_gbs(torch, dev, nbytes=1 << 30, reps=5):
     return 2.0 * nbytes * reps / (e0.elapsed_time(e1) * 1e-3) / 1e9
 
 
+def smi_sample(dev_index=0):
+    """One sclk / package power / junction temperature reading of the GPU (rocm-smi; best effort -- None fields when the tool
+    or a field is missing)."""
+    import re
+    import subprocess
+    out = {"sclk_mhz": None, "power_w": None, "junction_c": None}
+    try:
+        r = subprocess.run(["rocm-smi", "-d", str(dev_index), "--showpower", "--showclocks", "--showtemp"], capture_output=True, text=True, timeout=20)
+        for ln in r.stdout.splitlines():
+            m = re.search(r"sclk clock level.*\((\d+)Mhz\)", ln)
+            if m:
+                out["sclk_mhz"] = int(m.group(1))
+            m = re.search(r"Power \(W\):\s*([0-9.]+)", ln)
+            if m:
+                out["power_w"] = float(m.group(1))
+            m = re.search(r"junction\).*:\s*([0-9.]+)", ln)
+            if m:
+                out["junction_c"] = float(m.group(1))
+    except Exception as ex:
+        out["error"] = str(ex)[:100]
+    return out
+
+
+def soak(leg, cells_job, min_gpu_s=6.0, max_steps=2000):
+    """The timed step again until >= min_gpu_s of GPU time: steps are enqueued in slices (the engine's stream is the clock:
+    the wall time of a slice that ends in a synchronize), an SMI reading is taken from a thread in mid-leg."""
+    import threading
+    readings = []
+    th = None
+    done_s, steps, slices = 0.0, 0, []
+    while done_s < min_gpu_s and steps < max_steps:
+        n = 20
+        leg.fence()
+        t0 = time.perf_counter()
+        for _ in range(n):
+            leg.step()
+        if th is None and done_s >= 0.25 * min_gpu_s:  # GPU queue is full for the next ~n steps: read clocks / power now
+            th = threading.Thread(target=lambda: readings.append(smi_sample(leg.dev.index or 0)))
+            th.start()
+        leg.fence()
+        dt = time.perf_counter() - t0
+        slices.append(1e3 * dt / n)
+        done_s += dt
+        steps += n
+    if th is not None:
+        th.join()
+    ms = 1e3 * done_s / max(steps, 1)
+    return {"steps": steps, "seconds": done_s, "ms_per_step": ms, "cells_per_s": cells_job / (ms * 1e-3) if ms else None,
+            "ms_per_step_slices_min_max": [min(slices), max(slices)] if slices else None,
+            "smi_mid_leg": readings[0] if readings else None,
+            "note": "same step as the timed region, repeated after it; reported separately, `steps`/`ms_per_step`/`value` are the K timed steps"}
+
+
 def cpu_baseline(cfg, bits, ndop, target_s=12.0):
     """The oracle's float build (own mixed-radix FFT; `port`) timed single-threaded on a bounded sample of the
     same capture.  The reference binary itself cannot run on the GPU box (it needs FFTW; oracle/_ref/README)."""
@@ -111,7 +173,10 @@ def cpu_baseline(cfg, bits, ndop, target_s=12.0):
     dt = time.perf_counter() - t0
     return {"value": cells / dt, "unit": "cells/s", "cores": 1, "kind": "port",
             "sample": f"{nblk} blocks x {ndop} bins = {cells} cells of the same capture, oracle f32 build (own FFT, -O3), "
-                      f"{dt:.1f} s on {os.cpu_count()} core host ({cpu_model()}), 1 thread"}
+                      f"{dt:.1f} s on {os.cpu_count()} core host ({cpu_model()}), 1 thread",
+            "context": "the reference itself needs FFTW3f, absent from this image and from the GPU box (oracle/_ref unbuildable); the survey "
+                       "timed the reference's sources against an MKL FFT stand-in at 3.2-5.7 k cells/s per core of a 2.1 GHz Xeon (BASELINE.md "
+                       "section 2; SURVEY.md section 8d) -- the same range as this port, so the port is a fair stand-in for the reference's CPU rate"}
 
 
 def cpu_baseline_reference(cfg, bits, ndop, target_s=15.0):
@@ -329,6 +394,9 @@ def main():
     ap.add_argument("--input", choices=["bits", "iq8"], default="bits",
                     help="iq8: an 8-bit IQ capture (uint8, offset 128) converted inside the forward transform (configs 1-3 schedules)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-dist", action="store_true", help="N = 1: do not create the one-rank nccl process group")
+    ap.add_argument("--force-dist", action="store_true", help="N = 1: the one-rank nccl group must come up (no fallback)")
+    ap.add_argument("--soak-seconds", type=float, default=6.0, help="GPU time of the soak leg after the timed steps (0: skip)")
     ap.add_argument("--no-e2e", action="store_true", help="skip the gps_test end-to-end leg")
     ap.add_argument("--spawn-check", action="store_true",
                     help="launcher check without a GPU: every rank joins a gloo group, rank 0 prints the ranks it saw, all exit")
@@ -384,12 +452,37 @@ def main():
         raise SystemExit(f"rank {rank}: device {dev_index} not visible ({torch.cuda.device_count()} device(s), --gpus {args.gpus})")
     torch.cuda.set_device(dev_index)
     dist = None
+    dist_note = None
     if world > 1:
         import torch.distributed as dist
         if backend == "nccl":
             dist.init_process_group(backend="nccl", device_id=torch.device("cuda", dev_index))
         else:
             dist.init_process_group(backend=backend)
+    elif not args.no_dist and backend == "nccl":
+        # N = 1: a one-rank RCCL group, so that every collective line of the N > 1 runs executes here too
+        import socket
+        import torch.distributed as dist
+        try:
+            if "MASTER_ADDR" not in os.environ or "MASTER_PORT" not in os.environ:
+                with socket.socket() as sk:
+                    sk.bind(("127.0.0.1", 0))
+                    os.environ["MASTER_PORT"] = str(sk.getsockname()[1])
+                os.environ["MASTER_ADDR"] = "127.0.0.1"
+            dist.init_process_group(backend="nccl", rank=0, world_size=1, device_id=torch.device("cuda", dev_index))
+            probe = torch.ones(1, dtype=torch.int64, device=torch.device("cuda", dev_index))
+            dist.all_reduce(probe, op=dist.ReduceOp.MAX)  # the communicator is created lazily: bring it up before anything is timed
+            torch.cuda.synchronize()
+        except Exception as ex:
+            if args.force_dist:
+                raise
+            dist_note = f"one-rank nccl group unavailable ({str(ex)[:160]}): ran without a process group"
+            try:
+                if dist.is_initialized():
+                    dist.destroy_process_group()
+            except Exception:
+                pass
+            dist = None
 
     ranks_seen = dist.get_world_size() if dist is not None else 1
     if ranks_seen != args.gpus:
@@ -527,6 +620,10 @@ def main():
     elapsed, kern_ms, best = leg.run(args.steps, args.warmup)
     timing = eng.last_timing() if n_tasks > 0 else None
 
+    soak_leg = None
+    if args.soak_seconds > 0 and world == 1 and n_tasks > 0:
+        soak_leg = soak(leg, cells_job, args.soak_seconds)
+
     weak = None
     if iq8:
         weak_blocks = 0
@@ -578,7 +675,7 @@ def main():
             "config": {"workload": workload, "fs_hz": fs, "if_hz": cfg["fc"], "blocks_rank0": nblk,
                        "cells_per_step_rank0": cells_rank, "cells_per_step_job": cells_job, "parallelism": parallelism,
                        "input": "8-bit IQ (uint8 offset 128), converted inside the forward transform" if iq8 else "1-bit real IF"},
-            "rccl_ranks_seen": ranks_seen, "dist_backend": (backend if world > 1 else None),
+            "rccl_ranks_seen": ranks_seen, "dist_backend": (backend if dist is not None else None), "dist_note": dist_note,
             ("tasks_per_rank" if grid else "blocks_per_rank"): blocks_per_rank,
             # What binds k_corr is the fp32 vector pipe, not HBM: the fused kernel keeps the IFFT intermediate in LDS
             # and reads both spectra from L2, so the algorithmic bytes of SURVEY 8(d) never reach HBM.
@@ -598,6 +695,8 @@ def main():
             "stage_ms": {k: timing[k] for k in ("ms_total", "ms_sample", "ms_correlate", "ms_peaks")} if timing else None,
             "device": eng.device_name,
         }
+        if soak_leg is not None:
+            out["soak"] = soak_leg
         if weak is not None:
             out["weak_scaling"] = weak
         if iq8 and leg.sample_ms:

@@ -468,6 +468,7 @@ __global__ void k_merge_cells(const Cell* parts, Cell* cells, size_t n_cells, in
 // thread t scans lags t, t + 256, ... ascending with a strict '>', the partial results merge with "higher power, ties to the
 // lower lag" -- the first maximum, like the serial scan.
 __global__ __launch_bounds__(256) void k_scan_power(const float* __restrict__ pdump, Cell* cells, int nlags) {
+    if (cells[blockIdx.x].max_i < 0) return;  // a task k_corr rejected (cells were zeroed before the passes): keep its marker
     const float* p = pdump + (size_t)blockIdx.x * nlags;
     float mx = 0.f, sum = 0.f;
     int mi = 0;

@@ -135,6 +135,7 @@ struct Capture {
 };
 
 static const size_t kFwdChunk = 32768;  // blocks per forward-transform launch (grid.y bound)
+static const size_t kPdumpBytes = (size_t)1 << 30;  // per-lag power sums of the multi-pass re-alignment path, per chunk of tasks
 
 // Scratch buffers grow on demand, stream-ordered (hipFreeAsync / hipMallocAsync on the engine's stream): work already
 // enqueued keeps the old buffer until it has run, and no device-wide synchronisation happens in mid-stream.  They grow by at
@@ -160,6 +161,7 @@ static int ensure_code_slots(gpsacq_engine* e, size_t n_patch) {
     HIPCHK(hipFree(e->d_code));
     e->d_code = nd;
     e->patch_cap = 0;
+    e->sched_valid = false;  // the cached default schedule's patch list lived in the buffer freed below
     if (e->d_patch_blocks) HIPCHK(hipFree(e->d_patch_blocks));
     e->d_patch_blocks = nullptr;
     HIPCHK(hipMalloc((void**)&e->d_patch_blocks, n_patch * sizeof(int32_t)));
@@ -263,7 +265,7 @@ extern "C" int gpsacq_create(const gpsacq_params* params, gpsacq_engine** out) {
         std::vector<uint32_t> chips;
     };
     const gpsacq_params prm = *params;
-    std::future<std::unique_ptr<HostPrep>> prep_job = std::async(std::launch::async, [prm]() {
+    auto host_prep = [prm]() {
         std::unique_ptr<HostPrep> h(new HostPrep());
         forward_tables(1, h->tn, h->rot8);
         h->cosm.resize(BLOCK_BYTES);
@@ -284,7 +286,14 @@ extern "C" int gpsacq_create(const gpsacq_params* params, gpsacq_engine** out) {
             }
         }
         return h;
-    });
+    };
+    // the worker starts BEFORE the first HIP call: the runtime's start-up is what it hides behind (an early return below waits
+    // the 15-20 ms the tables take -- a delay, nothing else)
+    std::future<std::unique_ptr<HostPrep>> prep_job;
+    try {
+        prep_job = std::async(std::launch::async, host_prep);
+    } catch (const std::exception&) {  // no thread to be had (std::system_error): the tables are computed inline below; nothing crosses the C ABI
+    }
     (void)hipGetLastError();  // HIP's last-error slot is sticky: do not inherit an earlier, unrelated failure of this thread
     int ndev = 0;
     hipError_t he = hipGetDeviceCount(&ndev);
@@ -330,7 +339,7 @@ extern "C" int gpsacq_create(const gpsacq_params* params, gpsacq_engine** out) {
     const double ms_before_prep = lap();
     std::unique_ptr<HostPrep> hp;
     try {
-        hp = prep_job.get();
+        hp = prep_job.valid() ? prep_job.get() : host_prep();
     } catch (const std::exception& ex) {  // nothing may cross the C ABI as an exception
         int rc_ = fail(GPSACQ_ERR_NOMEM, "host table preparation failed: %s", ex.what());
         gpsacq_destroy(e);
@@ -447,11 +456,41 @@ static void launch_patches(gpsacq_engine* e, size_t n_patch, const uint8_t* d_bi
     qa.halo = e->halo;
     launch_quirk_patch(qa, (int)n_patch, e->stream);
 }
+// The reference schedule for n_tasks tasks, uploaded and marked cached.  Every buffer it lives in (d_tasks, d_patch_blocks) is
+// written here after any reallocation, and whoever else reallocates one of them (grow of d_tasks for a user task list,
+// ensure_code_slots) clears sched_valid -- a cached schedule never points at memory that was not filled.
+static int build_default_schedule(gpsacq_engine* e, size_t n_tasks) {
+    const bool quirks = e->p.ref_quirks != 0;
+    e->sched_valid = false;
+    if (int rc = grow(e->d_tasks, e->task_cap, n_tasks, e->stream)) return rc;
+    std::vector<Task> tk(n_tasks);
+    std::vector<int32_t> patch_blocks;
+    for (size_t t = 0; t < n_tasks; ++t) {
+        tk[t].spec = (int32_t)t;
+        tk[t].code = (int32_t)(t % GPSACQ_NUM_SATS);
+        if (quirks && tk[t].code == 0) {
+            tk[t].code = GPSACQ_NUM_SATS + (int32_t)patch_blocks.size();
+            patch_blocks.push_back((int32_t)t);
+        }
+    }
+    if (!patch_blocks.empty()) {
+        if (int rc = ensure_code_slots(e, patch_blocks.size())) return rc;
+        HIPCHK(hipMemcpyAsync(e->d_patch_blocks, patch_blocks.data(), patch_blocks.size() * sizeof(int32_t), hipMemcpyHostToDevice, e->stream));
+    }
+    HIPCHK(hipMemcpyAsync(e->d_tasks, tk.data(), n_tasks * sizeof(Task), hipMemcpyHostToDevice, e->stream));
+    HIPCHK(hipStreamSynchronize(e->stream));  // tk / patch_blocks go out of scope
+    e->sched_valid = true;
+    e->sched_tasks = n_tasks;
+    return GPSACQ_OK;
+}
 static int prepare_tasks(gpsacq_engine* e, const gpsacq_task* h_tasks, const void* d_user_tasks, size_t n_blocks,
                          size_t n_tasks, const uint8_t* d_bits, size_t stride) {
     const bool quirks = e->p.ref_quirks != 0;
     const bool deflt = !h_tasks && !d_user_tasks;
-    if (deflt && e->sched_valid && n_tasks <= e->sched_tasks && e->n_acc == 1) {  // cached (a prefix is the same schedule)
+    if (deflt && e->n_acc == 1) {  // cached on the device (a prefix of a longer one is the same schedule)
+        if (n_tasks > n_blocks) return fail(GPSACQ_ERR_ARG, "reference schedule: %zu tasks but %zu blocks", n_tasks, n_blocks);
+        if (!(e->sched_valid && n_tasks <= e->sched_tasks))
+            if (int rc = build_default_schedule(e, n_tasks)) return rc;
         if (quirks) launch_patches(e, (n_tasks + GPSACQ_NUM_SATS - 1) / GPSACQ_NUM_SATS, d_bits, stride);
         return GPSACQ_OK;
     }
@@ -491,10 +530,6 @@ static int prepare_tasks(gpsacq_engine* e, const gpsacq_task* h_tasks, const voi
     }
     HIPCHK(hipMemcpyAsync(e->d_tasks, tk.data(), n_tasks * sizeof(Task), hipMemcpyHostToDevice, e->stream));
     HIPCHK(hipStreamSynchronize(e->stream));  // tk / patch_blocks go out of scope
-    if (deflt && e->n_acc == 1) {
-        e->sched_valid = true;
-        e->sched_tasks = n_tasks;
-    }
     return GPSACQ_OK;
 }
 
@@ -519,7 +554,10 @@ static int search_core(gpsacq_engine* e, const Capture& cap_in, size_t n_blocks,
         }
         if (e->p.ref_quirks) {
             // the quirk patch reads the 960 samples past each block from a 1-bit stream: convert first (same arithmetic,
-            // iq_convert.hpp), then search the bits -- the un-fused route, kept for this one mode
+            // iq_convert.hpp), then search the bits -- the un-fused route, kept for this one mode.  All 40960 samples of a
+            // Sample() call are read per block: checked BEFORE the conversion is enqueued (it would read past a short upload)
+            if (cap.stride < (size_t)BLOCK_BYTES * 16)
+                return fail(GPSACQ_ERR_ARG, "ref_quirks needs all 40960 samples of a block: 8-bit IQ stride %zu < 81920 bytes", cap.stride);
             const size_t n_samples = (n_blocks - 1) * (cap.stride / 2) + (size_t)BLOCK_BYTES * 8;
             if (int rc = grow(e->d_iqbits, e->iqbits_cap, (n_samples + 7) / 8, e->stream)) return rc;
             IqConv cv = cap.iq;
@@ -622,17 +660,29 @@ static int search_core(gpsacq_engine* e, const Capture& cap_in, size_t n_blocks,
     } else if (realign) {
         // re-aligned lags cross the passes' column windows: the per-lag sums of every cell go to device memory (nlags floats per
         // cell), every pass adds its window's powers at their re-aligned lags, one scan per cell at the end
-        const size_t n_cells = n_tasks * (size_t)e->ndop;
-        if (int rc = grow(e->d_pdump, e->pdump_cap, n_cells * (size_t)e->nlags, e->stream)) return rc;
-        HIPCHK(hipMemsetAsync(e->d_pdump, 0, n_cells * (size_t)e->nlags * sizeof(float), e->stream));
+        // The tasks are taken in chunks so that the sums stay within kPdumpBytes (1 GB: 32 tasks x 201 points x 16368 lags are
+        // 0.4 GB, a 2048-task batch would otherwise ask for 27 GB); a single task's points always go together.
+        const size_t per_task = (size_t)e->ndop * (size_t)e->nlags;
+        const size_t chunk_tasks = std::max<size_t>(1, std::min(n_tasks, kPdumpBytes / sizeof(float) / per_task));
+        if (int rc = grow(e->d_pdump, e->pdump_cap, chunk_tasks * per_task, e->stream)) return rc;
         if (e->creep_comp) ca.creep = (float)((double)e->acc_step * block_samples * (e->p.fs / N_FFT * e->dstride / e->sub) / 1575.42e6);
         ca.pdump = e->d_pdump;
-        for (int p = 0; p < n_pass; ++p) {
-            ca.m0 = p * MC_MAX;
-            const int mc = pass_columns(n_cols, p);
-            if (launch_corr(ca, mc, e->stream) != 0) return fail(GPSACQ_ERR_UNSUPPORTED, "no correlate kernel for %d columns", mc);
+        // cells start as zeros: a task the kernel rejects (device task list out of range) leaves max_i = -1 there, which the
+        // scan keeps -- the marker every other path reports
+        HIPCHK(hipMemsetAsync(d_cells, 0, n_tasks * (size_t)e->ndop * sizeof(Cell), e->stream));
+        for (size_t t0 = 0; t0 < n_tasks; t0 += chunk_tasks) {
+            const size_t cnt = std::min(chunk_tasks, n_tasks - t0);
+            HIPCHK(hipMemsetAsync(e->d_pdump, 0, cnt * per_task * sizeof(float), e->stream));
+            ca.tasks = e->d_tasks + t0;
+            ca.n_tasks = (int)cnt;
+            ca.cells = d_cells + t0 * (size_t)e->ndop;
+            for (int p = 0; p < n_pass; ++p) {
+                ca.m0 = p * MC_MAX;
+                const int mc = pass_columns(n_cols, p);
+                if (launch_corr(ca, mc, e->stream) != 0) return fail(GPSACQ_ERR_UNSUPPORTED, "no correlate kernel for %d columns", mc);
+            }
+            launch_scan_power(e->d_pdump, ca.cells, cnt * (size_t)e->ndop, e->nlags, e->stream);
         }
-        launch_scan_power(e->d_pdump, d_cells, n_cells, e->nlags, e->stream);
     } else {
         const size_t n_cells = n_tasks * (size_t)e->ndop;
         if (int rc = grow(e->d_parts, e->parts_cap, n_cells * (size_t)n_pass, e->stream)) return rc;
@@ -870,9 +920,15 @@ extern "C" int gpsacq_reserve(gpsacq_engine* e, size_t n_blocks) {
     HIPCHK(hipSetDevice(e->p.device));
     if (int rc = grow(e->d_dpp, e->dpp_cap, n_blocks * (size_t)e->sub, e->stream, (size_t)NPOLY * M_SUB * sizeof(cf))) return rc;
     if (int rc = grow(e->d_cells, e->cell_cap, n_blocks * (size_t)e->ndop, e->stream)) return rc;
-    if (int rc = grow(e->d_tasks, e->task_cap, n_blocks, e->stream)) return rc;
-    if (e->p.ref_quirks)
-        if (int rc = ensure_code_slots(e, (n_blocks + GPSACQ_NUM_SATS - 1) / GPSACQ_NUM_SATS)) return rc;
+    if (e->n_acc == 1) {
+        // the reference schedule for the largest batch, built once: every shorter batch (the front end's 1, 2, 4, ... run ramp)
+        // is a prefix of it and enqueues without waiting for the stream
+        if (!(e->sched_valid && n_blocks <= e->sched_tasks))
+            if (int rc = build_default_schedule(e, n_blocks)) return rc;
+    } else {
+        if (int rc = grow(e->d_tasks, e->task_cap, n_blocks, e->stream)) return rc;
+        e->sched_valid = false;  // (never valid in the non-coherent mode; the buffer may just have moved)
+    }
     return GPSACQ_OK;
 }
 

@@ -9,18 +9,32 @@
 // engine on one GPU no RCCL call is made at all (and RCCL is not even loaded) -- which is also how the N > 1 control flow
 // (partitions, per-engine buffers, merge, window restore) is tested on the one-GPU box.
 //
+// GPSACQ_MULTI_FORCE_RCCL=1 (read at gpsacq_multi_create) makes the communicator and the all-reduce happen whatever the
+// device list: with one distinct GPU that is ncclCommInitAll(1) and a one-rank ncclAllReduce inside ncclGroupStart/End --
+// the very calls an 8-GPU node makes, executed on the one-GPU box (tests/test_gpu_round4.py::test_rccl_single_rank_*).
+//
+// The caller's thread is not the critical path: each engine's share of a call -- staging copy of its part of the (pageable)
+// capture into its own pinned buffer, upload, search, key packing, download of its peaks into pinned memory -- is enqueued by
+// its own host thread, so device i + 1 is searching while device i's copy is still running (round 3 did all of it on one
+// thread through pageable hipMemcpyAsync, which blocks: every device waited for the ones before it).  gpsacq_multi_last_call_ms
+// reports how long the enqueue phase of the last call took on the host next to the whole call.
+//
 // RCCL is loaded with dlopen at the first gpsacq_multi_create so that libgpsacq.so carries no link dependency on it
 // (a process that already holds an RCCL -- PyTorch bundles one under the same SONAME -- keeps using that copy).
 #include <dlfcn.h>
 #include <hip/hip_runtime.h>
 #include <rccl/rccl.h>
 
+#include <algorithm>
+#include <chrono>
 #include <cstdarg>
 #include <cstdio>
-#include <algorithm>
+#include <cstdlib>
 #include <cstring>
 #include <mutex>
 #include <string>
+#include <system_error>
+#include <thread>
 #include <vector>
 
 #include "../../include/gpsacq.h"
@@ -98,6 +112,14 @@ struct gpsacq_multi {
     std::vector<float*> d_pwr;
     std::vector<float*> d_pwr_merged;
     std::vector<size_t> task_cap;
+    // pinned staging per engine: its share of the caller's capture on the way in, its peaks on the way out
+    std::vector<uint8_t*> h_bits;
+    std::vector<size_t> h_bits_cap;
+    std::vector<Peak*> h_peaks;
+    std::vector<size_t> h_peaks_cap;
+    bool force_rccl = false;         // GPSACQ_MULTI_FORCE_RCCL=1: communicator + all-reduce even with one distinct GPU
+    long rccl_allreduces = 0;        // ncclAllReduce calls issued so far (all ranks of a group count once)
+    double last_enqueue_ms = 0, last_total_ms = 0;
     gpsacq_info info{};
 };
 
@@ -119,6 +141,8 @@ extern "C" void gpsacq_multi_destroy(gpsacq_multi* m) {
         for (void* p : {(void*)m->d_bits[i], (void*)m->d_tasks[i], (void*)m->d_peaks[i], (void*)m->d_keys[i], (void*)m->d_merged[i],
                         (void*)m->d_pwr[i], (void*)m->d_pwr_merged[i]})
             if (p) (void)hipFree(p);
+        if (m->h_bits[i]) (void)hipHostFree(m->h_bits[i]);
+        if (m->h_peaks[i]) (void)hipHostFree(m->h_peaks[i]);
         gpsacq_destroy(m->eng[i]);
     }
     delete m;
@@ -144,6 +168,14 @@ extern "C" int gpsacq_multi_create(const gpsacq_params* params, const int32_t* d
     m->d_pwr.assign(n, nullptr);
     m->d_pwr_merged.assign(n, nullptr);
     m->task_cap.assign(n, 0);
+    m->h_bits.assign(n, nullptr);
+    m->h_bits_cap.assign(n, 0);
+    m->h_peaks.assign(n, nullptr);
+    m->h_peaks_cap.assign(n, 0);
+    {
+        const char* fr = getenv("GPSACQ_MULTI_FORCE_RCCL");
+        m->force_rccl = fr && *fr && atoi(fr) != 0;
+    }
     for (size_t i = 0; i < n; ++i) {
         m->dev[i] = devices ? devices[i] : (int)i;
         m->rep[i] = (int)i;
@@ -168,7 +200,7 @@ extern "C" int gpsacq_multi_create(const gpsacq_params* params, const int32_t* d
             return rc;
         }
     }
-    if (m->reps.size() > 1) {  // one communicator rank per distinct GPU
+    if (m->reps.size() > 1 || m->force_rccl) {  // one communicator rank per distinct GPU
         if (const char* why = load_rccl()) {
             int rc = failf(GPSACQ_ERR_DEVICE, "RCCL unavailable: %s", why);
             gpsacq_multi_destroy(m);
@@ -244,6 +276,61 @@ void drain(gpsacq_multi* m) {
         (void)hipStreamSynchronize((hipStream_t)gpsacq_stream(m->eng[i]));
     }
 }
+// pinned staging of engine i (host side of its uploads / downloads); calls are synchronous, so nothing is in flight when one grows
+int grow_pinned(gpsacq_multi* m, size_t i, size_t nbytes, size_t n_peaks) {
+    if (nbytes > m->h_bits_cap[i]) {
+        if (m->h_bits[i]) HIPM(hipHostFree(m->h_bits[i]));
+        m->h_bits[i] = nullptr;
+        m->h_bits_cap[i] = 0;
+        const size_t want = std::max(nbytes, (size_t)1 << 16);
+        HIPM(hipHostMalloc((void**)&m->h_bits[i], want, hipHostMallocDefault));
+        m->h_bits_cap[i] = want;
+    }
+    if (n_peaks > m->h_peaks_cap[i]) {
+        if (m->h_peaks[i]) HIPM(hipHostFree(m->h_peaks[i]));
+        m->h_peaks[i] = nullptr;
+        m->h_peaks_cap[i] = 0;
+        const size_t want = std::max(n_peaks, (size_t)1024);
+        HIPM(hipHostMalloc((void**)&m->h_peaks[i], want * sizeof(Peak), hipHostMallocDefault));
+        m->h_peaks_cap[i] = want;
+    }
+    return GPSACQ_OK;
+}
+// body(i) for every engine, each on its own host thread with that engine's device current (engine 0 on the calling thread):
+// an engine is only ever touched by its own thread, gpsacq_last_error() is per thread, so the first failure's text is carried
+// back to the caller's.  Threads that cannot be had (std::system_error) run inline -- slower, never wrong.
+template <class F>
+int for_each_engine(gpsacq_multi* m, F&& body) {
+    const size_t n = m->eng.size();
+    std::vector<int> rcs(n, GPSACQ_OK);
+    std::vector<std::string> errs(n);
+    auto run = [&](size_t i) {
+        int rc;
+        const hipError_t he = hipSetDevice(m->dev[i]);
+        if (he != hipSuccess) rc = failf(GPSACQ_ERR_DEVICE, "hipSetDevice(%d): %s", m->dev[i], hipGetErrorString(he));
+        else rc = body(i);
+        rcs[i] = rc;
+        if (rc) errs[i] = gpsacq_last_error();
+    };
+    std::vector<std::thread> workers;
+    size_t threaded = 0;  // engines 1 .. threaded have a worker
+    try {
+        for (size_t i = 1; i < n; ++i) {
+            workers.emplace_back(run, i);
+            threaded = i;
+        }
+    } catch (const std::system_error&) {
+    }
+    run(0);
+    for (size_t i = threaded + 1; i < n; ++i) run(i);
+    for (std::thread& w : workers) w.join();
+    for (size_t i = 0; i < n; ++i)
+        if (rcs[i]) return acq::set_last_error(rcs[i], errs[i].c_str());
+    return GPSACQ_OK;
+}
+typedef std::chrono::steady_clock MClock;
+double ms_since(MClock::time_point t0) { return std::chrono::duration<double, std::milli>(MClock::now() - t0).count(); }
+
 // MAX-merge of one array per engine (64-bit keys, or float powers): engines of one GPU merge into their representative on
 // the device, the representatives all-reduce over RCCL (the path's one exchange step between GPUs), and every engine gets
 // the result back.  buf[i]: engine i's array (in: own values, out: merged), `count` entries.
@@ -265,8 +352,9 @@ int merge_max(gpsacq_multi* m, const std::vector<T*>& buf, size_t count) {
         launch_max(buf[r], buf[j], stream(r));
         HIPM(hipGetLastError());
     }
-    // 2. across GPUs
-    if (m->reps.size() > 1) {
+    // 2. across GPUs (a one-rank group when GPSACQ_MULTI_FORCE_RCCL made a communicator for a single GPU)
+    if (m->comm[(size_t)m->reps[0]]) {
+        ++m->rccl_allreduces;
         ncclResult_t r = g_rccl.GroupStart();
         if (r != ncclSuccess) return failf(GPSACQ_ERR_DEVICE, "ncclGroupStart: %s", g_rccl.GetErrorString(r));
         ncclResult_t first_bad = ncclSuccess;
@@ -331,19 +419,24 @@ void unpack_key(unsigned long long k, float pwr, int kmax, gpsacq_peak* p) {
 
 static int search_grid_impl(gpsacq_multi* m, const uint8_t* bits, size_t n_blocks, size_t stride, const gpsacq_task* tasks,
                             size_t n_tasks, gpsacq_peak* peaks) {
+    const MClock::time_point t_call = MClock::now();
     const size_t n = m->eng.size();
     const size_t nbytes = (n_blocks - 1) * stride + (stride < (size_t)GPSACQ_BLOCK_BYTES ? stride : (size_t)GPSACQ_BLOCK_BYTES);
     const int total = m->info.num_doppler_total, first = m->info.first_doppler_total, kmax = -first;
-    for (size_t i = 0; i < n; ++i) {
+    const int rc_enq = for_each_engine(m, [&](size_t i) -> int {
         // contiguous, balanced slab of the grid for device i (possibly empty when there are more devices than points)
         const int base = total / (int)n, rem = total % (int)n;
         const int cnt = base + ((int)i < rem ? 1 : 0), off = (int)i * base + ((int)i < rem ? (int)i : rem);
-        HIPM(hipSetDevice(m->dev[i]));
         hipStream_t st = (hipStream_t)gpsacq_stream(m->eng[i]);
         if (int rc = grow_dev(m, i, nbytes, n_tasks)) return rc;
         if (cnt > 0) {
-            HIPM(hipMemcpyAsync(m->d_bits[i], bits, nbytes, hipMemcpyHostToDevice, st));
-            HIPM(hipMemcpyAsync(m->d_tasks[i], tasks, n_tasks * sizeof(Task), hipMemcpyHostToDevice, st));
+            // capture and task list through this engine's pinned staging (tasks behind the capture, 16-byte aligned)
+            const size_t task_off = (nbytes + 15) & ~(size_t)15;
+            if (int rc = grow_pinned(m, i, task_off + n_tasks * sizeof(Task), 0)) return rc;
+            memcpy(m->h_bits[i], bits, nbytes);
+            memcpy(m->h_bits[i] + task_off, tasks, n_tasks * sizeof(Task));
+            HIPM(hipMemcpyAsync(m->d_bits[i], m->h_bits[i], nbytes, hipMemcpyHostToDevice, st));
+            HIPM(hipMemcpyAsync(m->d_tasks[i], m->h_bits[i] + task_off, n_tasks * sizeof(Task), hipMemcpyHostToDevice, st));
             if (int rc = gpsacq_set_doppler_window(m->eng[i], first + off, cnt)) return rc;
             if (int rc = gpsacq_search_device(m->eng[i], m->d_bits[i], n_blocks, stride, m->d_tasks[i], n_tasks, nullptr, m->d_peaks[i], 0)) return rc;
             launch_pack_keys(m->d_peaks[i], m->d_keys[i], (int)n_tasks, kmax, st);
@@ -353,8 +446,11 @@ static int search_grid_impl(gpsacq_multi* m, const uint8_t* bits, size_t n_block
             HIPM(hipMemsetAsync(m->d_keys[i], 0, n_tasks * sizeof(unsigned long long), st));  // key 0 = "nothing found": neutral for MAX
             HIPM(hipMemsetAsync(m->d_pwr[i], 0, n_tasks * sizeof(float), st));
         }
-    }
+        return GPSACQ_OK;
+    });
+    if (rc_enq) return rc_enq;
     if (int rc = merge_peaks(m, 0, n_tasks)) return rc;
+    m->last_enqueue_ms = ms_since(t_call);
     std::vector<unsigned long long> keys(n_tasks);
     std::vector<float> pwr(n_tasks);
     HIPM(hipSetDevice(m->dev[0]));
@@ -365,6 +461,7 @@ static int search_grid_impl(gpsacq_multi* m, const uint8_t* bits, size_t n_block
         HIPM(hipStreamSynchronize((hipStream_t)gpsacq_stream(m->eng[i])));
     }
     for (size_t t = 0; t < n_tasks; ++t) unpack_key(keys[t], pwr[t], kmax, &peaks[t]);
+    m->last_total_ms = ms_since(t_call);
     return GPSACQ_OK;
 }
 
@@ -388,6 +485,7 @@ extern "C" int gpsacq_multi_search_grid(gpsacq_multi* m, const uint8_t* bits, si
 
 // ---- the block decomposition: whole runs of the reference schedule split over the devices -------------------------------
 static int search_blocks_impl(gpsacq_multi* m, const uint8_t* bits, size_t n_runs, size_t stride, gpsacq_peak* peaks, gpsacq_peak* best) {
+    const MClock::time_point t_call = MClock::now();
     const size_t n = m->eng.size();
     const int first = m->info.first_doppler_total, total = m->info.num_doppler_total, kmax = -first;
     size_t off = 0;  // the 32 per-PRN entries live behind the per-task entries: the same offset on every engine
@@ -396,30 +494,39 @@ static int search_blocks_impl(gpsacq_multi* m, const uint8_t* bits, size_t n_run
         off = std::max((base + (rem ? 1 : 0)) * GPSACQ_NUM_SATS, (size_t)1);
         for (size_t i = 0; i < n; ++i) off = std::max(off, m->task_cap[i]);
     }
-    for (size_t i = 0; i < n; ++i) {
-        // contiguous, balanced range of whole runs for device i; a run starts at PRN index 0, so the reference schedule
-        // (block t <-> PRN t % 32) holds inside every range
+    // contiguous, balanced range of whole runs for device i; a run starts at PRN index 0, so the reference schedule
+    // (block t <-> PRN t % 32) holds inside every range
+    auto share = [&](size_t i, size_t& first_run, size_t& nblk) {
         const size_t base = n_runs / n, rem = n_runs % n;
-        const size_t cnt = base + (i < rem ? 1 : 0), first_run = i * base + (i < rem ? i : rem);
-        const size_t nblk = cnt * GPSACQ_NUM_SATS;
-        HIPM(hipSetDevice(m->dev[i]));
+        const size_t cnt = base + (i < rem ? 1 : 0);
+        first_run = i * base + (i < rem ? i : rem);
+        nblk = cnt * GPSACQ_NUM_SATS;
+    };
+    const int rc_enq = for_each_engine(m, [&](size_t i) -> int {
+        size_t first_run, nblk;
+        share(i, first_run, nblk);
         hipStream_t st = (hipStream_t)gpsacq_stream(m->eng[i]);
         const size_t nbytes = nblk ? (nblk - 1) * stride + GPSACQ_BLOCK_BYTES : 0;
         if (int rc = grow_dev(m, i, std::max(nbytes, (size_t)1), off)) return rc;
         if (nblk > 0) {
-            HIPM(hipMemcpyAsync(m->d_bits[i], bits + first_run * GPSACQ_NUM_SATS * stride, nbytes, hipMemcpyHostToDevice, st));
+            if (int rc = grow_pinned(m, i, nbytes, peaks ? nblk : 0)) return rc;
+            memcpy(m->h_bits[i], bits + first_run * GPSACQ_NUM_SATS * stride, nbytes);  // this engine's share, by this engine's thread
+            HIPM(hipMemcpyAsync(m->d_bits[i], m->h_bits[i], nbytes, hipMemcpyHostToDevice, st));
             if (int rc = gpsacq_set_doppler_window(m->eng[i], first, total)) return rc;  // every device scans the whole grid
             if (int rc = gpsacq_search_device(m->eng[i], m->d_bits[i], nblk, stride, nullptr, nblk, nullptr, m->d_peaks[i], 0)) return rc;
             launch_pack_keys(m->d_peaks[i], m->d_keys[i], (int)nblk, kmax, st);
             launch_prn_best(m->d_keys[i], m->d_peaks[i], (int)nblk, m->d_keys[i] + off, m->d_pwr[i] + off, st);
             HIPM(hipGetLastError());
-            if (peaks) HIPM(hipMemcpyAsync(peaks + first_run * GPSACQ_NUM_SATS, m->d_peaks[i], nblk * sizeof(Peak), hipMemcpyDeviceToHost, st));
+            if (peaks) HIPM(hipMemcpyAsync(m->h_peaks[i], m->d_peaks[i], nblk * sizeof(Peak), hipMemcpyDeviceToHost, st));  // pinned: does not wait
         } else {
             HIPM(hipMemsetAsync(m->d_keys[i] + off, 0, GPSACQ_NUM_SATS * sizeof(unsigned long long), st));  // neutral for MAX
             HIPM(hipMemsetAsync(m->d_pwr[i] + off, 0, GPSACQ_NUM_SATS * sizeof(float), st));
         }
-    }
+        return GPSACQ_OK;
+    });
+    if (rc_enq) return rc_enq;
     if (int rc = merge_peaks(m, off, GPSACQ_NUM_SATS)) return rc;
+    m->last_enqueue_ms = ms_since(t_call);  // everything of this call is enqueued on every device
     unsigned long long keys[GPSACQ_NUM_SATS];
     float pwr[GPSACQ_NUM_SATS];
     HIPM(hipSetDevice(m->dev[0]));
@@ -429,8 +536,15 @@ static int search_blocks_impl(gpsacq_multi* m, const uint8_t* bits, size_t n_run
         HIPM(hipSetDevice(m->dev[i]));
         HIPM(hipStreamSynchronize((hipStream_t)gpsacq_stream(m->eng[i])));
     }
+    if (peaks)
+        for (size_t i = 0; i < n; ++i) {
+            size_t first_run, nblk;
+            share(i, first_run, nblk);
+            if (nblk) memcpy(peaks + first_run * GPSACQ_NUM_SATS, m->h_peaks[i], nblk * sizeof(Peak));
+        }
     if (best)
         for (int sv = 0; sv < GPSACQ_NUM_SATS; ++sv) unpack_key(keys[sv], pwr[sv], kmax, &best[sv]);
+    m->last_total_ms = ms_since(t_call);
     return GPSACQ_OK;
 }
 
@@ -445,5 +559,13 @@ extern "C" int gpsacq_multi_search_blocks(gpsacq_multi* m, const uint8_t* bits, 
     if (rc) drain(m);
     for (size_t i = 0; i < m->eng.size(); ++i) (void)gpsacq_set_doppler_window(m->eng[i], before[i].first_doppler, before[i].num_doppler);
     if (rc) return acq::set_last_error(rc, err.c_str());
+    return GPSACQ_OK;
+}
+
+extern "C" int gpsacq_multi_last_call_ms(const gpsacq_multi* m, double* enqueue_ms, double* total_ms, int64_t* rccl_allreduces) {
+    if (!m) return failf(GPSACQ_ERR_ARG, "gpsacq_multi_last_call_ms: null handle");
+    if (enqueue_ms) *enqueue_ms = m->last_enqueue_ms;
+    if (total_ms) *total_ms = m->last_total_ms;
+    if (rccl_allreduces) *rccl_allreduces = (int64_t)m->rccl_allreduces;
     return GPSACQ_OK;
 }

@@ -31,9 +31,13 @@
 //   GPSACQ_SUM_THREADS=<n>  IQ input: host threads that sum the capture for its mean (default 8, at most the cores present);
 //   GPSACQ_SUMS_ON_GPU=1    ... or read the file through a buffer and sum it on the GPU (the fallback when it cannot be mapped)
 //   GPSACQ_NO_MMAP=1        read the capture with fread only (what happens anyway when it is not a regular file); by default it is
-//                           mapped and the batches are copied into the staging buffers by GPSACQ_SUM_THREADS threads
+//                           mapped and the batches are copied into the staging buffers by GPSACQ_SUM_THREADS threads.  The file's
+//                           size is taken again (fstat) before every batch, so a capture that shrinks between batches ends the
+//                           search like the reference's short fread does; one truncated DURING a batch's copy raises SIGBUS --
+//                           the caveat of every mapping -- and GPSACQ_NO_MMAP=1 is the mode for a file another process rewrites
 //   GPSACQ_TRACE=1          wall-clock split of SearchInit / SearchTask on stderr
 #include <sys/mman.h>
+#include <sys/stat.h>
 
 #include <chrono>
 #include <cstdint>
@@ -376,7 +380,10 @@ void SearchTask(char *filename_1bit_bin) {
             Clock::time_point t0 = Clock::now();
             size_t got;
             if (map) {
-                got = map_len - map_pos < want ? map_len - map_pos : want;
+                struct stat st;  // the bytes the file holds NOW: a shorter file ends the search at its last whole run
+                const size_t live = (fstat(fileno(fp), &st) == 0 && st.st_size >= 0 && (size_t)st.st_size < map_len) ? (size_t)st.st_size : map_len;
+                const size_t avail = live > map_pos ? live - map_pos : 0;
+                got = avail < want ? avail : want;
                 copy_parallel(buf, map + map_pos, got);
                 map_pos += got;
             } else {

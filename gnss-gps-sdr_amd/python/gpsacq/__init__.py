@@ -66,7 +66,7 @@ EXPORTS = ["gpsacq_generate", "gpsacq_generate_device", "gpsacq_generate_sig", "
            "gpsacq_sample_spectrum", "gpsacq_code_spectrum", "gpsacq_multi_create", "gpsacq_multi_destroy",
            "gpsacq_multi_set_doppler_step", "gpsacq_multi_get_info", "gpsacq_multi_search_grid", "gpsacq_multi_search_blocks",
            "gpsacq_pipe_buffer", "gpsacq_pipe_submit", "gpsacq_pipe_collect", "gpsacq_search_iq8", "gpsacq_search_iq8_device",
-           "gpsacq_iq8_accumulate_sums", "gpsacq_handoff_step", "gpsacq_handoff_engine", "gpsacq_reserve"]
+           "gpsacq_iq8_accumulate_sums", "gpsacq_handoff_step", "gpsacq_handoff_engine", "gpsacq_reserve", "gpsacq_multi_last_call_ms"]
 
 _lib = None
 
@@ -184,6 +184,8 @@ def load_library(path=None):
     lib.gpsacq_handoff_engine.restype = ctypes.c_int
     lib.gpsacq_reserve.argtypes = [vp, sz]
     lib.gpsacq_reserve.restype = ctypes.c_int
+    lib.gpsacq_multi_last_call_ms.argtypes = [vp, ctypes.POINTER(ctypes.c_double), ctypes.POINTER(ctypes.c_double), ctypes.POINTER(ctypes.c_int64)]
+    lib.gpsacq_multi_last_call_ms.restype = ctypes.c_int
     if path is None:
         _lib = lib
     return lib
@@ -388,6 +390,10 @@ class Engine:
     def synchronize(self):
         _check(self._lib, self._lib.gpsacq_synchronize(self._h))
 
+    def reserve(self, n_blocks):
+        """Scratch (and the cached reference schedule) for batches of up to n_blocks blocks, once (gpsacq_reserve)."""
+        _check(self._lib, self._lib.gpsacq_reserve(self._h, int(n_blocks)))
+
     def last_timing(self, n_back=0):
         """Stage times (ms) of the search n_back calls ago (0 = the last one); waits for that search only."""
         t = Timing()
@@ -502,6 +508,12 @@ class MultiEngine:
         _check(self._lib, self._lib.gpsacq_multi_search_blocks(self._h, buf.ctypes.data_as(ctypes.c_void_p), n_runs, stride,
                                                                peaks.ctypes.data_as(ctypes.c_void_p), best.ctypes.data_as(ctypes.c_void_p)))
         return peaks, best
+
+    def last_call_ms(self):
+        """Host-side times of the last search_* call: {"enqueue_ms", "total_ms", "rccl_allreduces"} (gpsacq_multi_last_call_ms)."""
+        a, b, c = ctypes.c_double(), ctypes.c_double(), ctypes.c_int64()
+        _check(self._lib, self._lib.gpsacq_multi_last_call_ms(self._h, ctypes.byref(a), ctypes.byref(b), ctypes.byref(c)))
+        return {"enqueue_ms": a.value, "total_ms": b.value, "rccl_allreduces": c.value}
 
     def close(self):
         if self._h:

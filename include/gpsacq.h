@@ -212,7 +212,8 @@ GPSACQ_API int gpsacq_set_noncoherent(gpsacq_engine* e, int n_acc, int block_ste
  * With compensation on, block k's powers are moved back by round(k * c * bin) whole samples (modulo
  * the fs/1000 lags) before they are summed, c = T * (fs/40000) / 1575.42e6 in float, bin = the cell's
  * Doppler bin; ca_shift then refers to block 0.  At fs > 10 MHz (more than 10000 lags, searched in
- * several passes of 40 columns) the per-lag sums are kept in device memory -- 4 * fs/1000 bytes per cell of the batch.
+ * several passes of 40 columns) the per-lag sums are kept in device memory -- 4 * fs/1000 bytes per cell, the batch's tasks taken
+ * in chunks of at most 1 GB of sums.
  */
 GPSACQ_API int gpsacq_set_creep_compensation(gpsacq_engine* e, int on);
 /*
@@ -350,8 +351,14 @@ GPSACQ_API int gpsacq_handoff_engine(const gpsacq_engine* e, const gpsacq_peak* 
  * into a 64-bit key (snr bits << 32 | (0xFFFF - grid index) << 16 | ca_shift: integer MAX = higher SNR, ties to the
  * LOWER Doppler point like the strict '>' of :196-198) and ONE ncclAllReduce(MAX, uint64) over RCCL (xGMI) merges them.
  * devices == NULL: ordinals 0..n_devices-1.  n_devices == 1 is the degenerate case (same result as gpsacq_search's
- * peaks).  peaks[n_tasks]: snr / lo_shift / ca_shift of the merged best; max_pwr is not carried by the key and reads 0.
- * RCCL is dlopen'ed on first use (librccl.so.1); GPSACQ_ERR_DEVICE if it is missing.
+ * peaks).  peaks[n_tasks]: snr / lo_shift / ca_shift of the merged best and its max_pwr -- the key has no room for the
+ * power, so the winner's value follows in a second all-reduce(MAX, float) (the engine whose key won contributes its value,
+ * the others 0).  A device may be listed more than once: engines of one GPU merge their keys on that GPU and RCCL joins the
+ * distinct GPUs only.  RCCL is dlopen'ed on first use (librccl.so.1); GPSACQ_ERR_DEVICE if it is missing.  With one distinct
+ * GPU no RCCL call is made -- unless GPSACQ_MULTI_FORCE_RCCL=1 is set when the handle is created: then the communicator
+ * (ncclCommInitAll over one device) and both all-reduces run as a one-rank group, the same calls a multi-GPU node makes.
+ * Each engine's share of a call (staging copy out of the caller's pageable buffer, upload, search, download) is enqueued by
+ * its own host thread through pinned buffers, so no device waits for another one's copies.
  */
 typedef struct gpsacq_multi gpsacq_multi;
 GPSACQ_API int gpsacq_multi_create(const gpsacq_params* params, const int32_t* devices, int n_devices, gpsacq_multi** out);
@@ -366,11 +373,15 @@ GPSACQ_API int gpsacq_multi_search_grid(gpsacq_multi* m, const uint8_t* bits, si
  * is cut into one contiguous range of runs per device; every device searches its runs over the full Doppler grid, reduces
  * its peaks to the best per PRN as packed keys, and ONE ncclAllReduce(MAX, uint64) of 32 keys merges them.  Outputs, either
  * may be NULL: peaks[n_runs * 32] -- every (run, PRN) peak in file order, what SearchTask() reports -- and best[32], the
- * merged per-PRN best over the whole capture (max_pwr reads 0: the key does not carry it).  n_devices == 1 is the
- * degenerate case.  The engines' Doppler windows are left as they were.
+ * merged per-PRN best over the whole capture (max_pwr included: the winner's value, merged next to the keys as above).
+ * n_devices == 1 is the degenerate case.  The engines' Doppler windows are left as they were.
  */
 GPSACQ_API int gpsacq_multi_search_blocks(gpsacq_multi* m, const uint8_t* bits, size_t n_runs, size_t stride, gpsacq_peak* peaks,
                                gpsacq_peak* best);
+/* Host-side times of the last gpsacq_multi_search_* call, milliseconds: enqueue_ms = entry until every device's work and the
+ * merge were enqueued (what the calling thread costs the devices; flat in the number of devices), total_ms = the whole call;
+ * rccl_allreduces = ncclAllReduce groups issued by this handle so far (0 when no communicator exists).  Any pointer may be NULL. */
+GPSACQ_API int gpsacq_multi_last_call_ms(const gpsacq_multi* m, double* enqueue_ms, double* total_ms, int64_t* rccl_allreduces);
 
 /* SearchCode(): chips to clock PRN sv's generator until its G1 register reads g1 (-1 if never) */
 GPSACQ_API int gpsacq_search_code(int sv, int g1);

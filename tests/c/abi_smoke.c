@@ -103,6 +103,15 @@ int main(int argc, char **argv) {
                 return 73;
             }
         printf("multi blocks (2 engines on device 0): best sv %d snr %.1f max_pwr %.4g\n", best, bestp[best].snr, bestp[best].max_pwr);
+        {
+            double enq = -1.0, tot = -1.0;
+            int64_t ar = -1;
+            if (gpsacq_multi_last_call_ms(m, &enq, &tot, &ar) != GPSACQ_OK || !(enq > 0.0) || !(tot >= enq) || ar != 0) {
+                fprintf(stderr, "gpsacq_multi_last_call_ms: enqueue %.3f total %.3f all-reduces %d\n", enq, tot, (int)ar);
+                gpsacq_multi_destroy(m);
+                return 76;
+            }
+        }
         gpsacq_multi_destroy(m);
     }
     {

@@ -16,6 +16,8 @@ def _bench(*args, env=None):
     for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT"):
         e.pop(k, None)
     e.update(env or {})
+    if "--soak-seconds" not in args:
+        args = ("--soak-seconds", "0") + tuple(args)  # the soak leg has its own test (tests/test_gpu_round4.py)
     r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "1", "--warmup", "1", "--no-cpu-baseline", *args],
                        capture_output=True, text=True, timeout=600, env=e)
     assert r.returncode == 0, r.stderr[-2000:]
