@@ -144,7 +144,8 @@ __global__ __launch_bounds__(WG) void k_quirk_patch(QuirkArgs a) {
 // grid point; 0 = plain sum) and by the code phase between block starts that are not whole code periods apart (a.lag_step samples
 // per block; 0 = none): power of lag n goes to lag (n - round(k * creep * point) - k * lag_step) mod S.
 // W1H: half of the pass-1 twiddles derived instead of held (acq_math.hpp): 18 registers for 18 packed multiplies.
-// PROF: s_memtime stamps per segment, summed over the launch into a.prof[1024][16] (GPSACQ_PROF=1; costs a few per cent).
+// PROF: s_memtime stamps per segment, summed over the launch into a.prof[1024][16] (GPSACQ_PROF=1; costs a few per cent): instantiated
+// in the variant build only (-DACQ_EXPERIMENTS).
 // L: LDS slot map and lane map (acq_math.hpp): LayC (LayB's slots, conflict-free lane assignment) everywhere except the two
 // widest non-coherent instances, whose per-lag power array leaves room for the 40 KB map LayA only (33 columns: 77 KB -> still two
 // workgroups per CU).
@@ -364,6 +365,7 @@ __global__ __launch_bounds__(WG, WPS) void k_corr(CorrArgs a) {
     }
 }
 
+#ifdef ACQ_EXPERIMENTS  // not in the product library: `make experiments` builds build/var_exp/libgpsacq.so with it (GPSACQ_CORR8=2|3)
 // ---------------------------------------------------------------------------------------
 // The 8-wave correlator (acq_corr8.hpp): the same cell as k_corr<MC> (coherent, one pass, up to 10000 lags) with the
 // 5000-point sub-transforms as 5 x 10 x 10 x 10 on 500 threads.  Same blockIdx -> cell map, same outputs.
@@ -447,6 +449,8 @@ __global__ __launch_bounds__(WG8, WPS) void k_corr8(CorrArgs a) {
         a.cells[(size_t)task * a.ndop + di] = c;
     }
 }
+
+#endif  // ACQ_EXPERIMENTS
 
 // More than 10000 lags (fs > 10 MHz) take several k_corr passes of 40 columns each; this folds the
 // partial cells (ascending lag ranges, so strict '>' keeps the first maximum) and sets the SNR.
@@ -587,7 +591,9 @@ int launch_corr(const CorrArgs& a, int mc, hipStream_t s) {
             break;
         case 22:
             if (a.n_acc > 1) hipLaunchKernelGGL((k_corr<22, 2, 2, true>), grid, block, 0, s, a);
+#ifdef ACQ_EXPERIMENTS
             else if (a.prof) hipLaunchKernelGGL((k_corr<22, 3, 2, false, false, true>), grid, block, 0, s, a);
+#endif
             else hipLaunchKernelGGL((k_corr<22, 3, 2, false>), grid, block, 0, s, a);
             break;
         case 28:
@@ -606,6 +612,7 @@ int launch_corr(const CorrArgs& a, int mc, hipStream_t s) {
     }
     return 0;
 }
+#ifdef ACQ_EXPERIMENTS
 int corr8_columns(int nlags) {
     const int need = (nlags + NT8 - 1) / NT8;
     const int have[] = {6, 11, 14, 17, 20};
@@ -629,6 +636,7 @@ int launch_corr8(const CorrArgs& a, int mc8, int wgs_per_cu, hipStream_t s) {
 #undef K8
     return 0;
 }
+#endif  // ACQ_EXPERIMENTS
 void launch_scan_power(const float* pdump, Cell* cells, size_t n_cells, int nlags, hipStream_t s) {
     hipLaunchKernelGGL(k_scan_power, dim3((unsigned)n_cells), dim3(256), 0, s, pdump, cells, nlags);
 }

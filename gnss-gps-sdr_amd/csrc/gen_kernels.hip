@@ -100,6 +100,37 @@ __global__ __launch_bounds__(256) void k_siggen(SigArgs a) {
     }
     a.bits[byte] = (uint8_t)out;
 }
+// gps_sig_gen.m:21-30, the script's other output (gps_sig_tmp_for_hackrf_tx.bin, replayed through a HackRF in README.md
+// section 2.2): x = conv(rcosine(1, 8), [data x n_repeat]) .* 50 as I, zeros as Q, interleaved int8 (fwrite rounds to nearest,
+// ties away from zero, and saturates) -- the same shaped baseband as k_siggen's, at IF 0.  One complex sample per thread.
+__global__ __launch_bounds__(256) void k_siggen_tx(SigTxArgs a) {
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= a.n_samples) return;
+    const long long m = a.first_sample + (long long)i;
+    const long long per_rep = (long long)a.n_data * 20 * 1023, n_chip = per_rep * a.n_repeat;
+    const long long jmax = m >> 3;
+    double acc = 0.0;
+#pragma unroll
+    for (int o = 6; o >= 0; --o) {  // oldest contributing chip first
+        const long long j = jmax - o;
+        const int tap = (int)(m - 8 * j);
+        if (j >= 0 && j < n_chip && tap <= 48) {
+            const int idx = (int)(j % 1023);
+            const int chip = ((c_chips[a.sv][idx >> 5] >> (idx & 31)) & 1u) ? -1 : 1;
+            const double d = (double)(chip * (int)a.data[(j % per_rep) / (20 * 1023)]);
+            acc = __dadd_rn(acc, __dmul_rn(d, c_rc[tap]));
+        }
+    }
+    double v = round(__dmul_rn(acc, 50.0));  // C round(): half away from zero, like MATLAB's
+    v = v > 127.0 ? 127.0 : (v < -128.0 ? -128.0 : v);
+    char2 o2;
+    o2.x = (signed char)(int)v;
+    o2.y = 0;
+    reinterpret_cast<char2*>(a.iq)[i] = o2;
+}
+void launch_siggen_tx(const SigTxArgs& a, hipStream_t s) {
+    hipLaunchKernelGGL(k_siggen_tx, dim3((unsigned)((a.n_samples + 255) / 256)), dim3(256), 0, s, a);
+}
 void launch_siggen(const SigArgs& a, hipStream_t s) {
     hipLaunchKernelGGL(k_siggen, dim3((unsigned)((a.n_bytes + 255) / 256)), dim3(256), 0, s, a);
 }

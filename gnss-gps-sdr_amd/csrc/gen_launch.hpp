@@ -35,6 +35,15 @@ struct SigArgs {
     double two_pi_fc;    // (2 pi) * (ca_rate / 4), rounded like the script's left-to-right product
     double inv_rate;     // 1 / ca_rate
 };
+// gps_sig_gen.m:21-30, the HackRF transmit file (gen_kernels.hip, k_siggen_tx)
+struct SigTxArgs {
+    int8_t* iq;            // [2 * n_samples] interleaved I, Q (Q = 0)
+    size_t n_samples;      // complex samples to write
+    long long first_sample;// index of the first one in the stream of n_repeat * n_data * 20 * 1023 * 8 + 48
+    const int8_t* data;    // [n_data] navigation bits +-1 (device)
+    int n_data, n_repeat, sv;
+};
+void launch_siggen_tx(const SigTxArgs& a, hipStream_t s);
 hipError_t upload_chips(const uint32_t* host);
 void launch_siggen(const SigArgs& a, hipStream_t s);
 void launch_generate(const GenArgs& a, hipStream_t s);

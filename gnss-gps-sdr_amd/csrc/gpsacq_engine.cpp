@@ -51,6 +51,10 @@ __attribute__((visibility("hidden"))) int acq::set_last_error(int code, const ch
 
 struct gpsacq_engine {
     gpsacq_params p{};
+    // GPSACQ_WARM=1: the first launch of each search kernel (runtime-side set-up of a kernel's first dispatch) is made by a
+    // worker right after gpsacq_create, on its own stream and buffers, while the caller allocates its staging buffers; the
+    // first search waits for it (join_warm)
+    std::future<void> warm;
     int dmax = 0, ndop = 0, dop_first = 0, nlags = 0, mc = 0, halo = 0, crow = 0;  // searched bins: dop_first .. +ndop-1
     int n_acc = 1, acc_step = 0;  // non-coherent accumulation (gpsacq_set_noncoherent)
     // Doppler grid (gpsacq_set_doppler_step): step = bin * dstride / sub, points -kmax..+kmax; sub = dstride = 1 is the reference's
@@ -71,8 +75,10 @@ struct gpsacq_engine {
     // constants
     cf *d_t1 = nullptr, *d_t2 = nullptr, *d_bq = nullptr, *d_tn = nullptr;
     unsigned char* d_rho = nullptr;
-    cf *d_t1_8 = nullptr, *d_t2_8 = nullptr, *d_t3_8 = nullptr, *d_bq8 = nullptr;  // tables of the 8-wave correlator
-    int corr8 = 0;  // GPSACQ_CORR8=2|3: coherent single-pass searches run k_corr8 at that many workgroups per CU  // LayC's pass-3 thread -> rho table (acq_math.hpp kRhoC)
+    // variant build (-DACQ_EXPERIMENTS) only: tables of the 8-wave correlator; GPSACQ_CORR8=2|3 runs coherent single-pass searches
+    // on k_corr8 at that many workgroups per CU.  Always NULL / 0 in the product library.
+    cf *d_t1_8 = nullptr, *d_t2_8 = nullptr, *d_t3_8 = nullptr, *d_bq8 = nullptr;
+    int corr8 = 0;
     uint8_t *d_cos = nullptr, *d_sin = nullptr;
     uint64_t *d_cos_t = nullptr, *d_sin_t = nullptr;  // bit-transposed masks for k_fwd
     cf* d_code = nullptr;  // [32 + patch_cap][8][crow]
@@ -211,8 +217,11 @@ static int run_forward(gpsacq_engine* e, FwdKind kind, const void* src, size_t s
 
 extern "C" const char* gpsacq_last_error(void) { return g_err.c_str(); }
 
+static void join_warm(gpsacq_engine* e);
+static void warm_kernels(gpsacq_engine* e);
 extern "C" void gpsacq_destroy(gpsacq_engine* e) {
     if (!e) return;
+    join_warm(e);
     (void)hipSetDevice(e->p.device);
     if (e->stream) (void)hipStreamSynchronize(e->stream);
     void* bufs[] = {e->d_t1, e->d_t2, e->d_bq, e->d_tn, e->d_rho, e->d_t1_8, e->d_t2_8, e->d_t3_8, e->d_bq8, e->d_cos, e->d_sin, e->d_cos_t, e->d_sin_t, e->d_code, e->d_patch_blocks, e->d_bits, e->d_iq, e->d_iqbits, e->d_fsamp, e->d_pdump, e->d_sums, e->d_sats, e->d_gen, e->d_prof, e->d_rot8,
@@ -257,7 +266,9 @@ extern "C" int gpsacq_create(const gpsacq_params* params, gpsacq_engine** out) {
     // it runs in a worker while this thread sits in the HIP runtime's start-up (>100 ms in the first HIP call of a process).
     struct HostPrep {
         Tables T;
+#ifdef ACQ_EXPERIMENTS
         Tables8 T8;
+#endif
         std::vector<cf> tn, rot8;
         std::vector<uint8_t> cosm, sinm;
         std::vector<uint64_t> cos_t, sin_t;
@@ -318,10 +329,12 @@ extern "C" int gpsacq_create(const gpsacq_params* params, gpsacq_engine** out) {
     e->crow = M_SUB + 2 * e->halo;
     e->cus = prop.multiProcessorCount;
     snprintf(e->name, sizeof e->name, "%s", prop.name);
+#ifdef ACQ_EXPERIMENTS
     {
         const char* pv = getenv("GPSACQ_PROF");  // diagnostic (k_corr phase profile); read once, here
         e->prof = pv && *pv && atoi(pv) != 0;
     }
+#endif
 #define HCK(expr)                                                                     \
     do {                                                                              \
         hipError_t e_ = (expr);                                                       \
@@ -361,6 +374,7 @@ extern "C" int gpsacq_create(const gpsacq_params* params, gpsacq_engine** out) {
         HCK(hipMalloc((void**)&e->d_rho, sizeof rho));
         HCK(hipMemcpy(e->d_rho, rho, sizeof rho, hipMemcpyHostToDevice));
     }
+#ifdef ACQ_EXPERIMENTS
     {
         const Tables8& T8 = hp->T8;
         HCK(hipMalloc((void**)&e->d_t1_8, T8.t1.size() * sizeof(cf)));
@@ -375,6 +389,7 @@ extern "C" int gpsacq_create(const gpsacq_params* params, gpsacq_engine** out) {
         const char* c8 = getenv("GPSACQ_CORR8");
         e->corr8 = (c8 && *c8) ? atoi(c8) : 0;
     }
+#endif
     HCK(hipMalloc((void**)&e->d_bq, T.bq.size() * sizeof(cf)));
     HCK(hipMemcpy(e->d_bq, T.bq.data(), T.bq.size() * sizeof(cf), hipMemcpyHostToDevice));
     HCK(hipMemcpy(e->d_t1, T.t1.data(), T.t1.size() * sizeof(cf), hipMemcpyHostToDevice));
@@ -415,6 +430,15 @@ extern "C" int gpsacq_create(const gpsacq_params* params, gpsacq_engine** out) {
         fprintf(stderr, "gpsacq trace: gpsacq_create %.1f ms = HIP runtime/device start-up %.1f (host tables and code replicas computed meanwhile; "
                         "waited %.1f more for them) + stream, events, table uploads, code object load %.1f + 32 code spectra %.1f\n",
                 lap(), ms_runtime, ms_prep_wait, ms_tables - ms_runtime - ms_prep_wait, lap() - ms_tables);
+    {
+        const char* wv = getenv("GPSACQ_WARM");
+        if (wv && *wv && atoi(wv) != 0) {
+            try {
+                e->warm = std::async(std::launch::async, [e]() { warm_kernels(e); });
+            } catch (const std::exception&) {  // no thread: no warm-up
+            }
+        }
+    }
     *out = e;
     return GPSACQ_OK;
 }
@@ -542,8 +566,73 @@ static int pass_columns(int n_cols, int p) {
     return left >= MC_MAX ? MC_MAX : corr_columns(left * NBF3);
 }
 
+static void join_warm(gpsacq_engine* e) {
+    if (e->warm.valid()) {
+        try {
+            e->warm.get();
+        } catch (...) {  // a warm-up is an optimisation: nothing of it is an error of the search
+        }
+    }
+}
+// one block, one task through the three kernels of SearchTask() on a private stream and private buffers (results discarded)
+static void warm_kernels(gpsacq_engine* e) {
+    if (hipSetDevice(e->p.device) != hipSuccess) return;
+    hipStream_t st = nullptr;
+    uint8_t* buf = nullptr;
+    const size_t dpp_bytes = (size_t)NPOLY * M_SUB * sizeof(cf), cells_bytes = (size_t)e->ndop * sizeof(Cell);
+    const size_t off_dpp = 8192, off_task = off_dpp + dpp_bytes, off_cells = off_task + 256, off_peaks = off_cells + ((cells_bytes + 255) & ~(size_t)255);
+    if (hipStreamCreateWithFlags(&st, hipStreamNonBlocking) != hipSuccess) return;
+    if (hipMalloc((void**)&buf, off_peaks + 256) == hipSuccess) {
+        (void)hipMemsetAsync(buf, 0, off_dpp + 16, st);
+        FwdArgs fa{};
+        fa.src = buf;
+        fa.src_stride = BLOCK_BYTES;
+        fa.sub = 1;
+        fa.rot8 = e->d_rot8;
+        fa.cos_t = e->d_cos_t;
+        fa.sin_t = e->d_sin_t;
+        fa.t1 = e->d_t1;
+        fa.t2 = e->d_t2;
+        fa.tn = e->d_tn;
+        fa.out = (cf*)(buf + off_dpp);
+        fa.item_stride = (size_t)NPOLY * M_SUB;
+        fa.row = M_SUB;
+        fa.off = 0;
+        fa.conj_out = 1;
+        launch_fwd_bits(fa, 1, st);
+        (void)hipMemsetAsync(buf + off_task, 0, sizeof(Task), st);  // task (spectrum 0, code 0)
+        CorrArgs ca{};
+        ca.dpp = (const cf*)(buf + off_dpp);
+        ca.cpp = e->d_code;
+        ca.tasks = (const Task*)(buf + off_task);
+        ca.t1 = e->d_t1;
+        ca.t2 = e->d_t2;
+        ca.bq = e->d_bq;
+        ca.rho_map = e->d_rho;
+        ca.cells = (Cell*)(buf + off_cells);
+        ca.n_tasks = 1;
+        ca.ndop = e->ndop;
+        ca.dop_first = e->dop_first;
+        ca.nlags = e->nlags;
+        ca.crow = e->crow;
+        ca.halo = e->halo;
+        ca.n_acc = 1;
+        ca.n_spec = 1;
+        ca.n_code = GPSACQ_NUM_SATS;
+        ca.sub = 1;
+        ca.dstride = 1;
+        if (e->nlags <= MC_MAX * NBF3) (void)launch_corr(ca, e->mc, st);
+        launch_peaks(ca.cells, (Peak*)(buf + off_peaks), 1, e->ndop, e->dop_first, st);
+        (void)hipStreamSynchronize(st);
+        (void)hipFree(buf);
+    }
+    (void)hipStreamDestroy(st);
+    (void)hipGetLastError();
+}
+
 static int search_core(gpsacq_engine* e, const Capture& cap_in, size_t n_blocks, const gpsacq_task* h_tasks,
                        const void* d_user_tasks, size_t n_tasks, Cell* d_cells, Peak* d_peaks) {
+    join_warm(e);
     Capture cap = cap_in;
     if (n_blocks == 0 || n_tasks == 0) return fail(GPSACQ_ERR_ARG, "empty batch");
     if (cap.iq8) {
@@ -617,10 +706,12 @@ static int search_core(gpsacq_engine* e, const Capture& cap_in, size_t n_blocks,
     ca.t2 = e->d_t2;
     ca.bq = e->d_bq;
     ca.rho_map = e->d_rho;
+#ifdef ACQ_EXPERIMENTS
     ca.t1_8 = e->d_t1_8;
     ca.t2_8 = e->d_t2_8;
     ca.t3_8 = e->d_t3_8;
     ca.bq8 = e->d_bq8;
+#endif
     ca.cells = d_cells;
     ca.n_tasks = (int)n_tasks;
     ca.ndop = e->ndop;
@@ -653,10 +744,13 @@ static int search_core(gpsacq_engine* e, const Capture& cap_in, size_t n_blocks,
         // samples the code advances per accumulated block per Doppler bin: elapsed samples x (bin Hz / L1)
         if (e->creep_comp && e->n_acc > 1)
             ca.creep = (float)((double)e->acc_step * block_samples * (e->p.fs / N_FFT * e->dstride / e->sub) / 1575.42e6);
+#ifdef ACQ_EXPERIMENTS
         const int mc8 = corr8_columns(e->nlags);
         if (e->corr8 >= 2 && e->n_acc == 1 && mc8 > 0) {
             if (launch_corr8(ca, mc8, e->corr8, e->stream) != 0) return fail(GPSACQ_ERR_UNSUPPORTED, "no 8-wave correlate kernel for %d columns", mc8);
-        } else if (launch_corr(ca, e->mc, e->stream) != 0) return fail(GPSACQ_ERR_UNSUPPORTED, "no correlate kernel for %d columns", e->mc);
+        } else
+#endif
+        if (launch_corr(ca, e->mc, e->stream) != 0) return fail(GPSACQ_ERR_UNSUPPORTED, "no correlate kernel for %d columns", e->mc);
     } else if (realign) {
         // re-aligned lags cross the passes' column windows: the per-lag sums of every cell go to device memory (nlags floats per
         // cell), every pass adds its window's powers at their re-aligned lags, one scan per cell at the end
@@ -963,6 +1057,7 @@ extern "C" int gpsacq_aligned_stride(const gpsacq_engine* e) {
 
 extern "C" int gpsacq_set_doppler_window(gpsacq_engine* e, int first_bin, int n_bins) {
     if (!e) return fail(GPSACQ_ERR_ARG, "gpsacq_set_doppler_window: null engine");
+    join_warm(e);
     if (n_bins <= 0 || first_bin < -e->kmax || first_bin + n_bins - 1 > e->kmax)
         return fail(GPSACQ_ERR_ARG, "Doppler window [%d, %d] outside [-%d, %d]", first_bin, first_bin + n_bins - 1, e->kmax, e->kmax);
     e->dop_first = first_bin;
@@ -972,6 +1067,7 @@ extern "C" int gpsacq_set_doppler_window(gpsacq_engine* e, int first_bin, int n_
 
 extern "C" int gpsacq_set_doppler_step(gpsacq_engine* e, double step_hz) {
     if (!e) return fail(GPSACQ_ERR_ARG, "gpsacq_set_doppler_step: null engine");
+    join_warm(e);  // the worker reads the tables replaced below
     HIPCHK(hipSetDevice(e->p.device));
     const double bin = e->p.fs / N_FFT;
     int sub = 1, dstride = 1;
@@ -1109,6 +1205,42 @@ extern "C" int gpsacq_generate_sig(gpsacq_engine* e, int prn, const int8_t* data
     launch_siggen(a, e->stream);
     HIPCHK(hipGetLastError());
     HIPCHK(hipMemcpyAsync(bits_out, e->d_gen, n_bytes, hipMemcpyDeviceToHost, e->stream));
+    HIPCHK(hipStreamSynchronize(e->stream));
+    return GPSACQ_OK;
+}
+
+// gps_sig_gen.m:21-30: the script's HackRF transmit file, any range of its samples (k_siggen_tx)
+extern "C" uint64_t gpsacq_sig_tx_samples(int n_data_bits, int n_repeat) {
+    if (n_data_bits < 1 || n_repeat < 1) return 0;
+    return (uint64_t)n_repeat * (uint64_t)n_data_bits * 20 * 1023 * 8 + 48;
+}
+extern "C" int gpsacq_generate_sig_tx(gpsacq_engine* e, int prn, const int8_t* data_bits, int n_data_bits, int n_repeat,
+                                      uint64_t first_sample, size_t n_samples, int8_t* iq_out) {
+    if (!e || !data_bits || !iq_out || n_data_bits < 1 || n_data_bits > 100000 || n_repeat < 1 || n_repeat > 1000 || n_samples == 0)
+        return fail(GPSACQ_ERR_ARG, "gpsacq_generate_sig_tx: bad argument");
+    if (prn < 1 || prn > GPSACQ_NUM_SATS) return fail(GPSACQ_ERR_ARG, "gpsacq_generate_sig_tx: PRN %d out of 1..32", prn);
+    const uint64_t total = gpsacq_sig_tx_samples(n_data_bits, n_repeat);
+    if (first_sample > total || n_samples > total - first_sample)
+        return fail(GPSACQ_ERR_ARG, "gpsacq_generate_sig_tx: samples %llu..%llu outside the stream of %llu", (unsigned long long)first_sample,
+                    (unsigned long long)(first_sample + n_samples), (unsigned long long)total);
+    for (int i = 0; i < n_data_bits; ++i)
+        if (data_bits[i] != 1 && data_bits[i] != -1) return fail(GPSACQ_ERR_ARG, "gpsacq_generate_sig_tx: navigation bit %d is %d, not +-1", i, data_bits[i]);
+    HIPCHK(hipSetDevice(e->p.device));
+    const size_t out_bytes = 2 * n_samples, data_off = (out_bytes + 15) & ~(size_t)15;
+    if (int rc = grow(e->d_gen, e->gen_cap, data_off + (size_t)n_data_bits, e->stream)) return rc;
+    int8_t* d_data = (int8_t*)(e->d_gen + data_off);
+    HIPCHK(hipMemcpyAsync(d_data, data_bits, (size_t)n_data_bits, hipMemcpyHostToDevice, e->stream));
+    SigTxArgs a{};
+    a.iq = (int8_t*)e->d_gen;
+    a.n_samples = n_samples;
+    a.first_sample = (long long)first_sample;
+    a.data = d_data;
+    a.n_data = n_data_bits;
+    a.n_repeat = n_repeat;
+    a.sv = prn - 1;
+    launch_siggen_tx(a, e->stream);
+    HIPCHK(hipGetLastError());
+    HIPCHK(hipMemcpyAsync(iq_out, e->d_gen, out_bytes, hipMemcpyDeviceToHost, e->stream));
     HIPCHK(hipStreamSynchronize(e->stream));
     return GPSACQ_OK;
 }

@@ -66,7 +66,8 @@ EXPORTS = ["gpsacq_generate", "gpsacq_generate_device", "gpsacq_generate_sig", "
            "gpsacq_sample_spectrum", "gpsacq_code_spectrum", "gpsacq_multi_create", "gpsacq_multi_destroy",
            "gpsacq_multi_set_doppler_step", "gpsacq_multi_get_info", "gpsacq_multi_search_grid", "gpsacq_multi_search_blocks",
            "gpsacq_pipe_buffer", "gpsacq_pipe_submit", "gpsacq_pipe_collect", "gpsacq_search_iq8", "gpsacq_search_iq8_device",
-           "gpsacq_iq8_accumulate_sums", "gpsacq_handoff_step", "gpsacq_handoff_engine", "gpsacq_reserve", "gpsacq_multi_last_call_ms"]
+           "gpsacq_iq8_accumulate_sums", "gpsacq_handoff_step", "gpsacq_handoff_engine", "gpsacq_reserve", "gpsacq_multi_last_call_ms",
+           "gpsacq_sig_tx_samples", "gpsacq_generate_sig_tx"]
 
 _lib = None
 
@@ -184,6 +185,10 @@ def load_library(path=None):
     lib.gpsacq_handoff_engine.restype = ctypes.c_int
     lib.gpsacq_reserve.argtypes = [vp, sz]
     lib.gpsacq_reserve.restype = ctypes.c_int
+    lib.gpsacq_sig_tx_samples.argtypes = [ctypes.c_int, ctypes.c_int]
+    lib.gpsacq_sig_tx_samples.restype = ctypes.c_uint64
+    lib.gpsacq_generate_sig_tx.argtypes = [vp, ctypes.c_int, vp, ctypes.c_int, ctypes.c_int, ctypes.c_uint64, sz, vp]
+    lib.gpsacq_generate_sig_tx.restype = ctypes.c_int
     lib.gpsacq_multi_last_call_ms.argtypes = [vp, ctypes.POINTER(ctypes.c_double), ctypes.POINTER(ctypes.c_double), ctypes.POINTER(ctypes.c_int64)]
     lib.gpsacq_multi_last_call_ms.restype = ctypes.c_int
     if path is None:
@@ -429,6 +434,17 @@ class Engine:
         out = np.zeros(n, dtype=np.uint8)
         _check(self._lib, self._lib.gpsacq_generate_sig(self._h, int(prn), d.ctypes.data_as(ctypes.c_void_p), int(d.size),
                                                         out.ctypes.data_as(ctypes.c_void_p), n))
+        return out
+
+    def generate_sig_tx(self, prn, data_bits, n_repeat=5, first_sample=0, n_samples=None):
+        """gps_sig_gen.m:21-30 on the device: complex samples [first_sample, first_sample + n_samples) of the script's HackRF
+        transmit file (int8 I = round(50 x), Q = 0, interleaved).  Returns an int8 array of 2 * n_samples."""
+        d = np.ascontiguousarray(np.asarray(data_bits, dtype=np.int8))
+        total = int(self._lib.gpsacq_sig_tx_samples(int(d.size), int(n_repeat)))
+        n = total - int(first_sample) if n_samples is None else int(n_samples)
+        out = np.zeros(2 * n, dtype=np.int8)
+        _check(self._lib, self._lib.gpsacq_generate_sig_tx(self._h, int(prn), d.ctypes.data_as(ctypes.c_void_p), int(d.size), int(n_repeat),
+                                                           int(first_sample), n, out.ctypes.data_as(ctypes.c_void_p)))
         return out
 
     def generate_device(self, d_bits_ptr, n_bytes, sats=(), noise_sigma=1.0, seed=1, sync=True):

@@ -27,6 +27,7 @@
  *                            capture: proc_rtl_bin_for_gps.m:12-26,31-47, proc_hackrf_bin_for_gps.m:7-19
  *   gpsacq_generate          the role of gps_sig_gen.m (synthetic 1-bit capture; here noise + any PRN set with Doppler)
  *   gpsacq_generate_sig      gps_sig_gen.m:8-41 itself (one PRN, navigation bits, raised-cosine BPSK at fs/4), bit-exact
+ *   gpsacq_generate_sig_tx   gps_sig_gen.m:21-30, the script's int8 complex-baseband file for HackRF replay
  *   gpsacq_handoff           CHANNEL::Start()'s NCO set-up from a search hit, c/channel.cpp:134-163
  *                            (the first consumer of the search result in the online receiver)
  *   gpsacq_sample_spectrum   Sample()'s fwd_buf      c/search_offline.cpp:161 (parity probe)
@@ -323,6 +324,17 @@ GPSACQ_API int gpsacq_generate_device(gpsacq_engine* e, void* d_bits_out, size_t
  */
 GPSACQ_API size_t gpsacq_sig_bytes(int n_data_bits);
 GPSACQ_API int gpsacq_generate_sig(gpsacq_engine* e, int prn, const int8_t* data_bits, int n_data_bits, uint8_t* bits_out, size_t n_bytes);
+/*
+ * The script's OTHER output (gps_sig_gen.m:21-30, gps_sig_tmp_for_hackrf_tx.bin -- what README.md section 2.2 replays through a
+ * HackRF): the same shaped baseband, the navigation-bit sequence n_repeat times over (5 in the script), times 50, as 8-bit
+ * complex samples at IF 0: I = int8(round(x * 50)), Q = 0, interleaved.  The stream has gpsacq_sig_tx_samples(n_data_bits,
+ * n_repeat) = n_repeat * n_data_bits * 20 * 1023 * 8 + 48 complex samples (164 MB for the script's 100 bits x 5); any range
+ * [first_sample, first_sample + n_samples) of it is written to iq_out[2 * n_samples].  Search it as complex baseband:
+ * gpsacq_iq8_input{format = GPSACQ_IQ_S8, remove_dc = 0, multibit = GPSACQ_SAMPLES_COMPLEX} at fs = 8.184e6 (fc plays no part).
+ */
+GPSACQ_API uint64_t gpsacq_sig_tx_samples(int n_data_bits, int n_repeat);
+GPSACQ_API int gpsacq_generate_sig_tx(gpsacq_engine* e, int prn, const int8_t* data_bits, int n_data_bits, int n_repeat,
+                           uint64_t first_sample, size_t n_samples, int8_t* iq_out);
 
 /*
  * Acquisition hand-off record: what the tracking channel derives from a search hit

@@ -14,6 +14,11 @@ What the script does (citations: /root/reference/gps_sig_gen.m):
           decides the written bit
   :37-41  bit = (1 - sign(y))/2 written as 'ubit1' (LSB first); y == 0 gives 0.5, which fwrite rounds to 1
 
+  :21-30  the script's OTHER output, gps_sig_tmp_for_hackrf_tx.bin (README.md section 2.2 replays it through a HackRF):
+          x = conv(rcosine(1, 8), [data data data data data]) .* 50 as I, zeros as Q, interleaved, fwrite 'int8' (round to
+          nearest, ties away from zero, saturating) -- the same shaped baseband as the 1-bit file's, five times over, at IF 0
+          (hackrf_tx() below; the file itself is not bundled)
+
 Pin: with the 100 recovered bits generate() reproduces the reference's gps_sig_tmp.bin (2 046 006 bytes,
 sha256 a6242849...) BIT FOR BIT (tests/test_siggen.py).  Two details that the file itself settles: conv() accumulates
 oldest input first (MATLAB's filter order; the reverse order differs in 287 900 samples where shaped pulses cancel to
@@ -79,3 +84,59 @@ def recover_data_bits(capture_bytes, chips01):
     g = 1.0 - 2.0 * np.asarray(chips01, dtype=np.float64)
     per = (s * np.tile(g, CA_PER_DATA * n_data)).reshape(n_data, CA_PER_DATA * 1023).mean(axis=1)
     return np.sign(per), float(np.abs(per).min())
+
+
+# ---- gps_sig_gen.m:21-30: the HackRF transmit file ------------------------------------------------------------------------
+TX_REPEAT = 5     # x = [data, data, data, data, data], :23
+TX_SCALE = 50.0   # .*50, :25
+
+
+def tx_samples(n_data, n_repeat=TX_REPEAT):
+    """complex samples of the transmit file: length(conv(num, x)) = n_repeat * n_data * 20 * 1023 * 8 + 48"""
+    return n_repeat * n_data * CA_PER_DATA * 1023 * OV + 48
+
+
+def matlab_int8(v):
+    """fwrite(fid, v, 'int8') of doubles: round to nearest, ties away from zero (MATLAB round), saturate to [-128, 127]"""
+    v = np.asarray(v, dtype=np.float64)
+    t = np.trunc(v)
+    r = np.where(np.abs(v - t) == 0.5, t + np.sign(v), np.rint(v))
+    return np.clip(r, -128, 127).astype(np.int8)
+
+
+def tx_baseband(chips01, data_pm1, first=0, count=None, n_repeat=TX_REPEAT, newest_first=False):
+    """conv(num, x)[first : first + count] in double, x = the impulse train of n_repeat copies of the data-modulated code
+    (:13-19,23-24).  Accumulated oldest input first like shaped_pulses(); newest_first=True adds the seven terms in the
+    opposite order -- MATLAB's order for conv(short, long) is not documented, and the int8 file cannot tell (the two differ
+    by ~1e-17 where pulses cancel; a written value only moves if x * 50 sits within that of a half-integer), which
+    tests/test_siggen.py asserts on every sample it generates."""
+    g = 1.0 - 2.0 * np.asarray(chips01, dtype=np.float64)
+    data = np.asarray(data_pm1, dtype=np.float64)
+    n_chip = n_repeat * len(data) * CA_PER_DATA * 1023
+    total = n_chip * OV + 48
+    if count is None:
+        count = total - first
+    assert 0 <= first and first + count <= total
+    h = rcosine_taps()
+    m = np.arange(first, first + count, dtype=np.int64)
+    jmax = m // OV
+    acc = np.zeros(count)
+    order = range(0, 7) if newest_first else range(6, -1, -1)
+    for o in order:
+        j = jmax - o
+        tap = m - OV * j
+        ok = (j >= 0) & (j < n_chip) & (tap < len(h))
+        jj = j[ok]
+        d = data[(jj // (CA_PER_DATA * 1023)) % len(data)] * g[jj % 1023]
+        term = np.zeros(count)
+        term[ok] = d * h[tap[ok]]
+        acc = acc + term
+    return acc
+
+
+def hackrf_tx(chips01, data_pm1, first=0, count=None, n_repeat=TX_REPEAT, newest_first=False):
+    """gps_sig_tmp_for_hackrf_tx.bin, complex samples first .. first + count - 1, as interleaved int8 (I, Q = 0), :25-29"""
+    x = tx_baseband(chips01, data_pm1, first, count, n_repeat, newest_first) * TX_SCALE
+    out = np.zeros(2 * x.size, dtype=np.int8)
+    out[0::2] = matlab_int8(x)
+    return out

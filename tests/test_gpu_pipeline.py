@@ -327,33 +327,6 @@ def test_multi_engines_sharing_one_gpu(golden_dir, n_eng):
             assert np.array_equal(got, wgrid)  # snr, lo_shift, ca_shift and the winner's max_pwr
 
 
-@pytest.mark.parametrize("fc,fs,file", [(4.092e6, 5.456e6, "synth_nott_fs5456.bin"), (2.046e6, 8.184e6, "gps_sig_tmp.bin"), (0.62e6, 2.8e6, "synth_rtl_fs2800.bin")])
-def test_eight_wave_correlator_matches_the_product(golden_dir, fc, fs, file):
-    """k_corr8 (GPSACQ_CORR8=2: 5 x 10 x 10 x 10 on 500 threads, an opt-in experiment kept for A/B runs) computes the same cells
-    as the product's k_corr: powers to 2e-6, identical argmax, through a child process so that the switch is read at create."""
-    import json
-    buf = os.path.join(golden_dir, file)
-    child = (
-        "import sys, json, numpy as np; sys.path.insert(0, %r); import gpsacq\n"
-        "buf = open(%r, 'rb').read()[:33 * 5120]\n"
-        "with gpsacq.Engine(%r, %r, 5000.0) as e:\n"
-        "    c, p = e.search(buf)\n"
-        "np.save(sys.argv[1], c)\n" % (os.path.join(ROOT, "gnss-gps-sdr_amd", "python"), buf, fc, fs))
-    import tempfile
-    with tempfile.TemporaryDirectory() as d:
-        outs = []
-        for env in ({}, {"GPSACQ_CORR8": "2"}):
-            f = os.path.join(d, "c%d.npy" % len(outs))
-            r = subprocess.run([sys.executable, "-c", child, f], env=dict(os.environ, **env), capture_output=True, text=True, timeout=300)
-            assert r.returncode == 0, r.stderr[-1500:]
-            outs.append(np.load(f))
-    a, b = outs
-    assert not np.array_equal(a["tot_pwr"], b["tot_pwr"])  # it really was another kernel
-    np.testing.assert_allclose(b["max_pwr"], a["max_pwr"], rtol=2e-6)
-    np.testing.assert_allclose(b["tot_pwr"], a["tot_pwr"], rtol=2e-6)
-    assert (a["max_i"] != b["max_i"]).sum() <= 1
-
-
 def test_sample_spectrum_on_a_fresh_fine_grid_engine(golden_dir):
     """Advisor r2: gpsacq_sample_spectrum after gpsacq_set_doppler_step on an engine that never searched used to write
     `sub` spectra into a one-spectrum buffer.  The probe now transforms exactly one (offset 0) spectrum."""

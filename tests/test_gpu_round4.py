@@ -132,3 +132,61 @@ def test_multi_enqueue_time_is_flat_in_the_number_of_engines(golden_dir):
     print("engines: (enqueue ms, total ms)", rows)
     # generous: thread start-up and 8 x the launches on one GPU's queues; the serial form grew by the whole copy + search per engine
     assert rows[8][0] < rows[1][0] + 0.5 * rows[1][1], rows
+
+
+# ---- gps_sig_gen.m:21-30: the HackRF transmit file, generated on the device and searched as complex baseband -------------
+def _chips(prn):
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    from oracle_lib import lib, _p
+    c = np.zeros(1023, np.uint8)
+    lib("f64").oracle_ca_chips(prn - 1, _p(c))
+    return c
+
+
+def test_device_tx_generator_equals_the_restatement_and_is_found_as_complex_baseband(golden_dir, tmp_path):
+    """gpsacq_generate_sig_tx (k_siggen_tx) against oracle/sig_gen_oracle.py::hackrf_tx, bit for bit, on the head of the stream,
+    the seam between two repetitions and the filter tail; then the script's known answer through the product's complex-baseband
+    path (int8, no DC removal, IF 0, fs 8.184 MHz): PRN 8 in every block, Doppler bin 0 +- 1, ca_shift = (40960 b - 20) mod 8184
+    -- the law of the 1-bit file (384 blocks pinned there), here in the second file format; and the front end on the file."""
+    import gpsacq
+    import sig_gen_oracle as sg
+    db = json.load(open(os.path.join(golden_dir, "gps_sig_tmp_databits.json")))
+    prn, data = db["prn"], db["bits_pm1"]
+    chips = _chips(prn)
+    total, per_rep = sg.tx_samples(len(data)), 16368000
+    with gpsacq.Engine(0.0, 8.184e6, 5000.0) as eng:
+        for first, count in ((0, 2 * 1310720), (per_rep - 300000, 600000), (total - 100000, 100000)):
+            got = eng.generate_sig_tx(prn, data, first_sample=first, n_samples=count)
+            want = sg.hackrf_tx(chips, data, first=first, count=count)
+            assert got.dtype == np.int8 and np.array_equal(got, want), (first, int((got != want).sum()))
+        with pytest.raises(gpsacq.GpsAcqError):
+            eng.generate_sig_tx(prn, data, first_sample=total - 10, n_samples=11)
+        # two runs of the file (64 blocks of 40960 complex samples) + the blocks around the repetition seam
+        nblk = 64
+        iq = eng.generate_sig_tx(prn, data, first_sample=0, n_samples=nblk * 40960)
+        inp = eng.iq8_input(signed=True, remove_dc=False, total_samples=iq.size // 2, multibit=2)
+        tasks = [(b, prn - 1) for b in range(nblk)] + [(0, sv) for sv in range(32)]
+        _, pk = eng.search_iq8(iq, inp, tasks=tasks)
+        for b in range(nblk):
+            assert pk["snr"][b] > 300 and abs(int(pk["lo_shift"][b])) <= 1 and int(pk["ca_shift"][b]) == (40960 * b - 20) % 8184, (b, pk[b])
+        blk0 = pk[nblk:]
+        assert int(np.argmax(blk0["snr"])) == prn - 1 and np.sort(blk0["snr"])[-2] < 40
+        seam = eng.generate_sig_tx(prn, data, first_sample=398 * 40960, n_samples=4 * 40960)
+        _, ps = eng.search_iq8(seam, eng.iq8_input(signed=True, remove_dc=False, total_samples=seam.size // 2, multibit=2), tasks=[(i, prn - 1) for i in range(4)])
+        for i in range(4):  # (block 399 holds the bit flip of the seam: its broad peak sits one lag early, in the float64 restatement too)
+            assert ps["snr"][i] > 300 and int(ps["ca_shift"][i]) == (40960 * (398 + i) - 20) % 8184 - (1 if i == 1 else 0)
+        # reference schedule on the file: gps_test's report names sv 7 in both runs, at the ca_shift of block 32 r + 7
+        path = str(tmp_path / "gps_sig_tmp_for_hackrf_tx.head.bin")
+        iq.tofile(path)
+    exe = os.path.join(ROOT, "gnss-gps-sdr_amd", "bin", "gps_test")
+    r = subprocess.run([exe, path, "0", "8.184e6", "5000"], capture_output=True, text=True, timeout=300,
+                       env=dict(os.environ, GPSACQ_INPUT="iq_s8", GPSACQ_IQ_COMPLEX="1", GPSACQ_IQ_KEEP_DC="1"))
+    assert r.returncode == 0, r.stderr
+    lines = r.stdout.splitlines()
+    for run in range(2):
+        sat = [l for l in lines if l.startswith("%2d satellite:" % run)][0].split(":")[1].split()
+        ca = [l for l in lines if l.startswith("%2d  ca_shift:" % run)][0].split(":")[1].split()
+        lo = [l for l in lines if l.startswith("%2d  lo_shift:" % run)][0].split(":")[1].split()
+        k = sat.index("7")
+        assert int(ca[k]) == (40960 * (32 * run + 7) - 20) % 8184 and abs(int(lo[k])) <= 1
+    assert "run out of file!" in r.stdout

@@ -52,6 +52,67 @@ def test_product_tap_table_is_rcosine(golden_dir):
     assert len(vals) == 49 and np.array_equal(np.array(vals), sg.rcosine_taps())
 
 
+# ---- gps_sig_gen.m:21-30: the HackRF transmit file (second reference-defined known answer, complex-baseband format) ----
+def test_tx_restatement_against_the_reference_held_1bit_file(golden_dir):
+    """hackrf_tx() is the same shaped baseband as the bundled 1-bit file's, x 50, at IF 0.  Pins: (1) on every even sample the
+    fs/4 carrier of the 1-bit leg is exactly +-1, so the sign of the transmit file's I there must BE the reference file's bit
+    (wherever int8 did not round it to 0) -- the reference's own file checks the restated baseband of the first repetition;
+    (2) chip centres read exactly +-50 x data x chip, Q is zero, the stream has 5 x 16 368 000 + 48 samples; (3) the written
+    int8 does not depend on the order conv() adds its terms (undocumented for conv(short, long)): both orders, every sample."""
+    import sig_gen_oracle as sg
+    db = json.load(open(os.path.join(golden_dir, "gps_sig_tmp_databits.json")))
+    chips = _chips(db["prn"])
+    ref_bits = np.unpackbits(np.fromfile(os.path.join(golden_dir, "gps_sig_tmp.bin"), dtype=np.uint8), bitorder="little")
+    assert sg.tx_samples(len(db["bits_pm1"])) == 5 * 16368000 + 48
+    per_rep = 16368000
+    for first, count in ((0, 3000000), (per_rep - 1000000, 1000000)):
+        iq = sg.hackrf_tx(chips, db["bits_pm1"], first=first, count=count)
+        assert np.array_equal(iq, sg.hackrf_tx(chips, db["bits_pm1"], first=first, count=count, newest_first=True))
+        i, q = iq[0::2].astype(np.int32), iq[1::2]
+        assert not q.any() and np.abs(i).max() <= 75
+        m = np.arange(first, first + count)
+        bit = ref_bits[m]
+        e0, e2 = (m % 4 == 0) & (i != 0), (m % 4 == 2) & (i != 0)
+        assert e0.sum() > 0.2 * count and e2.sum() > 0.2 * count  # (I rounds to 0 on ~7 % of the samples: chip transitions)
+        assert np.array_equal(bit[e0], (i[e0] < 0).astype(np.uint8))   # carrier +1: bit = (s < 0)
+        assert np.array_equal(bit[e2], (i[e2] > 0).astype(np.uint8))   # carrier -1: bit = (s > 0)
+        centre = (m % 8 == 0) & (m >= 24)
+        k = (m[centre] - 24) // 8
+        g = 1 - 2 * chips.astype(np.int32)
+        d = np.asarray(db["bits_pm1"])[(k // 20460) % 100]
+        assert np.array_equal(i[centre], 50 * d * g[k % 1023])
+    # the second repetition repeats the first (16 368 000 samples = 2000 whole code periods, 100 whole bits); the tail is the filter's
+    a = sg.hackrf_tx(chips, db["bits_pm1"], first=48, count=200000)
+    b = sg.hackrf_tx(chips, db["bits_pm1"], first=per_rep + 48, count=200000)
+    assert np.array_equal(a, b)
+    tail = sg.hackrf_tx(chips, db["bits_pm1"], first=5 * per_rep, count=48)
+    assert tail[0::2].any() and not tail[1::2].any()
+
+
+def test_tx_file_searched_as_complex_baseband_on_the_cpu(golden_dir):
+    """The known answer the script defines for its transmit file, through Correlate() restated on complex samples (float64):
+    PRN 8 at Doppler bin 0, code phase (40960 b - 20) mod 8184 at block b -- the same law as the 1-bit file's
+    (test_oracle.py::test_code_phase_follows_from_gps_sig_gen), also across the seam of two repetitions (block 400)."""
+    import sig_gen_oracle as sg
+    from iq8_oracle import complex_cells
+    sys.path.insert(0, os.path.join(ROOT, "tests", "golden"))
+    from make_golden import code_replica
+    db = json.load(open(os.path.join(golden_dir, "gps_sig_tmp_databits.json")))
+    chips, fs = _chips(db["prn"]), 8.184e6
+    for b in (0, 7, 399, 400):
+        iq = sg.hackrf_tx(chips, db["bits_pm1"], first=40960 * b, count=40000)
+        z = iq[0::2].astype(np.float64) + 1j * iq[1::2].astype(np.float64)
+        mp, mi, tp = complex_cells(z, code_replica(fs, db["prn"] - 1), 24, 8184)
+        snr = mp / (tp / 8184)
+        k = int(np.argmax(snr))
+        # block 399 holds the seam 24 960 samples in, where navigation bit 99 (+1) meets bit 0 (-1): the two parts of the block
+        # pull against each other (a quarter of the amplitude is left) and the broad peak (8 samples per chip) tips to the next lag
+        want = (40960 * b - 20) % 8184
+        assert k - 24 == 0 and snr[k] > 300 and (mi[k] == want if b != 399 else mi[k] == want - 1)
+        mp2, _, tp2 = complex_cells(z, code_replica(fs, 3), 24, 8184)  # another PRN: nothing
+        assert (mp2 / (tp2 / 8184)).max() < 40
+
+
 @pytest.mark.gpu
 def test_device_generator_reproduces_the_reference_file(golden_dir):
     """gpsacq_generate_sig (gen_kernels.hip, k_siggen) against the reference's own gps_sig_tmp.bin: every one of the
