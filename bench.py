@@ -376,6 +376,29 @@ class Leg:
         return float(t.item()), (float(np.mean(corr_ms)) if corr_ms else 0.0), best
 
 
+_REAL_STDOUT = None
+
+
+def claim_stdout():
+    """From here on file descriptor 1 is stderr, and the JSON line is written to the saved descriptor of the real stdout:
+    libraries that print to the C-level stdout (RCCL writes a five-line version banner there when its communicator comes up,
+    flushed at exit, i.e. AFTER the result) can no longer add lines to what the driver parses."""
+    global _REAL_STDOUT
+    if _REAL_STDOUT is None:
+        sys.stdout.flush()
+        _REAL_STDOUT = os.dup(1)
+        os.dup2(2, 1)
+
+
+def emit(line):
+    data = (line + "\n").encode()
+    if _REAL_STDOUT is None:
+        sys.stdout.write(line + "\n")
+        sys.stdout.flush()
+    else:
+        os.write(_REAL_STDOUT, data)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -422,6 +445,7 @@ def main():
                "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
         raise SystemExit(subprocess.call(cmd))
 
+    claim_stdout()
     import torch
 
     rank = int(os.environ.get("RANK", "0"))
@@ -439,7 +463,7 @@ def main():
             seen = int(t.item())
             dist.destroy_process_group()
         if rank == 0:
-            print(json.dumps({"spawn_check": True, "n_gpus": args.gpus, "rccl_ranks_seen": seen, "world_size_env": world}), flush=True)
+            emit(json.dumps({"spawn_check": True, "n_gpus": args.gpus, "rccl_ranks_seen": seen, "world_size_env": world}))
         return
     import gpsacq
     from gpsacq import dist as gdist
@@ -736,7 +760,7 @@ def main():
             except Exception as ex:
                 out["e2e_cli"] = {"error": str(ex)}
         out.update(extra)
-        print(json.dumps(out), flush=True)
+        emit(json.dumps(out))
     if dist is not None:
         dist.destroy_process_group()
 

@@ -16,6 +16,8 @@
 // one pair are mapped to one XCD.
 #include <hip/hip_runtime.h>
 
+#include <cstdlib>
+
 #include "acq_launch.hpp"
 #include "acq_phases.hpp"
 
@@ -96,6 +98,46 @@ __global__ __launch_bounds__(WG) void k_fwd(FwdArgs a) {
         cf y[RC];
         fwd_phase3_load(tid, lds, y);
         fwd_phase3_store(tid, a.conj_out != 0, y, a.out + (size_t)item * a.item_stride + (size_t)kappa * a.row + a.off);
+    }
+}
+
+// The 1-bit / 8-bit IQ capture, second form (acq_phases.hpp fwd2_*): same spectra (conjugated, polyphase rows) as k_fwd<SRC_BITS>
+// to float rounding; three workgroups per CU (46 KB of LDS, <= 168 VGPRs).
+template <int SRC>
+__global__ __launch_bounds__(WG, 3) void k_fwd2(FwdArgs a) {
+    static_assert(SRC == SRC_BITS || SRC == SRC_IQ8, "k_fwd2 is the 1-bit path");
+    __shared__ __attribute__((aligned(16))) cf lds[M_SUB];  // transform buffer; before the first row: staging of the transposed block
+    __shared__ cf t2s[NT2];
+    __shared__ cf lutc[256];
+    const int tid = threadIdx.x, item = blockIdx.x;
+    const int srci = item / a.sub, r = item - srci * a.sub;
+    uint8_t* stage = reinterpret_cast<uint8_t*>(lds);            // [5000] converted bytes (iq8 only)
+    uint64_t* ib = reinterpret_cast<uint64_t*>(stage + 8192);    // [625]
+    uint64_t* qb = reinterpret_cast<uint64_t*>(stage + 16384);   // [625]
+    if (SRC == SRC_BITS) fwd_stage_bits(tid, (const uint8_t*)a.src + (size_t)srci * a.src_stride, a.cos_t, a.sin_t, ib, qb);
+    if (SRC == SRC_IQ8) {
+        fwd_convert_iq8(tid, (const uint8_t*)a.src + (size_t)srci * a.src_stride, a.iq_first + (size_t)srci * (a.src_stride / 2), a.iq_total, a.iq, stage);
+        __syncthreads();
+        fwd_stage_bits(tid, stage, a.cos_t, a.sin_t, ib, qb);
+    }
+    for (int i = tid; i < NT2; i += WG) t2s[i] = a.t2[i];
+    cf w[2][RA - 1];
+    load_tw1<true>(tid, a.t1, w);
+    __syncthreads();
+    uint32_t packed[RA];
+    fwd2_load_bytes(tid, reinterpret_cast<const uint8_t*>(ib), reinterpret_cast<const uint8_t*>(qb), packed);
+    const cf* lut_rows = a.lutc + (size_t)r * NPOLY * 256 + tid;  // this thread's entry of each row's look-up table (host-built)
+    lutc[tid] = lut_rows[0];
+    for (int kappa = 0; kappa < NPOLY; ++kappa) {
+        const cf* tn_row = a.tn + ((size_t)r * NPOLY + kappa) * M_SUB;
+        const cf next_lut = lut_rows[(kappa + 1 < NPOLY ? kappa + 1 : kappa) * 256];  // requested a row ahead
+        __syncthreads();  // table ready; the bytes are in registers (first row) / the previous row's pass-3 reads are done
+        fwd2_phase1(tid, packed, lutc, tn_row, w, lds);
+        __syncthreads();
+        lutc[tid] = next_lut;  // every look-up of this row is done; the next row reads it two barriers on
+        fwd2_phase2(tid, t2s, lds);
+        __syncthreads();
+        fwd2_phase3_store(tid, lds, a.out + (size_t)item * a.item_stride + (size_t)kappa * a.row + a.off);
     }
 }
 
@@ -574,11 +616,17 @@ __global__ __launch_bounds__(WG) void k_peaks(const Cell* cells, Peak* peaks, in
 
 // ---------------------------------------------------------------------------------------
 // launchers (host)
+static bool fwd_v1() {  // GPSACQ_FWD1=1: round 3's forward kernel (A/B runs)
+    static const bool v1 = [] { const char* v = getenv("GPSACQ_FWD1"); return v && *v && atoi(v) != 0; }();
+    return v1;
+}
 void launch_fwd_bits(const FwdArgs& a, int n_items, hipStream_t s) {
-    hipLaunchKernelGGL(k_fwd<SRC_BITS>, dim3(n_items), dim3(WG), 0, s, a);
+    if (fwd_v1() || !a.conj_out) hipLaunchKernelGGL(k_fwd<SRC_BITS>, dim3(n_items), dim3(WG), 0, s, a);
+    else hipLaunchKernelGGL(k_fwd2<SRC_BITS>, dim3(n_items), dim3(WG), 0, s, a);
 }
 void launch_fwd_iq8(const FwdArgs& a, int n_items, hipStream_t s) {
-    hipLaunchKernelGGL(k_fwd<SRC_IQ8>, dim3(n_items), dim3(WG), 0, s, a);
+    if (fwd_v1() || !a.conj_out) hipLaunchKernelGGL(k_fwd<SRC_IQ8>, dim3(n_items), dim3(WG), 0, s, a);
+    else hipLaunchKernelGGL(k_fwd2<SRC_IQ8>, dim3(n_items), dim3(WG), 0, s, a);
 }
 void launch_fwd_realmix(const FwdArgs& a, int n_items, hipStream_t s) {
     hipLaunchKernelGGL(k_fwd<SRC_REALMIX>, dim3(n_items), dim3(WG), 0, s, a);

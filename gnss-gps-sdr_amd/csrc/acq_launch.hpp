@@ -24,6 +24,7 @@ struct FwdArgs {
     const cf* t2;
     const cf* tn;        // [sub][8][5000] W_N^{n' (kappa + r/sub)}
     const cf* rot8;      // [sub][8][8]    exp(-2 pi i nu (kappa + r/sub) / 8)   (bits source only)
+    const cf* lutc;      // [sub][8][256]  conjugated radix-8 sums by transposed byte (k_fwd2; acq_tables.hpp forward_tables)
     int sub;             // spectra per source item (sub-bin Doppler offsets r/sub, r < sub); item i -> (source i / sub, r = i % sub)
     cf* out;             // [n_items][item_stride], polyphase rows
     size_t item_stride;  // complex elements per item in out

@@ -387,6 +387,60 @@ ACQ_HD void fwd_phase1(int tid, int kappa, const Src& src, const cf* __restrict_
     pass1_store<-1>(x0, 2 * tid, w[0], lds);
     pass1_store<-1>(x1, 2 * tid + 1, w[1], lds);
 }
+// ---- the 1-bit path, second form (round 4): the transform runs in the BACKWARD direction on conjugated inputs, so that the
+// conjugated spectrum Correlate() wants (:183-184) comes out as it is (no negation pass before the stores); the thread's 40
+// sample bytes (the same for all eight rows) live in ten registers instead of being re-read from LDS per row -- the staging
+// area is the transform buffer itself -- which makes room in LDS for pass 2's twiddle table; the look-ups of a row are
+// issued in two batches of twenty before anything waits for one; half of the pass-1 twiddles are derived (W1H).
+// packed[a] = bytes (I[n0], I[n0 + 1], Q[n0], Q[n0 + 1]) of the transposed block at n0 = 2 tid + 500 a
+ACQ_HD void fwd2_load_bytes(int tid, const uint8_t* ib, const uint8_t* qb, uint32_t (&packed)[RA]) {
+    if (tid >= NBF3) return;
+#pragma unroll
+    for (int a = 0; a < RA; ++a) {
+        const uint32_t i2 = *reinterpret_cast<const uint16_t*>(ib + 2 * tid + NBF1 * a);
+        const uint32_t q2 = *reinterpret_cast<const uint16_t*>(qb + 2 * tid + NBF1 * a);
+        packed[a] = i2 | (q2 << 16);
+    }
+}
+// w0: the thread's pass-1 twiddles W_5000^{2 tid alpha} (load_tw1<true>)
+ACQ_HD void fwd2_phase1(int tid, const uint32_t (&packed)[RA], const cf* lutc, const cf* __restrict__ tn_row, const cf (&w)[2][RA - 1], cf* lds) {
+    if (tid >= NBF3) return;
+    const cf* tk = tn_row + 2 * tid;
+    cf x0[RA], x1[RA];
+    constexpr int HALF = RA / 2;
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+        cf li0[HALF], li1[HALF], lq0[HALF], lq1[HALF], t0[HALF], t1[HALF];
+#pragma unroll
+        for (int i = 0; i < HALF; ++i) {
+            const uint32_t v = packed[h * HALF + i];
+            li0[i] = lutc[v & 0xffu];
+            li1[i] = lutc[(v >> 8) & 0xffu];
+            lq0[i] = lutc[(v >> 16) & 0xffu];
+            lq1[i] = lutc[v >> 24];
+            ld2(tk + NBF1 * (h * HALF + i), t0[i], t1[i]);
+        }
+        ACQ_SCHED_FENCE();
+#pragma unroll
+        for (int i = 0; i < HALF; ++i) {  // conj(z tn) = conj(z) conj(tn), conj(z) = conj(lut[I]) - i conj(lut[Q])
+            x0[h * HALF + i] = cmulc(sub_i(li0[i], lq0[i]), t0[i]);
+            x1[h * HALF + i] = cmulc(sub_i(li1[i], lq1[i]), t1[i]);
+        }
+    }
+    pass1_store_pair_w1h<+1, LayA>(x0, x1, 2 * tid, w[0], lds);
+}
+ACQ_HD void fwd2_phase2(int tid, const cf* t2s, cf* lds) {
+    if (tid < NBF2) pass2_inplace<+1>(tid, t2s, lds);
+}
+// pass 3 and the stores: output n of the 64 lanes of a wave is 64 consecutive bins k' = 250 n + tid of the row, already conjugated
+ACQ_HD void fwd2_phase3_store(int tid, const cf* lds, cf* dst) {
+    if (tid >= NBF3) return;
+    cf y[RC];
+    pass3_load<+1>(tid, lds, y);
+#pragma unroll
+    for (int n = 0; n < RC; ++n) dst[NBF3 * n + tid] = y[n];
+}
+
 ACQ_HD void fwd_phase2(int tid, const cf* __restrict__ t2, cf* lds) {
     if (tid < NBF2) pass2_inplace<-1>(tid, t2, lds);
 }

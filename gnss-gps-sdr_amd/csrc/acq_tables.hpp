@@ -83,9 +83,35 @@ struct Tables8 {
 // sub = 1): spectrum r of a block is the transform of x[n] exp(-2 pi i (r/sub) n / N), i.e. the block's spectrum
 // evaluated r/sub of a bin higher, which the decimation-in-frequency split absorbs exactly into its twiddles:
 //   tn [r][kappa][n'] = exp(-2 pi i n' (kappa + r/sub) / N),   rot8[r][kappa][nu] = exp(-2 pi i nu (kappa + r/sub) / 8)
-inline void forward_tables(int sub, std::vector<cf>& tn, std::vector<cf>& rot8) {
+//   lutc[r][kappa][b]  = conj( sum_nu (+1 / -1 by bit nu of b: Bipolar(), :68-70) rot8[r][kappa][nu] ): the pruned radix-8 sum of the
+//                        eight 1-bit samples a transposed byte holds, conjugated (k_fwd2 runs the transform backwards on
+//                        conjugated inputs); summed in long double from the exact angles
+inline void forward_tables(int sub, std::vector<cf>& tn, std::vector<cf>& rot8, std::vector<cf>* lutc = nullptr) {
     tn.resize((size_t)sub * NPOLY * M_SUB);
     rot8.resize((size_t)sub * NPOLY * NPOLY);
+    if (lutc) {
+        lutc->resize((size_t)sub * NPOLY * 256);
+        const long double tp = 6.283185307179586476925286766559005768L;
+        for (int r = 0; r < sub; ++r)
+            for (int ka = 0; ka < NPOLY; ++ka) {
+                long double c[NPOLY], sn[NPOLY];
+                for (int nu = 0; nu < NPOLY; ++nu) {
+                    long long num = ((long long)ka * sub + r) * nu % ((long long)NPOLY * sub);
+                    const long double th = tp * (long double)num / (long double)(NPOLY * sub);
+                    c[nu] = cosl(th);
+                    sn[nu] = -sinl(th);
+                }
+                for (int b = 0; b < 256; ++b) {
+                    long double re = 0, im = 0;
+                    for (int nu = 0; nu < NPOLY; ++nu) {
+                        const long double sg = ((b >> nu) & 1) ? -1.0L : 1.0L;
+                        re += sg * c[nu];
+                        im += sg * sn[nu];
+                    }
+                    (*lutc)[((size_t)r * NPOLY + ka) * 256 + b] = mk((float)re, (float)(-im));
+                }
+            }
+    }
     for (int r = 0; r < sub; ++r)
         for (int ka = 0; ka < NPOLY; ++ka) {
             const long long m = (long long)ka * sub + r;  // (kappa + r/sub) * sub

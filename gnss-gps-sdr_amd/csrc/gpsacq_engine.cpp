@@ -51,15 +51,12 @@ __attribute__((visibility("hidden"))) int acq::set_last_error(int code, const ch
 
 struct gpsacq_engine {
     gpsacq_params p{};
-    // GPSACQ_WARM=1: the first launch of each search kernel (runtime-side set-up of a kernel's first dispatch) is made by a
-    // worker right after gpsacq_create, on its own stream and buffers, while the caller allocates its staging buffers; the
-    // first search waits for it (join_warm)
-    std::future<void> warm;
     int dmax = 0, ndop = 0, dop_first = 0, nlags = 0, mc = 0, halo = 0, crow = 0;  // searched bins: dop_first .. +ndop-1
     int n_acc = 1, acc_step = 0;  // non-coherent accumulation (gpsacq_set_noncoherent)
     // Doppler grid (gpsacq_set_doppler_step): step = bin * dstride / sub, points -kmax..+kmax; sub = dstride = 1 is the reference's
     int sub = 1, dstride = 1, kmax = 0;
     cf* d_rot8 = nullptr;
+    cf* d_lutc = nullptr;  // [sub][8][256] look-up tables of k_fwd2
     bool creep_comp = false;      // re-align accumulated blocks by the code creep of each Doppler bin
     bool block_align = false;     // re-align accumulated blocks by the code phase between their starts (any stride)
     int cus = 0;
@@ -197,6 +194,7 @@ static int run_forward(gpsacq_engine* e, FwdKind kind, const void* src, size_t s
         }
         fa.sub = sub;
         fa.rot8 = e->d_rot8;
+        fa.lutc = e->d_lutc;
         fa.cos_t = e->d_cos_t;
         fa.sin_t = e->d_sin_t;
         fa.t1 = e->d_t1;
@@ -218,14 +216,11 @@ static int run_forward(gpsacq_engine* e, FwdKind kind, const void* src, size_t s
 
 extern "C" const char* gpsacq_last_error(void) { return g_err.c_str(); }
 
-static void join_warm(gpsacq_engine* e);
-static void warm_kernels(gpsacq_engine* e);
 extern "C" void gpsacq_destroy(gpsacq_engine* e) {
     if (!e) return;
-    join_warm(e);
     (void)hipSetDevice(e->p.device);
     if (e->stream) (void)hipStreamSynchronize(e->stream);
-    void* bufs[] = {e->d_t1, e->d_t2, e->d_bq, e->d_t2q, e->d_tq, e->d_tn, e->d_rho, e->d_t1_8, e->d_t2_8, e->d_t3_8, e->d_bq8, e->d_cos, e->d_sin, e->d_cos_t, e->d_sin_t, e->d_code, e->d_patch_blocks, e->d_bits, e->d_iq, e->d_iqbits, e->d_fsamp, e->d_pdump, e->d_sums, e->d_sats, e->d_gen, e->d_prof, e->d_rot8,
+    void* bufs[] = {e->d_t1, e->d_t2, e->d_bq, e->d_t2q, e->d_tq, e->d_tn, e->d_rho, e->d_t1_8, e->d_t2_8, e->d_t3_8, e->d_bq8, e->d_cos, e->d_sin, e->d_cos_t, e->d_sin_t, e->d_code, e->d_patch_blocks, e->d_bits, e->d_iq, e->d_iqbits, e->d_fsamp, e->d_pdump, e->d_sums, e->d_sats, e->d_gen, e->d_prof, e->d_rot8, e->d_lutc,
                     e->d_dpp, e->d_parts, e->d_tasks, e->d_cells, e->d_peaks};
     for (void* b : bufs)
         if (b) (void)hipFree(b);
@@ -273,7 +268,7 @@ extern "C" int gpsacq_create(const gpsacq_params* params, gpsacq_engine** out) {
 #ifdef ACQ_EXPERIMENTS
         Tables8 T8;
 #endif
-        std::vector<cf> tn, rot8;
+        std::vector<cf> tn, rot8, lutc;
         std::vector<uint8_t> cosm, sinm;
         std::vector<uint64_t> cos_t, sin_t;
         std::vector<float> rep;
@@ -282,7 +277,7 @@ extern "C" int gpsacq_create(const gpsacq_params* params, gpsacq_engine** out) {
     const gpsacq_params prm = *params;
     auto host_prep = [prm]() {
         std::unique_ptr<HostPrep> h(new HostPrep());
-        forward_tables(1, h->tn, h->rot8);
+        forward_tables(1, h->tn, h->rot8, &h->lutc);
         h->cosm.resize(BLOCK_BYTES);
         h->sinm.resize(BLOCK_BYTES);
         lo_masks(prm.fc, prm.fs, BLOCK_BYTES, h->cosm.data(), h->sinm.data());
@@ -370,6 +365,8 @@ extern "C" int gpsacq_create(const gpsacq_params* params, gpsacq_engine** out) {
     HCK(hipMemcpy(e->d_tn, hp->tn.data(), hp->tn.size() * sizeof(cf), hipMemcpyHostToDevice));
     HCK(hipMalloc((void**)&e->d_rot8, hp->rot8.size() * sizeof(cf)));
     HCK(hipMemcpy(e->d_rot8, hp->rot8.data(), hp->rot8.size() * sizeof(cf), hipMemcpyHostToDevice));
+    HCK(hipMalloc((void**)&e->d_lutc, hp->lutc.size() * sizeof(cf)));
+    HCK(hipMemcpy(e->d_lutc, hp->lutc.data(), hp->lutc.size() * sizeof(cf), hipMemcpyHostToDevice));
     HCK(upload_wq(T.wq.data()));
     HCK(upload_chips(hp->chips.data()));
     {
@@ -440,15 +437,6 @@ extern "C" int gpsacq_create(const gpsacq_params* params, gpsacq_engine** out) {
         fprintf(stderr, "gpsacq trace: gpsacq_create %.1f ms = HIP runtime/device start-up %.1f (host tables and code replicas computed meanwhile; "
                         "waited %.1f more for them) + stream, events, table uploads, code object load %.1f + 32 code spectra %.1f\n",
                 lap(), ms_runtime, ms_prep_wait, ms_tables - ms_runtime - ms_prep_wait, lap() - ms_tables);
-    {
-        const char* wv = getenv("GPSACQ_WARM");
-        if (wv && *wv && atoi(wv) != 0) {
-            try {
-                e->warm = std::async(std::launch::async, [e]() { warm_kernels(e); });
-            } catch (const std::exception&) {  // no thread: no warm-up
-            }
-        }
-    }
     *out = e;
     return GPSACQ_OK;
 }
@@ -576,75 +564,8 @@ static int pass_columns(int n_cols, int p) {
     return left >= MC_MAX ? MC_MAX : corr_columns(left * NBF3);
 }
 
-static void join_warm(gpsacq_engine* e) {
-    if (e->warm.valid()) {
-        try {
-            e->warm.get();
-        } catch (...) {  // a warm-up is an optimisation: nothing of it is an error of the search
-        }
-    }
-}
-// one block, one task through the three kernels of SearchTask() on a private stream and private buffers (results discarded)
-static void warm_kernels(gpsacq_engine* e) {
-    if (hipSetDevice(e->p.device) != hipSuccess) return;
-    hipStream_t st = nullptr;
-    uint8_t* buf = nullptr;
-    const size_t dpp_bytes = (size_t)NPOLY * M_SUB * sizeof(cf), cells_bytes = (size_t)e->ndop * sizeof(Cell);
-    const size_t off_dpp = 8192, off_task = off_dpp + dpp_bytes, off_cells = off_task + 256, off_peaks = off_cells + ((cells_bytes + 255) & ~(size_t)255);
-    if (hipStreamCreateWithFlags(&st, hipStreamNonBlocking) != hipSuccess) return;
-    if (hipMalloc((void**)&buf, off_peaks + 256) == hipSuccess) {
-        (void)hipMemsetAsync(buf, 0, off_dpp + 16, st);
-        FwdArgs fa{};
-        fa.src = buf;
-        fa.src_stride = BLOCK_BYTES;
-        fa.sub = 1;
-        fa.rot8 = e->d_rot8;
-        fa.cos_t = e->d_cos_t;
-        fa.sin_t = e->d_sin_t;
-        fa.t1 = e->d_t1;
-        fa.t2 = e->d_t2;
-        fa.tn = e->d_tn;
-        fa.out = (cf*)(buf + off_dpp);
-        fa.item_stride = (size_t)NPOLY * M_SUB;
-        fa.row = M_SUB;
-        fa.off = 0;
-        fa.conj_out = 1;
-        launch_fwd_bits(fa, 1, st);
-        (void)hipMemsetAsync(buf + off_task, 0, sizeof(Task), st);  // task (spectrum 0, code 0)
-        CorrArgs ca{};
-        ca.dpp = (const cf*)(buf + off_dpp);
-        ca.cpp = e->d_code;
-        ca.tasks = (const Task*)(buf + off_task);
-        ca.t1 = e->d_t1;
-        ca.t2 = e->d_t2;
-        ca.bq = e->d_bq;
-        ca.t2q = e->d_t2q;
-        ca.tq = e->d_tq;
-        ca.rho_map = e->d_rho;
-        ca.cells = (Cell*)(buf + off_cells);
-        ca.n_tasks = 1;
-        ca.ndop = e->ndop;
-        ca.dop_first = e->dop_first;
-        ca.nlags = e->nlags;
-        ca.crow = e->crow;
-        ca.halo = e->halo;
-        ca.n_acc = 1;
-        ca.n_spec = 1;
-        ca.n_code = GPSACQ_NUM_SATS;
-        ca.sub = 1;
-        ca.dstride = 1;
-        if (e->nlags <= MC_MAX * NBF3) (void)launch_corr(ca, e->mc, st);
-        launch_peaks(ca.cells, (Peak*)(buf + off_peaks), 1, e->ndop, e->dop_first, st);
-        (void)hipStreamSynchronize(st);
-        (void)hipFree(buf);
-    }
-    (void)hipStreamDestroy(st);
-    (void)hipGetLastError();
-}
-
 static int search_core(gpsacq_engine* e, const Capture& cap_in, size_t n_blocks, const gpsacq_task* h_tasks,
                        const void* d_user_tasks, size_t n_tasks, Cell* d_cells, Peak* d_peaks) {
-    join_warm(e);
     Capture cap = cap_in;
     if (n_blocks == 0 || n_tasks == 0) return fail(GPSACQ_ERR_ARG, "empty batch");
     if (cap.iq8) {
@@ -1071,7 +992,6 @@ extern "C" int gpsacq_aligned_stride(const gpsacq_engine* e) {
 
 extern "C" int gpsacq_set_doppler_window(gpsacq_engine* e, int first_bin, int n_bins) {
     if (!e) return fail(GPSACQ_ERR_ARG, "gpsacq_set_doppler_window: null engine");
-    join_warm(e);
     if (n_bins <= 0 || first_bin < -e->kmax || first_bin + n_bins - 1 > e->kmax)
         return fail(GPSACQ_ERR_ARG, "Doppler window [%d, %d] outside [-%d, %d]", first_bin, first_bin + n_bins - 1, e->kmax, e->kmax);
     e->dop_first = first_bin;
@@ -1081,7 +1001,6 @@ extern "C" int gpsacq_set_doppler_window(gpsacq_engine* e, int first_bin, int n_
 
 extern "C" int gpsacq_set_doppler_step(gpsacq_engine* e, double step_hz) {
     if (!e) return fail(GPSACQ_ERR_ARG, "gpsacq_set_doppler_step: null engine");
-    join_warm(e);  // the worker reads the tables replaced below
     HIPCHK(hipSetDevice(e->p.device));
     const double bin = e->p.fs / N_FFT;
     int sub = 1, dstride = 1;
@@ -1096,17 +1015,21 @@ extern "C" int gpsacq_set_doppler_step(gpsacq_engine* e, double step_hz) {
     if (2 * kmax + 1 > 0xFFFF) return fail(GPSACQ_ERR_UNSUPPORTED, "%d Doppler points exceed the 65535 the peak keys can carry", 2 * kmax + 1);
     if (sub != e->sub) {  // forward-transform tables of the sub-bin offsets
         HIPCHK(hipStreamSynchronize(e->stream));
-        std::vector<cf> tn, rot8;
-        forward_tables(sub, tn, rot8);
-        cf *ntn = nullptr, *nrot = nullptr;
+        std::vector<cf> tn, rot8, lutc;
+        forward_tables(sub, tn, rot8, &lutc);
+        cf *ntn = nullptr, *nrot = nullptr, *nlut = nullptr;
         HIPCHK(hipMalloc((void**)&ntn, tn.size() * sizeof(cf)));
         HIPCHK(hipMalloc((void**)&nrot, rot8.size() * sizeof(cf)));
+        HIPCHK(hipMalloc((void**)&nlut, lutc.size() * sizeof(cf)));
         HIPCHK(hipMemcpy(ntn, tn.data(), tn.size() * sizeof(cf), hipMemcpyHostToDevice));
         HIPCHK(hipMemcpy(nrot, rot8.data(), rot8.size() * sizeof(cf), hipMemcpyHostToDevice));
+        HIPCHK(hipMemcpy(nlut, lutc.data(), lutc.size() * sizeof(cf), hipMemcpyHostToDevice));
         HIPCHK(hipFree(e->d_tn));
         HIPCHK(hipFree(e->d_rot8));
+        HIPCHK(hipFree(e->d_lutc));
         e->d_tn = ntn;
         e->d_rot8 = nrot;
+        e->d_lutc = nlut;
     }
     e->sub = sub;
     e->dstride = dstride;

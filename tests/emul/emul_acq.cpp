@@ -68,6 +68,35 @@ void emul_forward_bits_sub(const uint8_t* bytes, const uint8_t* cosm, const uint
     }
     pp_to_natural(pp.data(), M_SUB, 0, true, out);
 }
+// The same through the second form of the 1-bit path (k_fwd2: bytes in registers, host-built conjugated look-up table, the
+// transform run backwards on conjugated inputs, derived pass-1 twiddles): spectrum r of `sub` sub-bin offsets, natural order.
+void emul_forward_bits2_sub(const uint8_t* bytes, const uint8_t* cosm, const uint8_t* sinm, int sub, int r, float* out) {
+    const Tables& T = tables();
+    std::vector<uint64_t> ib(625), qb(625), cos_t(625), sin_t(625);
+    transpose_masks(cosm, cos_t.data());
+    transpose_masks(sinm, sin_t.data());
+    for (int tid = 0; tid < WG; ++tid) fwd_stage_bits(tid, bytes, cos_t.data(), sin_t.data(), ib.data(), qb.data());
+    std::vector<cf> tn, rot8, lutc;
+    forward_tables(sub, tn, rot8, &lutc);
+    std::vector<cf> pp((size_t)NPOLY * M_SUB), lds(M_SUB);
+    std::vector<uint32_t> packed((size_t)WG * RA);
+    std::vector<cf> w1((size_t)WG * 2 * (RA - 1));
+    for (int tid = 0; tid < WG; ++tid) {
+        fwd2_load_bytes(tid, reinterpret_cast<const uint8_t*>(ib.data()), reinterpret_cast<const uint8_t*>(qb.data()),
+                        *reinterpret_cast<uint32_t(*)[RA]>(&packed[(size_t)tid * RA]));
+        load_tw1<true>(tid, T.t1.data(), *reinterpret_cast<cf(*)[2][RA - 1]>(&w1[(size_t)tid * 2 * (RA - 1)]));
+    }
+    for (int kappa = 0; kappa < NPOLY; ++kappa) {
+        const cf* lut = lutc.data() + ((size_t)r * NPOLY + kappa) * 256;
+        const cf* tn_row = tn.data() + ((size_t)r * NPOLY + kappa) * M_SUB;
+        for (int tid = 0; tid < WG; ++tid)
+            fwd2_phase1(tid, *reinterpret_cast<uint32_t(*)[RA]>(&packed[(size_t)tid * RA]), lut, tn_row,
+                        *reinterpret_cast<cf(*)[2][RA - 1]>(&w1[(size_t)tid * 2 * (RA - 1)]), lds.data());
+        for (int tid = 0; tid < WG; ++tid) fwd2_phase2(tid, T.t2.data(), lds.data());
+        for (int tid = 0; tid < WG; ++tid) fwd2_phase3_store(tid, lds.data(), pp.data() + (size_t)kappa * M_SUB);
+    }
+    pp_to_natural(pp.data(), M_SUB, 0, true, out);  // stored conjugated
+}
 void emul_forward_bits(const uint8_t* bytes, const uint8_t* cosm, const uint8_t* sinm, float* out) {
     emul_forward_bits_sub(bytes, cosm, sinm, 1, 0, out);
 }

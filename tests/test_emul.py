@@ -22,6 +22,7 @@ def emul():
     vp, d, i = ctypes.c_void_p, ctypes.c_double, ctypes.c_int
     E.emul_forward_bits.argtypes = [vp] * 4
     E.emul_forward_bits_sub.argtypes = [vp, vp, vp, i, i, vp]
+    E.emul_forward_bits2_sub.argtypes = [vp, vp, vp, i, i, vp]
     E.emul_forward_real.argtypes = [vp] * 2
     E.emul_cell.argtypes = [vp, vp, i, i, i, i, i, i, vp, vp, vp]
     E.emul_cell8.argtypes = [vp, vp, i, i, i, vp, vp, vp]
@@ -113,11 +114,20 @@ def test_emulated_subbin_forward_vs_oracle(emul, golden_dir):
         orc.L.oracle_get_sample_spectrum(orc.h, _p(d_orc))
         a, b = d_emul.view(np.complex64), d_orc.view(np.complex64)
         assert np.abs(a - b).max() / np.abs(b).max() < 3e-6, (sub, r)
+        # the second form of the 1-bit path (k_fwd2): the same spectrum, its own rounding
+        d2 = np.zeros(80000, np.float32)
+        emul.emul_forward_bits2_sub(_p(blk), _p(cosm), _p(sinm), sub, r, _p(d2))
+        assert np.abs(d2.view(np.complex64) - b).max() / np.abs(b).max() < 3e-6, (sub, r)
     # r = 0 is the reference's Sample()
     d0, d1 = np.zeros(80000, np.float32), np.zeros(80000, np.float32)
     emul.emul_forward_bits_sub(_p(blk), _p(cosm), _p(sinm), 3, 0, _p(d0))
     emul.emul_forward_bits(_p(blk), _p(cosm), _p(sinm), _p(d1))
     assert np.array_equal(d0, d1)
+    d2 = np.zeros(80000, np.float32)
+    emul.emul_forward_bits2_sub(_p(blk), _p(cosm), _p(sinm), 1, 0, _p(d2))
+    d_orc = orc.sample_spectrum(blk)
+    assert np.abs(d2.view(np.complex64) - d_orc).max() / np.abs(d_orc).max() < 2e-6
+    assert np.abs(d2.view(np.complex64) - d1.view(np.complex64)).max() / np.abs(d_orc).max() < 1e-6  # the two forms of the kernel
 
 
 def test_lane_maps_are_bank_conflict_free_in_the_lds_model(emul):
