@@ -1,8 +1,8 @@
 // acq_kernels.hip -- gfx950 kernels of the GPS L1 C/A acquisition engine.
 //
 // Replaces the hot loops of c/search_offline.cpp (reference, /root/reference):
-//   k_fwd<bits>                 Sample()    :141-161  (unpack, XOR mix, FFT-40000)
-//                               SearchInit():101-106  (code replica -> code spectrum)
+//   k_fwd2<bits>                Sample()    :141-161  (unpack, XOR mix, FFT-40000)
+//   k_fwd<real>                 SearchInit():101-106  (code replica -> code spectrum)
 //   k_corr<MC>                  Correlate() :181-196  (shifted conj-multiply, IFFT-40000,
 //                                                      |.|^2 max/argmax/sum over FS/1000 lags)
 //   k_peaks                     Correlate() :196-200  (best SNR over the Doppler bins)
@@ -275,13 +275,9 @@ template <class L> __device__ __forceinline__ int corr_rho(const CorrArgs& a, in
 template <int MC, int WPS, int NB, bool NC, bool W1H = false, bool PROF = false, class L = ACQ_CORR_LAYOUT, bool NCREG = false>
 __global__ __launch_bounds__(WG, WPS) void k_corr(CorrArgs a) {
     __shared__ __attribute__((aligned(16))) cf lds[L::SIZE];  // transform buffer
-    __shared__ __attribute__((aligned(16))) cf t2s[NT2];    // the 500 pass-2 twiddles
+    __shared__ cf t2s[NT2];    // the 500 pass-2 twiddles
     __shared__ float red[4 * (WG / 64)];
     __shared__ float pws[NC && !NCREG ? MC * NBF3 : 1];  // non-coherent power per lag of this pass
-#ifdef ACQ_FOLD_BQ
-    constexpr int TQS = TqStride<MC>::value;
-    __shared__ __attribute__((aligned(16))) cf tqs[RA * TQS];  // this sub-transform's accumulate factors, [alpha][column]
-#endif
     const int tid = threadIdx.x;
     const int g = blockIdx.x, xcd = g & 7, slot = g >> 3;
     const int grp = slot / a.ndop, di = slot - grp * a.ndop;
@@ -306,9 +302,7 @@ __global__ __launch_bounds__(WG, WPS) void k_corr(CorrArgs a) {
     const cf* cpp = a.cpp + (size_t)tk.code * NPOLY * a.crow;
 
     // q-independent twiddles: pass 2's table into LDS (16-byte copies), pass 1's into registers
-#ifndef ACQ_FOLD_BQ
     for (int i = tid; i < NT2; i += WG) t2s[i] = a.t2[i];
-#endif
     cf w1[2][RA - 1];
     load_tw1<W1H, L>(tid, a.t1, w1);
 
@@ -338,16 +332,6 @@ __global__ __launch_bounds__(WG, WPS) void k_corr(CorrArgs a) {
     for (int k = 0; k < n_acc; ++k) {
         const cf* dk = dpp + (size_t)k * a.acc_step * a.sub * NPOLY * M_SUB;
         for (int q = 0; q < NPOLY; ++q) {
-#ifdef ACQ_FOLD_BQ
-            // this sub-transform's two tables: requested now, written to LDS behind phase 1 (pass 2 of the previous
-            // sub-transform read t2s before its second barrier, pass 3 read tqs before its third: both are free)
-            cf2 nt2 = {0.f, 0.f, 0.f, 0.f}, ntq = {0.f, 0.f, 0.f, 0.f};
-            if (tid < NT2 / 2) nt2 = *reinterpret_cast<const cf2*>(a.t2q + q * NT2 + 2 * tid);
-            constexpr int TQH = TQS / 2;  // 16-byte pairs per row
-            const int tq_al = tid / TQH, tq_c = 2 * (tid - tq_al * TQH);
-            // (an instance's last, padded pair may lie beyond its columns, at most into the next row or the table's tail padding: never used)
-            if (tid < RA * TQH) ntq = *reinterpret_cast<const cf2*>(a.tq + (q * RA + tq_al) * NW160 + a.m0 + tq_c);
-#else
             const cf b = a.bq[q * NBF3 + rho];  // per-thread rotation of this sub-transform
             // wave-uniform rotations: scalar loads, SGPR operands.  Up to 22 columns are fetched here, ahead of the sub-transform;
             // the wide instances fetch them in chunks inside pass 3 (corr_phase3) to stay inside the SGPR file
@@ -357,13 +341,8 @@ __global__ __launch_bounds__(WG, WPS) void k_corr(CorrArgs a) {
                 for (int m = 0; m < MC; ++m) wq_early[m] = c_wq[q * WQ_STRIDE + a.m0 + m];
             }
             const cf* wqv = MC <= 22 ? wq_early : c_wq + q * WQ_STRIDE + a.m0;
-#endif
             ACQ_PHASE1_PRIO(1);
             corr_phase1<NB, W1H, L>(tid, q, dop, dk, cpp, a.crow, a.halo, w1, lds);
-#ifdef ACQ_FOLD_BQ
-            if (tid < NT2 / 2) *reinterpret_cast<cf2*>(t2s + 2 * tid) = nt2;
-            if (tid < RA * TQH) *reinterpret_cast<cf2*>(tqs + tq_al * TQS + tq_c) = ntq;
-#endif
             ACQ_PHASE1_PRIO(0);
             ACQ_STAMP(1);  // inputs loaded and multiplied, pass 1, its LDS stores drained (the stamp waits on lgkmcnt)
             __syncthreads();  // also orders the t2s fill before its first use
@@ -372,11 +351,7 @@ __global__ __launch_bounds__(WG, WPS) void k_corr(CorrArgs a) {
             ACQ_STAMP(3);
             __syncthreads();
             ACQ_STAMP(4);
-#ifdef ACQ_FOLD_BQ
-            corr_phase3_fold<MC, L>(tid, rho, tqs, lds, acc);
-#else
             corr_phase3<MC, L>(tid, rho, b, wqv, lds, acc);
-#endif
             ACQ_STAMP(5);
             __syncthreads();
             ACQ_STAMP(6);
@@ -616,17 +591,25 @@ __global__ __launch_bounds__(WG) void k_peaks(const Cell* cells, Peak* peaks, in
 
 // ---------------------------------------------------------------------------------------
 // launchers (host)
-static bool fwd_v1() {  // GPSACQ_FWD1=1: round 3's forward kernel (A/B runs)
+// (the 1-bit / IQ paths always ask for the conjugated spectrum.  Round 3's form of them, k_fwd<SRC_BITS> / <SRC_IQ8>, is built into
+// the experiment library only and selected there with GPSACQ_FWD1=1 for A/B runs: profiles/r04_experiments/d_kfwd2.log)
+#ifdef ACQ_EXPERIMENTS
+static bool fwd_v1() {
     static const bool v1 = [] { const char* v = getenv("GPSACQ_FWD1"); return v && *v && atoi(v) != 0; }();
     return v1;
 }
+#endif
 void launch_fwd_bits(const FwdArgs& a, int n_items, hipStream_t s) {
-    if (fwd_v1() || !a.conj_out) hipLaunchKernelGGL(k_fwd<SRC_BITS>, dim3(n_items), dim3(WG), 0, s, a);
-    else hipLaunchKernelGGL(k_fwd2<SRC_BITS>, dim3(n_items), dim3(WG), 0, s, a);
+#ifdef ACQ_EXPERIMENTS
+    if (fwd_v1()) { hipLaunchKernelGGL(k_fwd<SRC_BITS>, dim3(n_items), dim3(WG), 0, s, a); return; }
+#endif
+    hipLaunchKernelGGL(k_fwd2<SRC_BITS>, dim3(n_items), dim3(WG), 0, s, a);
 }
 void launch_fwd_iq8(const FwdArgs& a, int n_items, hipStream_t s) {
-    if (fwd_v1() || !a.conj_out) hipLaunchKernelGGL(k_fwd<SRC_IQ8>, dim3(n_items), dim3(WG), 0, s, a);
-    else hipLaunchKernelGGL(k_fwd2<SRC_IQ8>, dim3(n_items), dim3(WG), 0, s, a);
+#ifdef ACQ_EXPERIMENTS
+    if (fwd_v1()) { hipLaunchKernelGGL(k_fwd<SRC_IQ8>, dim3(n_items), dim3(WG), 0, s, a); return; }
+#endif
+    hipLaunchKernelGGL(k_fwd2<SRC_IQ8>, dim3(n_items), dim3(WG), 0, s, a);
 }
 void launch_fwd_realmix(const FwdArgs& a, int n_items, hipStream_t s) {
     hipLaunchKernelGGL(k_fwd<SRC_REALMIX>, dim3(n_items), dim3(WG), 0, s, a);

@@ -49,8 +49,6 @@ struct CorrArgs {
     const cf* t1;
     const cf* t2;
     const cf* bq;      // [8][250] by rho
-    const cf* t2q;     // ACQ_FOLD_BQ: [8][25][20] pass-2 output twiddles with W_4000^{q beta} folded in (acq_tables.hpp TablesFold)
-    const cf* tq;      // ACQ_FOLD_BQ: [8][10][160] W_40000^{q (250 m + alpha)}
     const unsigned char* rho_map;  // [256] LayC: pass-3 thread -> rho (acq_math.hpp kRhoC)
     Cell* cells;       // [n_tasks][ndop]
     int n_tasks, ndop, dop_first, nlags, crow, halo;  // bins dop_first .. dop_first+ndop-1

@@ -110,17 +110,6 @@ ACQ_HD cf cmacc_u(cf acc, cf a, cf w) {
     return acc + cmulc(a, w);
 #endif
 }
-// acc + a * conj(w), w per lane (VGPR pair)
-ACQ_HD cf cmacc(cf acc, cf a, cf w) {
-#if ACQ_PK_ASM
-    cf r = acc;
-    asm("v_pk_fma_f32 %0, %1, %2, %0 op_sel_hi:[1,0,1]\n\t"
-        "v_pk_fma_f32 %0, %1, %2, %0 op_sel:[1,1,0] op_sel_hi:[0,1,1] neg_hi:[1,0,0]" : "+v"(r) : "v"(a), "v"(w));
-    return r;
-#else
-    return acc + cmulc(a, w);
-#endif
-}
 // acc + a * w, w wave-uniform
 ACQ_HD cf cmadd_u(cf acc, cf a, cf w) {
 #if ACQ_PK_ASM

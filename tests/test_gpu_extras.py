@@ -163,7 +163,15 @@ def test_other_sampling_rates(fc, fs, max_fo):
         np.testing.assert_allclose(cells["max_pwr"], ocells["max_pwr"], rtol=2e-5)
         np.testing.assert_allclose(cells["tot_pwr"], ocells["tot_pwr"], rtol=2e-5)
         assert (cells["max_i"] != ocells["max_i"]).mean() < 0.01
-        assert np.array_equal(peaks["lo_shift"], opeaks["lo_shift"]) and np.array_equal(peaks["ca_shift"], opeaks["ca_shift"])
+        for t in range(len(tasks)):
+            if peaks["lo_shift"][t] == opeaks["lo_shift"][t]:
+                assert peaks["ca_shift"][t] == opeaks["ca_shift"][t]
+                continue
+            # another Doppler bin may only win where the oracle's own two SNRs tie to rounding (a zero IF makes bins +d and -d
+            # mirror images of each other: equal powers, and the strict '>' scan keeps whichever rounds higher)
+            k_gpu, k_orc = int(peaks["lo_shift"][t]) + orc.dmax, int(opeaks["lo_shift"][t]) + orc.dmax
+            assert abs(ocells["snr"][t][k_gpu] / ocells["snr"][t][k_orc] - 1) < 2e-5, (t, peaks[t], opeaks[t])
+            assert peaks["ca_shift"][t] == ocells["max_i"][t][k_gpu]
 
 
 def test_cli_multi_engine_threads(golden_dir):
