@@ -159,6 +159,48 @@ def soak(leg, cells_job, min_gpu_s=6.0, max_steps=2000):
             "note": "same step as the timed region, repeated after it; reported separately, `steps`/`ms_per_step`/`value` are the K timed steps"}
 
 
+def live_traffic(argv_tail, timeout_s=150):
+    """HBM bytes of one k_corr launch measured IN THIS RUN: two short child runs of this file under `rocprofv3 --pmc FETCH_SIZE`
+    and `--pmc WRITE_SIZE` (separate passes, as /opt/skills/guides/MI355X_MICROARCH.md prescribes; no trace domains beside
+    --pmc), same workload, 2 timed steps.  FETCH_SIZE is in KiB and counts half the bytes of wide coalesced reads on gfx950
+    (x 2, the guide's correction); WRITE_SIZE KiB is uncalibrated.  Returns {"read_bytes", "write_bytes", "launches"} or
+    {"error": ...}; never raises."""
+    import csv
+    import glob
+    import shutil
+    import subprocess
+    import tempfile
+    if shutil.which("rocprofv3") is None:
+        return {"error": "rocprofv3 not on PATH"}
+    out = {}
+    tmp = tempfile.mkdtemp(prefix="gpsacq_pmc_", dir="/tmp")
+    try:
+        for counter, key in (("FETCH_SIZE", "read_bytes"), ("WRITE_SIZE", "write_bytes")):
+            d = os.path.join(tmp, counter)
+            cmd = ["rocprofv3", "--pmc", counter, "--output-format", "csv", "-d", d, "-o", "p", "--", sys.executable, os.path.abspath(__file__),
+                   "--steps", "2", "--warmup", "1", "--weak-blocks", "0", "--no-cpu-baseline", "--no-e2e", "--soak-seconds", "0", "--no-dist",
+                   "--no-live-traffic"] + argv_tail
+            env = dict(os.environ, TMPDIR="/tmp")
+            for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT"):
+                env.pop(k, None)
+            r = subprocess.run(cmd, cwd="/tmp", env=env, capture_output=True, text=True, timeout=timeout_s)
+            vals = []
+            for f in glob.glob(os.path.join(d, "**", "*counter_collection.csv"), recursive=True):
+                for row in csv.DictReader(open(f)):
+                    if "k_corr" in row.get("Kernel_Name", "") and row.get("Counter_Name") == counter:
+                        vals.append(float(row["Counter_Value"]))
+            if not vals:
+                return {"error": f"no {counter} rows for k_corr (rocprofv3 rc {r.returncode}): {(r.stderr or r.stdout)[-200:]}"}
+            kib = sum(vals) / len(vals)
+            out[key] = kib * 1024.0 * (2.0 if counter == "FETCH_SIZE" else 1.0)
+            out["launches"] = len(vals)
+        return out
+    except Exception as ex:
+        return {"error": str(ex)[:200]}
+    finally:
+        shutil.rmtree(tmp, ignore_errors=True)
+
+
 def cpu_baseline(cfg, bits, ndop, target_s=12.0):
     """The oracle's float build (own mixed-radix FFT; `port`) timed single-threaded on a bounded sample of the
     same capture.  The reference binary itself cannot run on the GPU box (it needs FFTW; oracle/_ref/README)."""
@@ -420,6 +462,9 @@ def main():
     ap.add_argument("--no-dist", action="store_true", help="N = 1: do not create the one-rank nccl process group")
     ap.add_argument("--force-dist", action="store_true", help="N = 1: the one-rank nccl group must come up (no fallback)")
     ap.add_argument("--soak-seconds", type=float, default=6.0, help="GPU time of the soak leg after the timed steps (0: skip)")
+    ap.add_argument("--live-traffic", action="store_true", help="measure roofline.traffic in this run even with --no-cpu-baseline")
+    ap.add_argument("--no-live-traffic", action="store_true",
+                    help="do not measure roofline.traffic in this run (two short rocprofv3 --pmc child runs); use profiles/traffic.json")
     ap.add_argument("--no-e2e", action="store_true", help="skip the gps_test end-to-end leg")
     ap.add_argument("--spawn-check", action="store_true",
                     help="launcher check without a GPU: every rank joins a gloo group, rank 0 prints the ranks it saw, all exit")
@@ -674,10 +719,20 @@ def main():
             traffic_sha = tj.get("kernel_source_sha")
         except Exception:
             pass
+        traffic_live = None
+        if (world == 1 and not args.no_live_traffic and (args.live_traffic or not args.no_cpu_baseline) and args.config == 1 and not iq8 and not args.capture
+                and "ROCPROFILER_REGISTER_FORCE_LOAD" not in os.environ and "ROCP_TOOL_LIBRARIES" not in os.environ):
+            # the default line: counters collected on THIS box, in this run (same capture size: the child generates the same data)
+            traffic_live = live_traffic(["--blocks-total", str(args.blocks_total)])
+            if "error" not in traffic_live:
+                traffic = traffic_live["read_bytes"] + traffic_live["write_bytes"]
+                traffic_src = ("measured in this run: rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE (separate child runs of this command, "
+                               "2 steps each), per k_corr launch; FETCH_SIZE KiB x 1024 x 2 (gfx950 correction), WRITE_SIZE KiB x 1024")
         sha_now = kernel_source_sha()
         # counters belong to the kernel binary they were collected on: flagged when the sources changed since (or the
         # profile predates the hash), or when this run's kernel instance is not the profiled one
-        traffic_stale = (traffic is not None) and (traffic_sha != sha_now or args.config not in (1, 4) or iq8)
+        live_ok = traffic_live is not None and "error" not in traffic_live
+        traffic_stale = False if live_ok else ((traffic is not None) and (traffic_sha != sha_now or args.config not in (1, 4) or iq8))
         alg_gbs = cells_rank * ALG_BYTES_PER_CELL / (kern_ms * 1e-3) / 1e9 if kern_ms else 0.0
         out = {
             "metric": "(PRN,Doppler) correlation cells/s, 32 PRN @ fs=5.456 MHz" if args.config in (1, 4) else
@@ -708,14 +763,15 @@ def main():
                          "flops_per_cell": fl, "flops_definition": "SURVEY.md 8(d): 6N + 5N log2 N + 5S",
                          "kernel_ms": kern_ms, "cells_per_launch": cells_rank,
                          "kernel_cells_per_s": cells_rank / (kern_ms * 1e-3) if kern_ms else None,
-                         "traffic": traffic, "traffic_source": traffic_src, "traffic_stale": traffic_stale,
+                         "traffic": traffic, "traffic_source": traffic_src, "traffic_stale": traffic_stale, "traffic_live": traffic_live,
                          "kernel_source_sha": sha_now, "traffic_kernel_source_sha": traffic_sha,
                          "hbm_secondary": {"algorithmic_bytes_per_cell": ALG_BYTES_PER_CELL, "algorithmic_GBs": alg_gbs,
                                            "hbm_peak_GBs": HBM_PEAK_GBS, "algorithmic_over_hbm_peak": alg_gbs / HBM_PEAK_GBS,
                                            "measured_hbm_GBs": (traffic / (kern_ms * 1e-3) / 1e9) if (traffic and kern_ms) else None,
                                            "note": "not a bound: the algorithmic bytes stay on chip; measured HBM traffic is what "
                                                    "`traffic` reports"},
-                         "onchip_counters": onchip, "l2_peak_GBs": L2_PEAK_GBS},
+                         "onchip_counters": onchip, "onchip_counters_stale": (onchip is not None) and (traffic_sha != sha_now),
+                         "l2_peak_GBs": L2_PEAK_GBS},
             "stage_ms": {k: timing[k] for k in ("ms_total", "ms_sample", "ms_correlate", "ms_peaks")} if timing else None,
             "device": eng.device_name,
         }

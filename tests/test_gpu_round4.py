@@ -110,6 +110,18 @@ def test_rccl_single_rank_bench_line():
     assert j0["dist_backend"] is None and "soak" not in j0 and j0["detected_prns"] == j["detected_prns"]
 
 
+def test_live_traffic_is_measured_in_the_run():
+    """roofline.traffic of the default line comes from two rocprofv3 --pmc child runs of the same command on the same box (not
+    from the committed profile): a few KB per cell -- both spectra of a cell come out of L2 -- far below the 1.28 MB of
+    algorithmic bytes."""
+    j = _bench("--live-traffic", "--steps", "2", "--warmup", "1", "--blocks-total", "640", "--weak-blocks", "0", "--soak-seconds", "0")
+    r = j["roofline"]
+    assert r["traffic_live"] is not None and "error" not in r["traffic_live"], r["traffic_live"]
+    assert r["traffic_stale"] is False and "measured in this run" in r["traffic_source"]
+    per_cell = r["traffic"] / r["cells_per_launch"]
+    assert 100 < per_cell < 100000, per_cell
+
+
 def test_multi_enqueue_time_is_flat_in_the_number_of_engines(golden_dir):
     """The calling thread is out of the devices' critical path: with 1, 2, 4, 8 engines (sharing the one GPU here) the host
     time until everything is enqueued does not grow with the engine count -- each engine's staging copy and enqueue run on
