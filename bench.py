@@ -782,7 +782,7 @@ def main():
         if iq8 and leg.sample_ms:
             ms = float(np.mean(leg.sample_ms))
             b_in, b_out = nblk * 80000, nblk * eng.doppler_sub * 8 * 5000 * 8
-            out["ingest"] = {"kernel": "k_fwd<iq8>", "ms": ms, "bytes_read": b_in, "bytes_written": b_out,
+            out["ingest"] = {"kernel": "k_fwd2<iq8>", "ms": ms, "bytes_read": b_in, "bytes_written": b_out,
                              "GBs": (b_in + b_out) / (ms * 1e-3) / 1e9, "copy_ceiling_GBs": 6290.0,
                              "frac_of_copy_ceiling": (b_in + b_out) / (ms * 1e-3) / 1e9 / 6290.0,
                              "note": "8-bit IQ read (80 000 B per block) + polyphase spectrum written (320 KB per block) over the "

@@ -48,7 +48,7 @@ def test_iq8_input_line():
     j = _bench("--input", "iq8", "--blocks-total", "256", "--no-e2e")
     assert "8-bit IQ" in j["config"]["input"] and j["config"]["cells_per_step_job"] == 256 * 73
     ing = j["ingest"]
-    assert ing["kernel"] == "k_fwd<iq8>" and ing["bytes_read"] == 256 * 80000 and 0 < ing["frac_of_copy_ceiling"] < 1
+    assert ing["kernel"] == "k_fwd2<iq8>" and ing["bytes_read"] == 256 * 80000 and 0 < ing["frac_of_copy_ceiling"] < 1
     assert j["roofline"]["traffic_stale"] is True  # the committed counters belong to the 1-bit line's kernel instance mix
     assert set(j["detected_prns"]) >= set(j["injected_prns_all_ranks"])
 

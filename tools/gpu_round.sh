@@ -19,7 +19,7 @@ GPSACQ_DIST_BACKEND=gloo python -m torch.distributed.run --nnodes=1 --nproc-per-
     bench.py --gpus 2 --steps 5 --warmup 2 --no-e2e 2> $OUT/bench_two_rank_gloo.err | grep '^{' > $OUT/bench_two_rank_gloo.json
 GPSACQ_DIST_BACKEND=gloo python bench.py --gpus 2 --config 4 --doppler-step 50 --steps 3 --warmup 1 2> $OUT/bench_two_rank_gloo_config4.err | grep '^{' > $OUT/bench_two_rank_gloo_config4.json
 python tools/multi_enqueue.py > $OUT/multi_enqueue.json 2> $OUT/multi_enqueue.err
-GPSACQ_MULTI_FORCE_RCCL=1 python tools/multi_enqueue.py > $OUT/multi_enqueue_force_rccl.json 2> $OUT/multi_enqueue_force_rccl.err
+GPSACQ_MULTI_FORCE_RCCL=1 python tools/multi_enqueue.py 2> $OUT/multi_enqueue_force_rccl.err | grep "^{" > $OUT/multi_enqueue_force_rccl.json  # (RCCL prints a version banner to stdout)
 for i in 1 2 3; do GPSACQ_TRACE=1 gnss-gps-sdr_amd/bin/gps_test tests/golden/gps_sig_tmp.bin 2.046e6 8.184e6 5000 2>&1 >/dev/null | grep trace; done > $OUT/cli_trace.log; cat $OUT/cli_trace.log
 bash tools/profile.sh $TAG
 python - <<PY
