@@ -304,13 +304,17 @@ int for_each_engine(gpsacq_multi* m, F&& body) {
     const size_t n = m->eng.size();
     std::vector<int> rcs(n, GPSACQ_OK);
     std::vector<std::string> errs(n);
-    auto run = [&](size_t i) {
-        int rc;
-        const hipError_t he = hipSetDevice(m->dev[i]);
-        if (he != hipSuccess) rc = failf(GPSACQ_ERR_DEVICE, "hipSetDevice(%d): %s", m->dev[i], hipGetErrorString(he));
-        else rc = body(i);
-        rcs[i] = rc;
-        if (rc) errs[i] = gpsacq_last_error();
+    auto run = [&](size_t i) noexcept {  // nothing may leave a worker thread (or the C ABI) as an exception
+        try {
+            int rc;
+            const hipError_t he = hipSetDevice(m->dev[i]);
+            if (he != hipSuccess) rc = failf(GPSACQ_ERR_DEVICE, "hipSetDevice(%d): %s", m->dev[i], hipGetErrorString(he));
+            else rc = body(i);
+            rcs[i] = rc;
+            if (rc) errs[i] = gpsacq_last_error();
+        } catch (...) {
+            rcs[i] = GPSACQ_ERR_NOMEM;  // (errs[i] stays empty: its assignment may be what failed)
+        }
     };
     std::vector<std::thread> workers;
     size_t threaded = 0;  // engines 1 .. threaded have a worker
@@ -325,7 +329,7 @@ int for_each_engine(gpsacq_multi* m, F&& body) {
     for (size_t i = threaded + 1; i < n; ++i) run(i);
     for (std::thread& w : workers) w.join();
     for (size_t i = 0; i < n; ++i)
-        if (rcs[i]) return acq::set_last_error(rcs[i], errs[i].c_str());
+        if (rcs[i]) return acq::set_last_error(rcs[i], errs[i].empty() ? "out of memory on a worker thread" : errs[i].c_str());
     return GPSACQ_OK;
 }
 typedef std::chrono::steady_clock MClock;

@@ -42,6 +42,20 @@ def test_reserve_between_searches_keeps_the_schedule_valid(golden_dir, quirks):
         assert np.array_equal(d, want[:65])
 
 
+def test_iq8_quirk_route_checks_the_stride_before_it_converts():
+    """8-bit IQ + ref_quirks converts 40960 samples per block before it searches (round-3 advisor finding): a stride that holds
+    fewer is refused up front -- before the conversion kernel is enqueued on a buffer that short -- not after."""
+    import gpsacq
+    iq = np.full(2 * 80000, 128, dtype=np.uint8)
+    with gpsacq.Engine(0.62e6, 2.8e6, 5000.0, ref_quirks=True) as eng:
+        with pytest.raises(gpsacq.GpsAcqError, match="81920"):
+            eng.search_iq8(iq, eng.iq8_input(signed=False, remove_dc=False), stride=80000)
+        iq2 = np.full(2 * 81920, 128, dtype=np.uint8)
+        iq2[::7] = 140
+        _, pk = eng.search_iq8(iq2, eng.iq8_input(signed=False, remove_dc=False), stride=81920)  # the full stride still works
+        assert pk.shape == (2,)
+
+
 # ---- every RCCL line on the one GPU --------------------------------------------------------------------------------------
 def _key(p):
     return (float(p["snr"]), -int(p["lo_shift"]), int(p["ca_shift"]))
