@@ -786,7 +786,7 @@ def main():
                              "GBs": (b_in + b_out) / (ms * 1e-3) / 1e9, "copy_ceiling_GBs": 6290.0,
                              "frac_of_copy_ceiling": (b_in + b_out) / (ms * 1e-3) / 1e9 / 6290.0,
                              "note": "8-bit IQ read (80 000 B per block) + polyphase spectrum written (320 KB per block) over the "
-                                     "stage's HIP-event time; the stage also does 40 000 double-precision sincos per block (the mixer)"}
+                                     "stage's HIP-event time; the stage also runs the mixer for 40 000 samples per block (float fast path, double-precision sincos where the sign could depend on it)"}
         if not grid:
             snr, lo, ca = gdist.unpack_keys(best.cpu(), eng.kmax)
             hits = torch.nonzero(snr >= 25).flatten().tolist()
