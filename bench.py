@@ -693,6 +693,21 @@ def main():
     if args.soak_seconds > 0 and world == 1 and n_tasks > 0:
         soak_leg = soak(leg, cells_job, args.soak_seconds)
 
+    # What one GPU's share of the capture costs at N = 8 (43 of the 340 runs = 1376 blocks per step, the one-rank all-reduce
+    # included): a PREDICTION of the strong-scaling point the driver measures on an 8-GPU node, from this one GPU --
+    # ms_per_step(whole capture) / ms_per_step(share) is the speed-up 8 GPUs reach if nothing but this step limits them.
+    share = None
+    if world == 1 and not grid and not iq8 and not args.capture and args.config == 1 and nblk >= 8 * 32 and args.soak_seconds > 0:
+        share_runs = -(-(nblk // 32) // 8)
+        sleg = Leg(torch, gpsacq, gdist, eng, dev, dist, backend, share_runs * 32, share_runs * 32, d_bits, None, stride, False)
+        s_elapsed, s_kern_ms, _ = sleg.run(max(20, args.steps // 2), 3)
+        s_ms = 1e3 * s_elapsed / max(20, args.steps // 2)
+        share = {"ranks_emulated": 8, "blocks_per_step": share_runs * 32, "ms_per_step": s_ms, "kernel_ms": s_kern_ms,
+                 "cells_per_s_this_gpu": share_runs * 32 * eng.num_doppler / (s_ms * 1e-3),
+                 "predicted_speedup_at_8_gpus": (1e3 * elapsed / args.steps) / s_ms,
+                 "note": "one GPU running the largest per-rank share of the capture at N = 8 (same step, one-rank all-reduce included); "
+                         "a prediction, not a measurement of 8 GPUs"}
+
     weak = None
     if iq8:
         weak_blocks = 0
@@ -721,7 +736,7 @@ def main():
             pass
         traffic_live = None
         if (world == 1 and not args.no_live_traffic and (args.live_traffic or not args.no_cpu_baseline) and args.config == 1 and not iq8 and not args.capture
-                and "ROCPROFILER_REGISTER_FORCE_LOAD" not in os.environ and "ROCP_TOOL_LIBRARIES" not in os.environ):
+                and not any(k.startswith(("ROCP_", "ROCPROF")) for k in os.environ) and "rocprof" not in os.environ.get("LD_PRELOAD", "")):  # not under a profiler already
             # the default line: counters collected on THIS box, in this run (same capture size: the child generates the same data)
             traffic_live = live_traffic(["--blocks-total", str(args.blocks_total)])
             if "error" not in traffic_live:
@@ -777,6 +792,8 @@ def main():
         }
         if soak_leg is not None:
             out["soak"] = soak_leg
+        if share is not None:
+            out["strong_share_at_8"] = share
         if weak is not None:
             out["weak_scaling"] = weak
         if iq8 and leg.sample_ms:

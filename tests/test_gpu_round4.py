@@ -120,6 +120,8 @@ def test_rccl_single_rank_bench_line():
     sk = j["soak"]
     assert sk["steps"] >= 20 and sk["seconds"] >= 1.5 and sk["ms_per_step"] > 0
     assert abs(sk["ms_per_step"] / j["ms_per_step"] - 1) < 0.5  # the same step (a 3-step timed region is noisy; not a perf assertion)
+    sh = j["strong_share_at_8"]  # one GPU's share of the capture at N = 8: 3 of the 20 runs
+    assert sh["blocks_per_step"] == 96 and sh["ms_per_step"] > 0 and sh["predicted_speedup_at_8_gpus"] > 1
     j0 = _bench("--no-dist", "--steps", "2", "--warmup", "1", "--blocks-total", "640", "--weak-blocks", "0", "--soak-seconds", "0")
     assert j0["dist_backend"] is None and "soak" not in j0 and j0["detected_prns"] == j["detected_prns"]
 
