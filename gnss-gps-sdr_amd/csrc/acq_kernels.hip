@@ -633,6 +633,15 @@ int corr_columns(int nlags) {  // accumulator columns of the smallest instance t
 int launch_corr(const CorrArgs& a, int mc, hipStream_t s) {
     const int groups = (a.n_tasks + 7) / 8;
     const dim3 grid((unsigned)groups * 8u * (unsigned)a.ndop), block(WG);
+#ifdef ACQ_EXPERIMENTS
+    // residency experiment (experiment library only): GPSACQ_CORR_LDS_PAD=<bytes> of unused dynamic LDS per workgroup of the
+    // 22-column coherent instance -- 31000 leaves two workgroups per CU, 60000 one (tools/residency_curve.py)
+    static const int lds_pad = [] { const char* v = getenv("GPSACQ_CORR_LDS_PAD"); return v && *v ? atoi(v) : 0; }();
+    if (lds_pad > 0 && mc == 22 && a.n_acc == 1 && !a.prof) {
+        hipLaunchKernelGGL((k_corr<22, 3, 2, false>), grid, block, (size_t)lds_pad, s, a);
+        return 0;
+    }
+#endif
     // <columns, waves per SIMD the register allocator is held to (k workgroups per CU <=> k waves per SIMD), load batches,
     // non-coherent, W1H>.  LDS (49 KB per workgroup) admits 3 workgroups per CU; 12, 22 and 28 columns fit 168 VGPRs,
     // 28 and 33 columns do with half the pass-1 twiddles derived (W1H); 40 columns then spill 40 bytes per lane and are still

@@ -289,7 +289,10 @@ void SearchTask(char *filename_1bit_bin) {
     const size_t n_dev = g_engines.size();
     // per device per batch; an IQ run is 16 times the bytes of a 1-bit run (2.6 MB), so fewer of them fill a staging buffer
     const int batch_dflt = iq ? 16 : 64, batch_env = env_int("GPSACQ_BATCH_RUNS", batch_dflt);
-    const size_t max_runs = (size_t)(batch_env > 0 ? batch_env : batch_dflt);
+    size_t max_runs = (size_t)(batch_env > 0 ? batch_env : batch_dflt);
+    // a mapped file's length is known: a short capture (the bundled gps_sig_tmp.bin has 12 runs) gets staging buffers of its own
+    // size, not of the largest batch (pinned allocations are the most expensive item of a short SearchTask)
+    if (map && map_len / run_bytes + 1 < max_runs) max_runs = map_len / run_bytes + 1;
 
     if (iq) {
         // `y = y - mean(y)` is the mean of the WHOLE capture (proc_rtl_bin_for_gps.m:17): one pass for the two integer sums
