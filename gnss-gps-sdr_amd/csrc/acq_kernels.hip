@@ -106,7 +106,7 @@ __global__ __launch_bounds__(WG) void k_fwd(FwdArgs a) {
 template <int SRC>
 __global__ __launch_bounds__(WG, 3) void k_fwd2(FwdArgs a) {
     static_assert(SRC == SRC_BITS || SRC == SRC_IQ8, "k_fwd2 is the 1-bit path");
-    __shared__ __attribute__((aligned(16))) cf lds[M_SUB];  // transform buffer; before the first row: staging of the transposed block
+    __shared__ __attribute__((aligned(16))) cf lds[Fwd2Lay::SIZE];  // transform buffer; before the first row: staging of the transposed block
     __shared__ cf t2s[NT2];
     __shared__ cf lutc[256];
     const int tid = threadIdx.x, item = blockIdx.x;
@@ -122,7 +122,7 @@ __global__ __launch_bounds__(WG, 3) void k_fwd2(FwdArgs a) {
     }
     for (int i = tid; i < NT2; i += WG) t2s[i] = a.t2[i];
     cf w[2][RA - 1];
-    load_tw1<true>(tid, a.t1, w);
+    load_tw1<true, Fwd2Lay>(tid, a.t1, w);
     __syncthreads();
     uint32_t packed[RA];
     fwd2_load_bytes(tid, reinterpret_cast<const uint8_t*>(ib), reinterpret_cast<const uint8_t*>(qb), packed);

@@ -431,35 +431,6 @@ template <int DIR, bool W1H = false> ACQ_HD void pass1_store_pair(const cf* x0, 
     pass1_pair_one<DIR, W1H, 9>(y0, y1, w0, w1, dst);
 }
 
-// Any slot map, direction DIR: butterflies jp and jp + 1 (jp even: both in row b = jp / 20) with the neighbour's twiddles derived
-// (W1H) -- the forward kernel's form (LayA: two 8-byte stores per alpha).
-template <int DIR, class L, int AL> ACQ_HD void pass1_w1h_one(const cf* y0, const cf* y1, const cf* w0, cf* d0) {
-    if (AL == 0) {
-        d0[0] = y0[0];
-        d0[L::SJ] = y1[0];
-    } else {
-        d0[L::SA * AL] = tw<DIR>(y0[AL], w0[AL - 1]);
-        d0[L::SA * AL + L::SJ] = tw<DIR>(tw_u<DIR>(y1[AL], w5000<(AL ? AL : 1)>()), w0[AL - 1]);
-    }
-}
-template <int DIR, class L> ACQ_HD void pass1_store_pair_w1h(const cf* x0, const cf* x1, int jp, const cf* w0, cf* lds) {
-    cf y0[RA], y1[RA];
-    radix10<DIR>(x0, y0);
-    radix10<DIR>(x1, y1);
-    const int b = jp / RC, jpp = jp - b * RC;
-    cf* d0 = lds + L::SJ * jpp + L::SB * b;
-    pass1_w1h_one<DIR, L, 0>(y0, y1, w0, d0);
-    pass1_w1h_one<DIR, L, 1>(y0, y1, w0, d0);
-    pass1_w1h_one<DIR, L, 2>(y0, y1, w0, d0);
-    pass1_w1h_one<DIR, L, 3>(y0, y1, w0, d0);
-    pass1_w1h_one<DIR, L, 4>(y0, y1, w0, d0);
-    pass1_w1h_one<DIR, L, 5>(y0, y1, w0, d0);
-    pass1_w1h_one<DIR, L, 6>(y0, y1, w0, d0);
-    pass1_w1h_one<DIR, L, 7>(y0, y1, w0, d0);
-    pass1_w1h_one<DIR, L, 8>(y0, y1, w0, d0);
-    pass1_w1h_one<DIR, L, 9>(y0, y1, w0, d0);
-}
-
 // pass 2 for butterfly e (0..199), in place; t2 may live in LDS (its own allocation, so the
 // compiler knows the in-place stores do not alias it) or in global memory.
 template <int DIR, class L = LayA> ACQ_HD void pass2_inplace(int e, const cf* __restrict__ t2, cf* lds) {

@@ -364,21 +364,27 @@ ACQ_HD void fwd_phase1(int tid, int kappa, const Src& src, const cf* __restrict_
 // conjugated spectrum Correlate() wants (:183-184) comes out as it is (no negation pass before the stores); the thread's 40
 // sample bytes (the same for all eight rows) live in ten registers instead of being re-read from LDS per row -- the staging
 // area is the transform buffer itself -- which makes room in LDS for pass 2's twiddle table; the look-ups of a row are
-// issued in two batches of twenty before anything waits for one; half of the pass-1 twiddles are derived (W1H).
-// packed[a] = bytes (I[n0], I[n0 + 1], Q[n0], Q[n0 + 1]) of the transposed block at n0 = 2 tid + 500 a
+// issued in two batches of twenty before anything waits for one; half of the pass-1 twiddles are derived (W1H); slot map LayB.
+// LDS slot map of k_fwd2: LayB (16-byte pass-1 stores; against LayA -4.5 % forward-stage time, against LayC's conflict-free lane
+// maps no difference: profiles/r04_experiments/f_kfwd2_slot_map.log).  Pass 3 keeps the identity butterfly -> thread map whatever
+// the slot map: that is what makes the 64 lanes of a wave store 64 consecutive bins.
+typedef LayB Fwd2Lay;
+// packed[a] = bytes (I[n0], I[n0 + 1], Q[n0], Q[n0 + 1]) of the transposed block at n0 = jp + 500 a, jp = pass1_jp<Fwd2Lay>(tid) the
+// first butterfly of the pair the thread owns (2 tid unless the lane map is LayC's)
 ACQ_HD void fwd2_load_bytes(int tid, const uint8_t* ib, const uint8_t* qb, uint32_t (&packed)[RA]) {
     if (tid >= NBF3) return;
 #pragma unroll
     for (int a = 0; a < RA; ++a) {
-        const uint32_t i2 = *reinterpret_cast<const uint16_t*>(ib + 2 * tid + NBF1 * a);
-        const uint32_t q2 = *reinterpret_cast<const uint16_t*>(qb + 2 * tid + NBF1 * a);
+        const uint32_t i2 = *reinterpret_cast<const uint16_t*>(ib + pass1_jp<Fwd2Lay>(tid) + NBF1 * a);
+        const uint32_t q2 = *reinterpret_cast<const uint16_t*>(qb + pass1_jp<Fwd2Lay>(tid) + NBF1 * a);
         packed[a] = i2 | (q2 << 16);
     }
 }
 // w0: the thread's pass-1 twiddles W_5000^{2 tid alpha} (load_tw1<true>)
 ACQ_HD void fwd2_phase1(int tid, const uint32_t (&packed)[RA], const cf* lutc, const cf* __restrict__ tn_row, const cf (&w)[2][RA - 1], cf* lds) {
     if (tid >= NBF3) return;
-    const cf* tk = tn_row + 2 * tid;
+    const int jp = pass1_jp<Fwd2Lay>(tid);
+    const cf* tk = tn_row + jp;
     cf x0[RA], x1[RA];
     constexpr int HALF = RA / 2;
 #pragma unroll
@@ -400,16 +406,17 @@ ACQ_HD void fwd2_phase1(int tid, const uint32_t (&packed)[RA], const cf* lutc, c
             x1[h * HALF + i] = cmulc(sub_i(li1[i], lq1[i]), t1[i]);
         }
     }
-    pass1_store_pair_w1h<+1, LayA>(x0, x1, 2 * tid, w[0], lds);
+    pass1_store_pair<+1, true>(x0, x1, jp, w[0], w[1], lds);  // one 16-byte store per alpha, the neighbour's twiddles derived (W1H)
 }
+
 ACQ_HD void fwd2_phase2(int tid, const cf* t2s, cf* lds) {
-    if (tid < NBF2) pass2_inplace<+1>(tid, t2s, lds);
+    if (tid < NBF2) pass2_inplace<+1, Fwd2Lay>(tid, t2s, lds);
 }
 // pass 3 and the stores: output n of the 64 lanes of a wave is 64 consecutive bins k' = 250 n + tid of the row, already conjugated
 ACQ_HD void fwd2_phase3_store(int tid, const cf* lds, cf* dst) {
     if (tid >= NBF3) return;
     cf y[RC];
-    pass3_load<+1>(tid, lds, y);
+    pass3_load<+1, Fwd2Lay>(tid, lds, y);
 #pragma unroll
     for (int n = 0; n < RC; ++n) dst[NBF3 * n + tid] = y[n];
 }

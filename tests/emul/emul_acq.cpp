@@ -78,13 +78,13 @@ void emul_forward_bits2_sub(const uint8_t* bytes, const uint8_t* cosm, const uin
     for (int tid = 0; tid < WG; ++tid) fwd_stage_bits(tid, bytes, cos_t.data(), sin_t.data(), ib.data(), qb.data());
     std::vector<cf> tn, rot8, lutc;
     forward_tables(sub, tn, rot8, &lutc);
-    std::vector<cf> pp((size_t)NPOLY * M_SUB), lds(M_SUB);
+    std::vector<cf> pp((size_t)NPOLY * M_SUB), lds(Fwd2Lay::SIZE);
     std::vector<uint32_t> packed((size_t)WG * RA);
     std::vector<cf> w1((size_t)WG * 2 * (RA - 1));
     for (int tid = 0; tid < WG; ++tid) {
         fwd2_load_bytes(tid, reinterpret_cast<const uint8_t*>(ib.data()), reinterpret_cast<const uint8_t*>(qb.data()),
                         *reinterpret_cast<uint32_t(*)[RA]>(&packed[(size_t)tid * RA]));
-        load_tw1<true>(tid, T.t1.data(), *reinterpret_cast<cf(*)[2][RA - 1]>(&w1[(size_t)tid * 2 * (RA - 1)]));
+        load_tw1<true, Fwd2Lay>(tid, T.t1.data(), *reinterpret_cast<cf(*)[2][RA - 1]>(&w1[(size_t)tid * 2 * (RA - 1)]));
     }
     for (int kappa = 0; kappa < NPOLY; ++kappa) {
         const cf* lut = lutc.data() + ((size_t)r * NPOLY + kappa) * 256;
