@@ -194,6 +194,9 @@ __global__ __launch_bounds__(WG) void k_quirk_patch(QuirkArgs a) {
 #ifndef ACQ_CORR_LAYOUT
 #define ACQ_CORR_LAYOUT LayC  // -DACQ_CORR_LAYOUT=LayB builds round 2's lane map for A/B runs (tools/build_variant.sh)
 #endif
+#ifndef ACQ_CORR_FOLD22
+#define ACQ_CORR_FOLD22 true  // -DACQ_CORR_FOLD22=false: the 22-column coherent instance with round 3's rotation (A/B runs)
+#endif
 // Wave priority (round 3, profiles/r03_experiments/b_priority_stagger.log): a wave runs the first phase of a sub-transform --
 // input loads, product, radix-10 pair, pass-1 stores: the short, latency-bound part that ends in the barrier its three
 // partner waves wait at -- one priority level above the long radix-25 / radix-20 phases of the waves of OTHER workgroups it
@@ -272,10 +275,22 @@ template <class L> __device__ __forceinline__ int corr_rho(const CorrArgs& a, in
     else return pass3_rho<L>(t3);
 }
 // NCREG: non-coherent sums kept in registers (no creep re-alignment asked for: every lag stays with its thread)
-template <int MC, int WPS, int NB, bool NC, bool W1H = false, bool PROF = false, class L = ACQ_CORR_LAYOUT, bool NCREG = false>
+// FOLD (round 4; the 22-column coherent instance): the radix-8 rotation W_40000^{q n} of pass 3, n = 250 m + 10 beta + alpha, is split
+// into W_4000^{q beta} -- folded into pass 2's output twiddles: a table per sub-transform q -- and W_40000^{q (250 m + alpha)} -- the
+// accumulate's factor, read from a [10][columns] LDS table (ten disjoint bank groups; lanes of one alpha broadcast) instead of
+// SGPRs.  Pass 3 then multiplies nothing by a per-thread factor: 626 -> 586 VALU instructions per thread and sub-transform.  Both
+// tables of the sub-transform in flight are one LDS image refreshed by LDS-DMA (buffer_load ... lds: 1 KB = 64 lanes x 16 bytes per
+// wave-instruction, no VGPRs, no ds_write; six of them per sub-transform, spread over the four waves): -1.4 % kernel time on
+// configs[1] and [4] (profiles/r04_experiments/a_fold_bq.log; with per-thread copies instead of the DMA it was -0.6 %).
+template <int MC, int WPS, int NB, bool NC, bool W1H = false, bool PROF = false, class L = ACQ_CORR_LAYOUT, bool NCREG = false, bool FOLD = false>
 __global__ __launch_bounds__(WG, WPS) void k_corr(CorrArgs a) {
     __shared__ __attribute__((aligned(16))) cf lds[L::SIZE];  // transform buffer
-    __shared__ cf t2s[NT2];    // the 500 pass-2 twiddles
+    // pass 2's 500 twiddles; with FOLD followed by the accumulate factors [alpha][column], in whole 1 KB chunks (the DMA's unit)
+    constexpr int TQS = TqStride<MC>::value;
+    constexpr int NTAB = NT2 + RA * TQS, NCHUNK = (NTAB + 127) / 128;
+    __shared__ __attribute__((aligned(16))) cf tabs[FOLD ? NCHUNK * 128 : NT2];
+    cf* const t2s = tabs;
+    const cf* const tqs = tabs + NT2;
     __shared__ float red[4 * (WG / 64)];
     __shared__ float pws[NC && !NCREG ? MC * NBF3 : 1];  // non-coherent power per lag of this pass
     const int tid = threadIdx.x;
@@ -302,7 +317,8 @@ __global__ __launch_bounds__(WG, WPS) void k_corr(CorrArgs a) {
     const cf* cpp = a.cpp + (size_t)tk.code * NPOLY * a.crow;
 
     // q-independent twiddles: pass 2's table into LDS (16-byte copies), pass 1's into registers
-    for (int i = tid; i < NT2; i += WG) t2s[i] = a.t2[i];
+    if constexpr (!FOLD)
+        for (int i = tid; i < NT2; i += WG) t2s[i] = a.t2[i];
     cf w1[2][RA - 1];
     load_tw1<W1H, L>(tid, a.t1, w1);
 
@@ -329,18 +345,53 @@ __global__ __launch_bounds__(WG, WPS) void k_corr(CorrArgs a) {
     const int t3 = tid < NBF3 ? tid : 0;
     const int rho = corr_rho<L>(a, t3);  // the radix-20 butterfly (output residue) this thread owns
     const int n_acc = NC ? a.n_acc : 1;
+    // FOLD: which 16 bytes of the global table fold[q] (acq_tables.hpp TablesFold: [t2q (500)][tq (10 x 160)] per q) each lane copies
+    // into its slot of the LDS image, for the one or two chunks this wave is responsible for (lanes past the image copy entry 0
+    // into the image's padding)
+    int fold_wave = 0, fold_voff[2] = {0, 0};
+    if constexpr (FOLD) {
+        fold_wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+#pragma unroll
+        for (int sdma = 0; sdma < 2; ++sdma) {
+            const int e = 128 * (fold_wave + 4 * sdma) + 2 * (tid & 63);
+            int src = 0;
+            if (e < NT2) src = e;
+            else if (e < NTAB) {
+                const int e2 = e - NT2, row = e2 / TQS;
+                src = NT2 + row * NW160 + a.m0 + (e2 - row * TQS);
+            }
+            fold_voff[sdma] = src * (int)sizeof(cf);
+        }
+    }
     for (int k = 0; k < n_acc; ++k) {
         const cf* dk = dpp + (size_t)k * a.acc_step * a.sub * NPOLY * M_SUB;
         for (int q = 0; q < NPOLY; ++q) {
-            const cf b = a.bq[q * NBF3 + rho];  // per-thread rotation of this sub-transform
-            // wave-uniform rotations: scalar loads, SGPR operands.  Up to 22 columns are fetched here, ahead of the sub-transform;
-            // the wide instances fetch them in chunks inside pass 3 (corr_phase3) to stay inside the SGPR file
-            cf wq_early[MC <= 22 ? MC : 1];
-            if (MC <= 22) {
+            cf b = mk(0.f, 0.f);
+            cf wq_early[(!FOLD && MC <= 22) ? MC : 1];
+            const cf* wqv = wq_early;
+            if constexpr (FOLD) {
+                // this sub-transform's tables, global -> LDS by DMA.  Nobody reads the image any more (pass 2 of the previous
+                // sub-transform read t2s before its second barrier, pass 3 read tqs before its third); the barrier that ends phase 1 --
+                // which waits for this wave's vmcnt first -- orders the new image before pass 2's reads.
+#if defined(__HIP_DEVICE_COMPILE__)
+                const __amdgpu_buffer_rsrc_t fold_rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)a.fold, 0, (int)((NPOLY * FOLD_Q + 8) * sizeof(cf)), 0x00020000);
 #pragma unroll
-                for (int m = 0; m < MC; ++m) wq_early[m] = c_wq[q * WQ_STRIDE + a.m0 + m];
+                for (int sdma = 0; sdma < 2; ++sdma)
+                    if (fold_wave + 4 * sdma < NCHUNK)
+                        __builtin_amdgcn_raw_ptr_buffer_load_lds(fold_rsrc, (__attribute__((address_space(3))) void*)(tabs + 128 * (fold_wave + 4 * sdma)), 16,
+                                                                 fold_voff[sdma], q * (int)(FOLD_Q * sizeof(cf)), 0, 0);
+#endif
+            } else {
+                b = a.bq[q * NBF3 + rho];  // per-thread rotation of this sub-transform
+                // wave-uniform rotations: scalar loads, SGPR operands.  Up to 22 columns are fetched here, ahead of the sub-transform;
+                // the wide instances fetch them in chunks inside pass 3 (corr_phase3) to stay inside the SGPR file
+                if (MC <= 22) {
+#pragma unroll
+                    for (int m = 0; m < MC; ++m) wq_early[m] = c_wq[q * WQ_STRIDE + a.m0 + m];
+                } else {
+                    wqv = c_wq + q * WQ_STRIDE + a.m0;
+                }
             }
-            const cf* wqv = MC <= 22 ? wq_early : c_wq + q * WQ_STRIDE + a.m0;
             ACQ_PHASE1_PRIO(1);
             corr_phase1<NB, W1H, L>(tid, q, dop, dk, cpp, a.crow, a.halo, w1, lds);
             ACQ_PHASE1_PRIO(0);
@@ -351,7 +402,8 @@ __global__ __launch_bounds__(WG, WPS) void k_corr(CorrArgs a) {
             ACQ_STAMP(3);
             __syncthreads();
             ACQ_STAMP(4);
-            corr_phase3<MC, L>(tid, rho, b, wqv, lds, acc);
+            if constexpr (FOLD) corr_phase3_fold<MC, L>(tid, rho, tqs, lds, acc);
+            else corr_phase3<MC, L>(tid, rho, b, wqv, lds, acc);
             ACQ_STAMP(5);
             __syncthreads();
             ACQ_STAMP(6);
@@ -638,7 +690,7 @@ int launch_corr(const CorrArgs& a, int mc, hipStream_t s) {
     // 22-column coherent instance -- 31000 leaves two workgroups per CU, 60000 one (tools/residency_curve.py)
     static const int lds_pad = [] { const char* v = getenv("GPSACQ_CORR_LDS_PAD"); return v && *v ? atoi(v) : 0; }();
     if (lds_pad > 0 && mc == 22 && a.n_acc == 1 && !a.prof) {
-        hipLaunchKernelGGL((k_corr<22, 3, 2, false>), grid, block, (size_t)lds_pad, s, a);
+        hipLaunchKernelGGL((k_corr<22, 3, 2, false, false, false, ACQ_CORR_LAYOUT, false, ACQ_CORR_FOLD22>), grid, block, (size_t)lds_pad, s, a);
         return 0;
     }
 #endif
@@ -657,9 +709,9 @@ int launch_corr(const CorrArgs& a, int mc, hipStream_t s) {
         case 22:
             if (a.n_acc > 1) hipLaunchKernelGGL((k_corr<22, 2, 2, true>), grid, block, 0, s, a);
 #ifdef ACQ_EXPERIMENTS
-            else if (a.prof) hipLaunchKernelGGL((k_corr<22, 3, 2, false, false, true>), grid, block, 0, s, a);
+            else if (a.prof) hipLaunchKernelGGL((k_corr<22, 3, 2, false, false, true, ACQ_CORR_LAYOUT, false, ACQ_CORR_FOLD22>), grid, block, 0, s, a);
 #endif
-            else hipLaunchKernelGGL((k_corr<22, 3, 2, false>), grid, block, 0, s, a);
+            else hipLaunchKernelGGL((k_corr<22, 3, 2, false, false, false, ACQ_CORR_LAYOUT, false, ACQ_CORR_FOLD22>), grid, block, 0, s, a);
             break;
         case 28:
             if (a.n_acc > 1) hipLaunchKernelGGL((k_corr<28, 2, 2, true>), grid, block, 0, s, a);

@@ -49,6 +49,8 @@ struct CorrArgs {
     const cf* t1;
     const cf* t2;
     const cf* bq;      // [8][250] by rho
+    const cf* fold;    // k_corr<..., FOLD>: [8][FOLD_Q] per sub-transform q: pass-2 output twiddles with W_4000^{q beta} folded in [25][20], then the
+                       // accumulate factors W_40000^{q (250 m + alpha)} [10][160] (acq_tables.hpp TablesFold)
     const unsigned char* rho_map;  // [256] LayC: pass-3 thread -> rho (acq_math.hpp kRhoC)
     Cell* cells;       // [n_tasks][ndop]
     int n_tasks, ndop, dop_first, nlags, crow, halo;  // bins dop_first .. dop_first+ndop-1

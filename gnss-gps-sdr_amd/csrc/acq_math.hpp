@@ -51,6 +51,7 @@ constexpr int NW160 = N_FFT / NBF3;  // 160
 constexpr int NT2 = RB * RC;         // 500 pass-2 twiddles
 constexpr int MC_MAX = 40;           // accumulator columns per pass: 10000 lags; more lags take more passes
 constexpr int WQ_STRIDE = NW160;     // wq[q][m] = W_160^{q m}, all 160 columns (40000 lags)
+constexpr int FOLD_Q = NT2 + RA * NW160;  // folded-rotation tables per sub-transform: 500 pass-2 twiddles + 10 x 160 accumulate factors
 
 typedef float cf __attribute__((ext_vector_type(2)));  // (re, im); one 64-bit VGPR pair on the device
 
@@ -105,6 +106,17 @@ ACQ_HD cf cmacc_u(cf acc, cf a, cf w) {
     cf r = acc;  // r += (ax wx, ay wx);  r += (ay wy, -ax wy)
     asm("v_pk_fma_f32 %0, %1, %2, %0 op_sel_hi:[1,0,1]\n\t"
         "v_pk_fma_f32 %0, %1, %2, %0 op_sel:[1,1,0] op_sel_hi:[0,1,1] neg_hi:[1,0,0]" : "+v"(r) : "v"(a), "s"(w));
+    return r;
+#else
+    return acc + cmulc(a, w);
+#endif
+}
+// acc + a * conj(w), w per lane (VGPR pair)
+ACQ_HD cf cmacc(cf acc, cf a, cf w) {
+#if ACQ_PK_ASM
+    cf r = acc;
+    asm("v_pk_fma_f32 %0, %1, %2, %0 op_sel_hi:[1,0,1]\n\t"
+        "v_pk_fma_f32 %0, %1, %2, %0 op_sel:[1,1,0] op_sel_hi:[0,1,1] neg_hi:[1,0,0]" : "+v"(r) : "v"(a), "v"(w));
     return r;
 #else
     return acc + cmulc(a, w);

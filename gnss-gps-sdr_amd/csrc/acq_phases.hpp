@@ -152,6 +152,33 @@ ACQ_HD void corr_phase3(int tid, int rho, cf b, const cf* wqv, const cf* lds, cf
     }
 }
 
+// The same with the rotation folded (k_corr<..., FOLD = true>, acq_tables.hpp TablesFold): pass 2 has applied W_4000^{q beta}; what is left,
+// W_40000^{q (250 m + alpha)}, depends on the lane only through alpha and is read from the workgroup's LDS copy tqs[alpha][m]
+// (row stride TQS: chosen per instance so that the ten rows a wave reads at once sit in disjoint banks; lanes of one alpha
+// read one address -- a broadcast).  No per-thread multiply: 20 complex multiplies fewer per thread and sub-transform.
+template <int MC> struct TqStride {  // even (16-byte reads), and {2 TQS alpha mod 64, alpha < 10} four banks apart
+    static constexpr int value = MC <= 12 ? 14 : MC <= 22 ? 22 : MC <= 28 ? 30 : MC <= 33 ? 34 : 42;
+};
+template <int MC, class L = LayB>
+ACQ_HD void corr_phase3_fold(int tid, int rho, const cf* tqs, const cf* lds, cf* acc) {
+    if (tid >= NBF3) return;
+    cf y[RC];
+    pass3_load<+1, L>(rho, lds, y);
+    const cf* wrow = tqs + (rho % RA) * TqStride<MC>::value;
+    constexpr int CH = 8;  // factors fetched per chunk: 4 16-byte reads, 16 VGPRs (requesting a chunk ahead: 168 VGPRs, no gain)
+#pragma unroll
+    for (int c0 = 0; c0 < MC; c0 += CH) {
+        cf w[CH];
+#pragma unroll
+        for (int i = 0; i < CH; i += 2)
+            if (c0 + i < MC) ld2(wrow + c0 + i, w[i], w[i + 1]);  // (the row is padded to an even length)
+        ACQ_SCHED_FENCE();
+#pragma unroll
+        for (int i = 0; i < CH; ++i)
+            if (c0 + i < MC) acc[c0 + i] = cmacc(acc[c0 + i], y[(c0 + i) % RC], w[i]);
+    }
+}
+
 // Doppler grid point k (in units of the grid step) -> whole-bin shift `dop` of the code spectrum (:182) and the
 // index r of the sub-bin-offset spectrum of the block.  sub > 1: step = bin / sub, k = dop * sub + r with
 // r in [0, sub); else step = dstride bins, k = dop / dstride.  sub = dstride = 1 is the reference's grid.

@@ -40,6 +40,30 @@ struct Tables {
     }
 };
 
+// Tables of the folded radix-8 rotation (k_corr<..., FOLD>): the rotation W_40000^{q n} of sub-transform q's outputs,
+// n = 250 m + 10 beta + alpha, split as  W_4000^{q beta} (into pass 2's output twiddle: one 500-entry table per q)  x
+// W_40000^{q (250 m + alpha)} (the accumulate's factor: per q a [10][160] table a workgroup copies its columns of into LDS),
+// so that pass 3 multiplies nothing by a per-thread factor any more (20 complex multiplies per thread and sub-transform).
+struct TablesFold {
+    std::vector<cf> t2q;  // [8][25][20]   W_500^{j'' beta} W_4000^{q beta}
+    std::vector<cf> tq;   // [8][10][160]  W_40000^{q (250 m + alpha)}
+    TablesFold() : t2q((size_t)NPOLY * NT2), tq((size_t)NPOLY * RA * NW160 + 8, mk(0.f, 0.f)) {  // (+ tail padding, see k_corr)
+        for (int q = 0; q < NPOLY; ++q) {
+            for (int be = 0; be < RB; ++be)
+                for (int jpp = 0; jpp < RC; ++jpp)  // j'' beta / 500 + q beta / 4000 = (8 j'' + q) beta / 4000
+                    t2q[((size_t)q * RB + be) * RC + jpp] = unit_fwd((long long)(8 * jpp + q) * be, 4000);
+            for (int al = 0; al < RA; ++al)
+                for (int m = 0; m < NW160; ++m) tq[((size_t)q * RA + al) * NW160 + m] = unit_fwd((long long)q * (NBF3 * m + al), N_FFT);
+        }
+        fold.assign((size_t)NPOLY * FOLD_Q + 8, mk(0.f, 0.f));  // the device image: per q [t2q][tq], + tail padding
+        for (int q = 0; q < NPOLY; ++q) {
+            for (int i = 0; i < NT2; ++i) fold[(size_t)q * FOLD_Q + i] = t2q[(size_t)q * NT2 + i];
+            for (int i = 0; i < RA * NW160; ++i) fold[(size_t)q * FOLD_Q + NT2 + i] = tq[(size_t)q * RA * NW160 + i];
+        }
+    }
+    std::vector<cf> fold;
+};
+
 // Tables of the 8-wave correlator (acq_corr8.hpp)
 struct Tables8 {
     std::vector<cf> t1;  // [5][1000]   W_5000^{j' alpha}

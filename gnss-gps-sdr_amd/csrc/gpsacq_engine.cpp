@@ -71,6 +71,7 @@ struct gpsacq_engine {
     long searches = 0;  // searches enqueued so far; search k uses ring slot k % kTimingRing
     // constants
     cf *d_t1 = nullptr, *d_t2 = nullptr, *d_bq = nullptr, *d_tn = nullptr;
+    cf* d_fold = nullptr;  // the folded-rotation tables of k_corr<..., FOLD> (acq_tables.hpp TablesFold)
     unsigned char* d_rho = nullptr;
     // variant build (-DACQ_EXPERIMENTS) only: tables of the 8-wave correlator; GPSACQ_CORR8=2|3 runs coherent single-pass searches
     // on k_corr8 at that many workgroups per CU.  Always NULL / 0 in the product library.
@@ -219,7 +220,7 @@ extern "C" void gpsacq_destroy(gpsacq_engine* e) {
     if (!e) return;
     (void)hipSetDevice(e->p.device);
     if (e->stream) (void)hipStreamSynchronize(e->stream);
-    void* bufs[] = {e->d_t1, e->d_t2, e->d_bq, e->d_tn, e->d_rho, e->d_t1_8, e->d_t2_8, e->d_t3_8, e->d_bq8, e->d_cos, e->d_sin, e->d_cos_t, e->d_sin_t, e->d_code, e->d_patch_blocks, e->d_bits, e->d_iq, e->d_iqbits, e->d_fsamp, e->d_pdump, e->d_sums, e->d_sats, e->d_gen, e->d_prof, e->d_rot8, e->d_lutc,
+    void* bufs[] = {e->d_t1, e->d_t2, e->d_bq, e->d_fold, e->d_tn, e->d_rho, e->d_t1_8, e->d_t2_8, e->d_t3_8, e->d_bq8, e->d_cos, e->d_sin, e->d_cos_t, e->d_sin_t, e->d_code, e->d_patch_blocks, e->d_bits, e->d_iq, e->d_iqbits, e->d_fsamp, e->d_pdump, e->d_sums, e->d_sats, e->d_gen, e->d_prof, e->d_rot8, e->d_lutc,
                     e->d_dpp, e->d_parts, e->d_tasks, e->d_cells, e->d_peaks};
     for (void* b : bufs)
         if (b) (void)hipFree(b);
@@ -261,6 +262,7 @@ extern "C" int gpsacq_create(const gpsacq_params* params, gpsacq_engine** out) {
     // it runs in a worker while this thread sits in the HIP runtime's start-up (>100 ms in the first HIP call of a process).
     struct HostPrep {
         Tables T;
+        TablesFold TF;
 #ifdef ACQ_EXPERIMENTS
         Tables8 T8;
 #endif
@@ -387,6 +389,8 @@ extern "C" int gpsacq_create(const gpsacq_params* params, gpsacq_engine** out) {
         e->corr8 = (c8 && *c8) ? atoi(c8) : 0;
     }
 #endif
+    HCK(hipMalloc((void**)&e->d_fold, hp->TF.fold.size() * sizeof(cf)));
+    HCK(hipMemcpy(e->d_fold, hp->TF.fold.data(), hp->TF.fold.size() * sizeof(cf), hipMemcpyHostToDevice));
     HCK(hipMalloc((void**)&e->d_bq, T.bq.size() * sizeof(cf)));
     HCK(hipMemcpy(e->d_bq, T.bq.data(), T.bq.size() * sizeof(cf), hipMemcpyHostToDevice));
     HCK(hipMemcpy(e->d_t1, T.t1.data(), T.t1.size() * sizeof(cf), hipMemcpyHostToDevice));
@@ -628,6 +632,7 @@ static int search_core(gpsacq_engine* e, const Capture& cap_in, size_t n_blocks,
     ca.t1 = e->d_t1;
     ca.t2 = e->d_t2;
     ca.bq = e->d_bq;
+    ca.fold = e->d_fold;
     ca.rho_map = e->d_rho;
 #ifdef ACQ_EXPERIMENTS
     ca.t1_8 = e->d_t1_8;

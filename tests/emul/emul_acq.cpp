@@ -116,8 +116,9 @@ void emul_forward_real(const float* x, float* out) {
 // lay: 1 = LayB (round 2's lane map), 2 = LayC (the product's: conflict-free lane assignment)
 template <class L>
 static int emul_cell_l(const float* dspec, const float* cspec, int halo, int dop, int S, int mc, int w1h, float* max_pwr,
-                       int* max_i, float* tot_pwr) {
+                       int* max_i, float* tot_pwr, bool fold = false) {
     const Tables& T = tables();
+    static const TablesFold TF;
     const int crow = M_SUB + 2 * halo;
     std::vector<cf> dpp((size_t)NPOLY * M_SUB), cpp((size_t)NPOLY * crow);
     for (int k = 0; k < N_FFT; ++k) {
@@ -143,7 +144,27 @@ static int emul_cell_l(const float* dspec, const float* cspec, int halo, int dop
             if (w1h) corr_phase1<2, true, L>(tid, q, dop, dpp.data(), cpp.data(), crow, halo, w, lds.data());
             else corr_phase1<2, false, L>(tid, q, dop, dpp.data(), cpp.data(), crow, halo, w, lds.data());
         }
-        for (int tid = 0; tid < WG; ++tid) corr_phase2<L>(tid, T.t2.data(), lds.data());
+        for (int tid = 0; tid < WG; ++tid) corr_phase2<L>(tid, fold ? TF.t2q.data() + (size_t)q * NT2 : T.t2.data(), lds.data());
+        if (fold) {  // the workgroup's LDS copy of this sub-transform's accumulate factors, as the kernel lays it out
+            std::vector<cf> tqs((size_t)RA * 42, mk(0.f, 0.f));
+            auto fill = [&](int tqs_stride) {
+                for (int al = 0; al < RA; ++al)
+                    for (int c = 0; c < tqs_stride; ++c) tqs[(size_t)al * tqs_stride + c] = TF.tq[((size_t)q * RA + al) * NW160 + c];
+            };
+            for (int tid = 0; tid < WG; ++tid) {
+                cf* a = &acc[(size_t)tid * MC_MAX];
+                const int rho = pass3_rho<L>(tid < NBF3 ? tid : 0);
+                switch (mc) {
+                    case 12: if (!tid) fill(TqStride<12>::value); corr_phase3_fold<12, L>(tid, rho, tqs.data(), lds.data(), a); break;
+                    case 22: if (!tid) fill(TqStride<22>::value); corr_phase3_fold<22, L>(tid, rho, tqs.data(), lds.data(), a); break;
+                    case 28: if (!tid) fill(TqStride<28>::value); corr_phase3_fold<28, L>(tid, rho, tqs.data(), lds.data(), a); break;
+                    case 33: if (!tid) fill(TqStride<33>::value); corr_phase3_fold<33, L>(tid, rho, tqs.data(), lds.data(), a); break;
+                    case 40: if (!tid) fill(TqStride<40>::value); corr_phase3_fold<40, L>(tid, rho, tqs.data(), lds.data(), a); break;
+                    default: return -1;
+                }
+            }
+            continue;
+        }
         for (int tid = 0; tid < WG; ++tid) {
             cf* a = &acc[(size_t)tid * MC_MAX];
             const int rho = pass3_rho<L>(tid < NBF3 ? tid : 0);
@@ -186,6 +207,7 @@ int emul_cell(const float* dspec, const float* cspec, int halo, int dop, int S, 
               int* max_i, float* tot_pwr) {
     if (lay == 1) return emul_cell_l<LayB>(dspec, cspec, halo, dop, S, mc, w1h, max_pwr, max_i, tot_pwr);
     if (lay == 2) return emul_cell_l<LayC>(dspec, cspec, halo, dop, S, mc, w1h, max_pwr, max_i, tot_pwr);
+    if (lay == 3) return emul_cell_l<LayC>(dspec, cspec, halo, dop, S, mc, w1h, max_pwr, max_i, tot_pwr, true);  // folded rotation (k_corr<..., FOLD>)
     return -1;
 }
 }  // extern "C"
