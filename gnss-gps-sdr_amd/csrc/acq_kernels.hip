@@ -197,6 +197,10 @@ __global__ __launch_bounds__(WG) void k_quirk_patch(QuirkArgs a) {
 #ifndef ACQ_CORR_FOLD22
 #define ACQ_CORR_FOLD22 true  // -DACQ_CORR_FOLD22=false: the 22-column coherent instance with round 3's rotation (A/B runs)
 #endif
+#ifndef ACQ_CORR_ROT22
+#define ACQ_CORR_ROT22 false  // -DACQ_CORR_ROT22=true: pass 2 by rotating roles (below): bit-identical cells, -8.9 % wave-instructions,
+                              // -0.3 % kernel time (profiles/r04_experiments/g_pass2_roles.log): measured, not in the product
+#endif
 // Wave priority (round 3, profiles/r03_experiments/b_priority_stagger.log): a wave runs the first phase of a sub-transform --
 // input loads, product, radix-10 pair, pass-1 stores: the short, latency-bound part that ends in the barrier its three
 // partner waves wait at -- one priority level above the long radix-25 / radix-20 phases of the waves of OTHER workgroups it
@@ -282,8 +286,11 @@ template <class L> __device__ __forceinline__ int corr_rho(const CorrArgs& a, in
 // tables of the sub-transform in flight are one LDS image refreshed by LDS-DMA (buffer_load ... lds: 1 KB = 64 lanes x 16 bytes per
 // wave-instruction, no VGPRs, no ds_write; six of them per sub-transform, spread over the four waves): -1.4 % kernel time on
 // configs[1] and [4] (profiles/r04_experiments/a_fold_bq.log; with per-thread copies instead of the DMA it was -0.6 %).
-template <int MC, int WPS, int NB, bool NC, bool W1H = false, bool PROF = false, class L = ACQ_CORR_LAYOUT, bool NCREG = false, bool FOLD = false>
+// ROT (round 4; with FOLD): pass 2 by roles (acq_phases.hpp corr_phase2_role): the wave that would run the radix-25 for 8 of its 64
+// lanes does those 8 butterflies as 2 x 40 five-point transforms instead, and the role rotates over the waves with q.
+template <int MC, int WPS, int NB, bool NC, bool W1H = false, bool PROF = false, class L = ACQ_CORR_LAYOUT, bool NCREG = false, bool FOLD = false, bool ROT = false>
 __global__ __launch_bounds__(WG, WPS) void k_corr(CorrArgs a) {
+    static_assert(!ROT || L::REMAP, "the light role is written for LayC's pass-2 lane map");
     __shared__ __attribute__((aligned(16))) cf lds[L::SIZE];  // transform buffer
     // pass 2's 500 twiddles; with FOLD followed by the accumulate factors [alpha][column], in whole 1 KB chunks (the DMA's unit)
     constexpr int TQS = TqStride<MC>::value;
@@ -293,6 +300,7 @@ __global__ __launch_bounds__(WG, WPS) void k_corr(CorrArgs a) {
     const cf* const tqs = tabs + NT2;
     __shared__ float red[4 * (WG / 64)];
     __shared__ float pws[NC && !NCREG ? MC * NBF3 : 1];  // non-coherent power per lag of this pass
+    __shared__ cf w25s[ROT ? 25 : 1];  // ROT: W_25^{k1 n2} by lane of the light role
     const int tid = threadIdx.x;
     const int g = blockIdx.x, xcd = g & 7, slot = g >> 3;
     const int grp = slot / a.ndop, di = slot - grp * a.ndop;
@@ -319,6 +327,9 @@ __global__ __launch_bounds__(WG, WPS) void k_corr(CorrArgs a) {
     // q-independent twiddles: pass 2's table into LDS (16-byte copies), pass 1's into registers
     if constexpr (!FOLD)
         for (int i = tid; i < NT2; i += WG) t2s[i] = a.t2[i];
+    if constexpr (ROT)
+        if (tid < 25) w25s[tid] = w25_of(tid / 5, tid % 5);  // (read two barriers on at the earliest)
+    const int my_wave = ROT ? __builtin_amdgcn_readfirstlane(tid >> 6) : 0;
     cf w1[2][RA - 1];
     load_tw1<W1H, L>(tid, a.t1, w1);
 
@@ -398,7 +409,8 @@ __global__ __launch_bounds__(WG, WPS) void k_corr(CorrArgs a) {
             ACQ_STAMP(1);  // inputs loaded and multiplied, pass 1, its LDS stores drained (the stamp waits on lgkmcnt)
             __syncthreads();  // also orders the t2s fill before its first use
             ACQ_STAMP(2);
-            corr_phase2<L>(tid, t2s, lds);
+            if constexpr (ROT) corr_phase2_role<L>((my_wave + q) & 3, tid & 63, t2s, w25s, lds);
+            else corr_phase2<L>(tid, t2s, lds);
             ACQ_STAMP(3);
             __syncthreads();
             ACQ_STAMP(4);
@@ -690,7 +702,7 @@ int launch_corr(const CorrArgs& a, int mc, hipStream_t s) {
     // 22-column coherent instance -- 31000 leaves two workgroups per CU, 60000 one (tools/residency_curve.py)
     static const int lds_pad = [] { const char* v = getenv("GPSACQ_CORR_LDS_PAD"); return v && *v ? atoi(v) : 0; }();
     if (lds_pad > 0 && mc == 22 && a.n_acc == 1 && !a.prof) {
-        hipLaunchKernelGGL((k_corr<22, 3, 2, false, false, false, ACQ_CORR_LAYOUT, false, ACQ_CORR_FOLD22>), grid, block, (size_t)lds_pad, s, a);
+        hipLaunchKernelGGL((k_corr<22, 3, 2, false, false, false, ACQ_CORR_LAYOUT, false, ACQ_CORR_FOLD22, ACQ_CORR_ROT22>), grid, block, (size_t)lds_pad, s, a);
         return 0;
     }
 #endif
@@ -709,9 +721,9 @@ int launch_corr(const CorrArgs& a, int mc, hipStream_t s) {
         case 22:
             if (a.n_acc > 1) hipLaunchKernelGGL((k_corr<22, 2, 2, true>), grid, block, 0, s, a);
 #ifdef ACQ_EXPERIMENTS
-            else if (a.prof) hipLaunchKernelGGL((k_corr<22, 3, 2, false, false, true, ACQ_CORR_LAYOUT, false, ACQ_CORR_FOLD22>), grid, block, 0, s, a);
+            else if (a.prof) hipLaunchKernelGGL((k_corr<22, 3, 2, false, false, true, ACQ_CORR_LAYOUT, false, ACQ_CORR_FOLD22, ACQ_CORR_ROT22>), grid, block, 0, s, a);
 #endif
-            else hipLaunchKernelGGL((k_corr<22, 3, 2, false, false, false, ACQ_CORR_LAYOUT, false, ACQ_CORR_FOLD22>), grid, block, 0, s, a);
+            else hipLaunchKernelGGL((k_corr<22, 3, 2, false, false, false, ACQ_CORR_LAYOUT, false, ACQ_CORR_FOLD22, ACQ_CORR_ROT22>), grid, block, 0, s, a);
             break;
         case 28:
             if (a.n_acc > 1) hipLaunchKernelGGL((k_corr<28, 2, 2, true>), grid, block, 0, s, a);

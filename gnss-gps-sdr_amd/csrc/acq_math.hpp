@@ -458,6 +458,58 @@ template <int DIR, class L = LayA> ACQ_HD void pass2_inplace(int e, const cf* __
     for (int be = 1; be < RB; ++be) p[L::SB * be] = tw<DIR>(y[be], t2[be * RC + jpp]);
 }
 
+// ---- pass 2, the light role (round 4).  200 radix-25 butterflies on 256 lanes leave the fourth wave 8 of them: 262 instructions for
+// 8 lanes.  Those 8 butterflies (LayC lanes 192..199: alpha = 8 + (i >> 2), j'' = 16 + (i & 3)) = 200 elements are instead done as two
+// rounds of 40 five-point transforms on 40 lanes of that wave -- the same dft5 calls, the same twiddle products in the same order
+// as radix25(), hence the same bits -- exchanging through the butterflies' own LDS slots (a wave's LDS operations complete in
+// order: no barrier between the rounds).  ~54 packed instructions instead of 262; the kernel rotates the role over the four waves
+// from sub-transform to sub-transform so that every SIMD is relieved equally.
+// forward value of W_25^{k1 n2} as radix25() applies it ((1, 0) where it applies none: that product is exact)
+ACQ_HD cf w25_of(int k1, int n2) {
+    switch (k1 * n2) {
+        case 1: return w25<1>();
+        case 2: return w25<2>();
+        case 3: return w25<3>();
+        case 4: return w25<4>();
+        case 6: return w25<6>();
+        case 8: return w25<8>();
+        case 9: return w25<9>();
+        case 12: return w25<12>();
+        case 16: return w25<16>();
+        default: return mk(1.f, 0.f);
+    }
+}
+// round A, lane l < 40 = (butterfly i = l / 5, n2 = l % 5): five-point transform over n1 of elements b = 5 n1 + n2, times W_25^{k1 n2},
+// written back to slot b = 5 k1 + n2.  w25s[k1 * 5 + n2] = w25_of(k1, n2) (a 25-entry LDS table).
+template <int DIR, class L> ACQ_HD void pass2_light_a(int l, const cf* w25s, cf* lds) {
+    const int i = l / 5, n2 = l - 5 * i;
+    cf* p = lds + L::SA * (8 + (i >> 2)) + L::SJ * (16 + (i & 3));
+    cf a = p[L::SB * n2], b = p[L::SB * (5 + n2)], c = p[L::SB * (10 + n2)], d = p[L::SB * (15 + n2)], e = p[L::SB * (20 + n2)];
+    dft5<DIR>(a, b, c, d, e);
+    p[L::SB * n2] = a;
+    p[L::SB * (5 + n2)] = tw<DIR>(b, w25s[5 + n2]);
+    p[L::SB * (10 + n2)] = tw<DIR>(c, w25s[10 + n2]);
+    p[L::SB * (15 + n2)] = tw<DIR>(d, w25s[15 + n2]);
+    p[L::SB * (20 + n2)] = tw<DIR>(e, w25s[20 + n2]);
+}
+// round B, lane l < 40 = (butterfly i, k1 = l % 5): five-point transform over n2 of slots 5 k1 + n2 -> outputs beta = k1 + 5 k2, times
+// pass 2's output twiddle, stored to slot beta
+// (src == dst in the kernel: every lane of the wave has read its five slots before any lane's stores are issued -- one instruction
+// stream, in-order LDS; the CPU emulation, which runs the lanes one after the other, reads from a snapshot)
+template <int DIR, class L> ACQ_HD void pass2_light_b(int l, const cf* __restrict__ t2, const cf* src, cf* dst) {
+    const int i = l / 5, k1 = l - 5 * i, jpp = 16 + (i & 3);
+    const int off = L::SA * (8 + (i >> 2)) + L::SJ * jpp;
+    const cf* ps = src + off;
+    cf* p = dst + off;
+    cf v0 = ps[L::SB * (5 * k1)], v1 = ps[L::SB * (5 * k1 + 1)], v2 = ps[L::SB * (5 * k1 + 2)], v3 = ps[L::SB * (5 * k1 + 3)], v4 = ps[L::SB * (5 * k1 + 4)];
+    dft5<DIR>(v0, v1, v2, v3, v4);
+    p[L::SB * k1] = k1 == 0 ? v0 : tw<DIR>(v0, t2[k1 * RC + jpp]);
+    p[L::SB * (k1 + 5)] = tw<DIR>(v1, t2[(k1 + 5) * RC + jpp]);
+    p[L::SB * (k1 + 10)] = tw<DIR>(v2, t2[(k1 + 10) * RC + jpp]);
+    p[L::SB * (k1 + 15)] = tw<DIR>(v3, t2[(k1 + 15) * RC + jpp]);
+    p[L::SB * (k1 + 20)] = tw<DIR>(v4, t2[(k1 + 20) * RC + jpp]);
+}
+
 // pass 3 for the butterfly rho = 10 beta + alpha (0..249): y[n''] = F[250 n'' + rho].
 template <int DIR, class L = LayA> ACQ_HD void pass3_load(int rho, const cf* lds, cf* y) {
     const int be = rho / RA, al = rho - be * RA;

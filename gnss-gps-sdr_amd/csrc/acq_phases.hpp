@@ -123,6 +123,19 @@ template <class L = LayB>
 ACQ_HD void corr_phase2(int tid, const cf* t2, cf* lds) {
     if (tid < NBF2) pass2_inplace<+1, L>(tid, t2, lds);
 }
+// The same with roles (k_corr<..., ROT>, LayC's lane map): roles 0..2 are the first 192 butterflies on full waves, role 3 does the
+// last 8 as two rounds of five-point transforms on 40 lanes (acq_math.hpp pass2_light_*); the kernel hands role (wave + q) mod 4 to
+// each wave, so the light role visits every wave -- and every SIMD -- twice per cell.  Same bits as corr_phase2.
+template <class L = LayC>
+ACQ_HD void corr_phase2_role(int role, int lane, const cf* t2, const cf* w25s, cf* lds) {
+    if (role < 3) {
+        pass2_inplace<+1, L>(64 * role + lane, t2, lds);
+    } else if (lane < 40) {
+        pass2_light_a<+1, L>(lane, w25s, lds);
+        ACQ_SCHED_FENCE();
+        pass2_light_b<+1, L>(lane, t2, lds, lds);
+    }
+}
 
 // acc[m] accumulates y[n] for n = 250 (m0 + m) + rho over the 8 polyphase components (m0, the first
 // column of this pass, is a multiple of 20 so that column m0 + m reads radix-20 output m % 20):

@@ -116,9 +116,11 @@ void emul_forward_real(const float* x, float* out) {
 // lay: 1 = LayB (round 2's lane map), 2 = LayC (the product's: conflict-free lane assignment)
 template <class L>
 static int emul_cell_l(const float* dspec, const float* cspec, int halo, int dop, int S, int mc, int w1h, float* max_pwr,
-                       int* max_i, float* tot_pwr, bool fold = false) {
+                       int* max_i, float* tot_pwr, bool fold = false, bool rot = false) {
     const Tables& T = tables();
     static const TablesFold TF;
+    cf w25s[25];
+    for (int i = 0; i < 25; ++i) w25s[i] = w25_of(i / 5, i % 5);
     const int crow = M_SUB + 2 * halo;
     std::vector<cf> dpp((size_t)NPOLY * M_SUB), cpp((size_t)NPOLY * crow);
     for (int k = 0; k < N_FFT; ++k) {
@@ -144,7 +146,21 @@ static int emul_cell_l(const float* dspec, const float* cspec, int halo, int dop
             if (w1h) corr_phase1<2, true, L>(tid, q, dop, dpp.data(), cpp.data(), crow, halo, w, lds.data());
             else corr_phase1<2, false, L>(tid, q, dop, dpp.data(), cpp.data(), crow, halo, w, lds.data());
         }
-        for (int tid = 0; tid < WG; ++tid) corr_phase2<L>(tid, fold ? TF.t2q.data() + (size_t)q * NT2 : T.t2.data(), lds.data());
+        const cf* t2_of_q = fold ? TF.t2q.data() + (size_t)q * NT2 : T.t2.data();
+        if (rot) {  // pass 2 by roles, the light role visiting wave (3 - q) mod 4 (k_corr<..., ROT>); its two rounds are wave-wide steps
+            for (int wave = 0; wave < WG / 64; ++wave) {
+                const int role = (wave + q) & 3;
+                if (role < 3) {
+                    for (int lane = 0; lane < 64; ++lane) pass2_inplace<+1, L>(64 * role + lane, t2_of_q, lds.data());
+                } else {
+                    for (int lane = 0; lane < 40; ++lane) pass2_light_a<+1, L>(lane, w25s, lds.data());
+                    const std::vector<cf> snap(lds);
+                    for (int lane = 0; lane < 40; ++lane) pass2_light_b<+1, L>(lane, t2_of_q, snap.data(), lds.data());
+                }
+            }
+        } else {
+            for (int tid = 0; tid < WG; ++tid) corr_phase2<L>(tid, t2_of_q, lds.data());
+        }
         if (fold) {  // the workgroup's LDS copy of this sub-transform's accumulate factors, as the kernel lays it out
             std::vector<cf> tqs((size_t)RA * 42, mk(0.f, 0.f));
             auto fill = [&](int tqs_stride) {
@@ -208,6 +224,8 @@ int emul_cell(const float* dspec, const float* cspec, int halo, int dop, int S, 
     if (lay == 1) return emul_cell_l<LayB>(dspec, cspec, halo, dop, S, mc, w1h, max_pwr, max_i, tot_pwr);
     if (lay == 2) return emul_cell_l<LayC>(dspec, cspec, halo, dop, S, mc, w1h, max_pwr, max_i, tot_pwr);
     if (lay == 3) return emul_cell_l<LayC>(dspec, cspec, halo, dop, S, mc, w1h, max_pwr, max_i, tot_pwr, true);  // folded rotation (k_corr<..., FOLD>)
+    if (lay == 4) return emul_cell_l<LayC>(dspec, cspec, halo, dop, S, mc, w1h, max_pwr, max_i, tot_pwr, true, true);  // ... + pass 2 by rotating roles (ROT)
+    if (lay == 5) return emul_cell_l<LayC>(dspec, cspec, halo, dop, S, mc, w1h, max_pwr, max_i, tot_pwr, false, true);  // roles without the fold
     return -1;
 }
 }  // extern "C"

@@ -80,7 +80,7 @@ def test_emulated_kernels_vs_oracle(emul, golden_dir, fc, fs, file, mc, w1h):
     assert emul.emul_lane_maps_are_permutations() == 0
     for dop in (-orc.dmax, -9, 0, 1, orc.dmax):
         got = {}
-        for lay in (1, 2, 3):  # LayB (round 2's lane map), LayC (conflict-free lane assignment), LayC with the folded rotation
+        for lay in (1, 2, 3, 4, 5):  # LayB (round 2's lane map), LayC (conflict-free lanes), LayC + folded rotation, + roles in pass 2, roles alone
             mp, mi, tp = ctypes.c_float(), ctypes.c_int(), ctypes.c_float()
             assert emul.emul_cell(_p(d_in), _p(c_in), 24, dop, orc.num_lags, mc, w1h, lay, ctypes.byref(mp), ctypes.byref(mi), ctypes.byref(tp)) == 0
             ref = cells[dop + orc.dmax]
@@ -91,6 +91,8 @@ def test_emulated_kernels_vs_oracle(emul, golden_dir, fc, fs, file, mc, w1h):
         assert got[1][:2] == got[2][:2] and abs(got[1][2] / got[2][2] - 1) < 1e-6
         # the folded rotation multiplies by one table value where the other form multiplies by two: powers agree to float rounding
         assert got[3][1] == got[2][1] and abs(got[3][0] / got[2][0] - 1) < 2e-6 and abs(got[3][2] / got[2][2] - 1) < 2e-6
+        # pass 2 by roles (the last 8 radix-25 butterflies as 2 x 40 five-point transforms) is the same arithmetic: the same bits
+        assert got[4] == got[3] and got[5] == got[2]
         # the 8-wave correlator (5 x 10 x 10 x 10 on 500 threads, acq_corr8.hpp): another factorisation of the same transform
         mp, mi, tp = ctypes.c_float(), ctypes.c_int(), ctypes.c_float()
         assert emul.emul_cell8(_p(d_in), _p(c_in), 24, dop, orc.num_lags, ctypes.byref(mp), ctypes.byref(mi), ctypes.byref(tp)) == 0
