@@ -323,7 +323,7 @@ int for_each_engine(gpsacq_multi* m, F&& body) {
             workers.emplace_back(run, i);
             threaded = i;
         }
-    } catch (const std::system_error&) {
+    } catch (...) {  // no thread to be had (std::system_error) or no memory for its handle: the rest runs inline below
     }
     run(0);
     for (size_t i = threaded + 1; i < n; ++i) run(i);

@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""tools/fuzz_gpu.py [first_seed] [n_seeds] -- wide seeded sweep of the engine against the oracle on the GPU box (one-off
+"""tools/fuzz_gpu.py [first_seed] [n_seeds] (env FUZZ_FS=lo,hi | FUZZ_CLI=1 | FUZZ_PLUMBING=1) -- wide seeded sweep of the engine against the oracle on the GPU box (one-off
 hunting tool; the bounded version lives in tests/test_gpu_extras.py::test_random_grid_configurations).  Per seed: a random
 (fs in 1.2..20 MHz, IF, Doppler range, Doppler step) and one of the modes
   coherent | ref_quirks | non-coherent (plain / creep re-aligned) | Doppler window | default schedule with stride
@@ -222,6 +222,9 @@ def plumbing_case(seed, rng, fs, fc, max_fo):
 def one(seed):
     rng = np.random.default_rng(50000 + seed)
     fs = float(rng.choice([rng.uniform(1.2e6, 4e6), rng.uniform(4e6, 10e6), rng.uniform(10e6, 20e6)]))
+    if os.environ.get("FUZZ_FS"):  # FUZZ_FS=lo,hi: sampling rates of one kernel instance only (5.25e6,5.5e6: k_corr<22, FOLD>)
+        lo, hi = (float(v) for v in os.environ["FUZZ_FS"].split(","))
+        fs = float(rng.uniform(lo, hi))
     fc = float(rng.uniform(0.0, 0.49 * fs))
     bin_hz = fs / 40000.0
     max_fo = float(rng.uniform(2 * bin_hz, min(60 * bin_hz, 25000.0)))
