@@ -175,10 +175,58 @@ template <int DIR> ACQ_HD void dft4(cf& a, cf& b, cf& c, cf& d) {
     d = sub_di<DIR>(amc, bmd);
 }
 
+// a + i s b  and  a - i s b  (s real, wave-uniform: its value in both halves of an SGPR pair): one packed FMA
+ACQ_HD cf fma_i(cf a, cf b, cf s) {
+#if ACQ_PK_ASM
+    cf r;  // (a.x - s b.y, a.y + s b.x)
+    asm("v_pk_fma_f32 %0, %1, %2, %3 op_sel:[1,0,0] op_sel_hi:[0,0,1] neg_lo:[1,0,0]" : "=v"(r) : "v"(b), "s"(s), "v"(a));
+    return r;
+#else
+    return mk(a.x - s.x * b.y, a.y + s.x * b.x);
+#endif
+}
+ACQ_HD cf fms_i(cf a, cf b, cf s) {
+#if ACQ_PK_ASM
+    cf r;  // (a.x + s b.y, a.y - s b.x)
+    asm("v_pk_fma_f32 %0, %1, %2, %3 op_sel:[1,0,0] op_sel_hi:[0,0,1] neg_hi:[1,0,0]" : "=v"(r) : "v"(b), "s"(s), "v"(a));
+    return r;
+#else
+    return mk(a.x + s.x * b.y, a.y - s.x * b.x);
+#endif
+}
+template <int DIR> ACQ_HD cf fma_di(cf a, cf b, cf s) { return DIR > 0 ? fma_i(a, b, s) : fms_i(a, b, s); }
+template <int DIR> ACQ_HD cf fms_di(cf a, cf b, cf s) { return DIR > 0 ? fms_i(a, b, s) : fma_i(a, b, s); }
+
+#ifndef ACQ_DFT5_FMA
+#define ACQ_DFT5_FMA 1  // -DACQ_DFT5_FMA=0: round 1-3's form of the five-point butterfly (18 packed instructions; A/B runs)
+#endif
+// Five-point butterfly.  With c1 = cos(2 pi/5), c2 = cos(4 pi/5), s1 = sin(2 pi/5), s2 = sin(4 pi/5):
+//   X0 = x0 + t1 + t2,  X1,4 = m1 +- i DIR sg1,  X2,3 = m2 +- i DIR sg2,
+//   m1 = x0 + c1 t1 + c2 t2,  m2 = x0 + c2 t1 + c1 t2,  sg1 = s1 t3 + s2 t4,  sg2 = s2 t3 - s1 t4.
+// Formed in 15 packed instructions, 9 of them FMAs (round 4; 18 before): the cosine part through u = t1 + t2, w = x0 + c2 u,
+// m1 = w + (c1 - c2) t1, m2 = w + (c1 - c2) t2 (5 instead of 6), the sine part scaled by 1/s1 -- sg1/s1 = t3 + (s2/s1) t4,
+// sg2/s1 = (s2/s1) t3 - t4 (2 instead of 4) -- with s1 restored inside the +-i add that forms the outputs (a packed FMA with
+// op_sel / neg modifiers instead of a packed add).
 template <int DIR> ACQ_HD void dft5(cf& x0, cf& x1, cf& x2, cf& x3, cf& x4) {
-    constexpr float C1 = 0.30901699437494745f, C2 = -0.8090169943749473f;
-    constexpr float S1 = 0.9510565162951535f, S2 = 0.5877852522924732f;
+    constexpr float C2 = -0.8090169943749473f, S1 = 0.9510565162951535f;
     cf t1 = x1 + x4, t2 = x2 + x3, t3 = x1 - x4, t4 = x2 - x3;
+#if ACQ_DFT5_FMA
+    constexpr float CD = 1.118033988749895f;   // c1 - c2 = sqrt(5)/2
+    constexpr float SR = 0.6180339887498949f;  // s2 / s1
+    const cf s1v = mk(S1, S1);
+    cf u = t1 + t2;
+    cf w = x0 + C2 * u;
+    x0 = x0 + u;
+    cf m1 = w + CD * t1;
+    cf m2 = w + CD * t2;
+    cf g1 = t3 + SR * t4;
+    cf g2 = SR * t3 - t4;
+    x1 = fma_di<DIR>(m1, g1, s1v);
+    x4 = fms_di<DIR>(m1, g1, s1v);
+    x2 = fma_di<DIR>(m2, g2, s1v);
+    x3 = fms_di<DIR>(m2, g2, s1v);
+#else
+    constexpr float C1 = 0.30901699437494745f, S2 = 0.5877852522924732f;
     cf m1 = x0 + C1 * t1 + C2 * t2;
     cf m2 = x0 + C2 * t1 + C1 * t2;
     cf s1 = S1 * t3 + S2 * t4;
@@ -188,6 +236,7 @@ template <int DIR> ACQ_HD void dft5(cf& x0, cf& x1, cf& x2, cf& x3, cf& x4) {
     x4 = sub_di<DIR>(m1, s1);
     x2 = add_di<DIR>(m2, s2);
     x3 = sub_di<DIR>(m2, s2);
+#endif
 }
 
 // forward value of W_8^m = exp(-2 pi i m / 8), m taken mod 8
