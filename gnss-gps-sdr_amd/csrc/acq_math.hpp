@@ -326,6 +326,55 @@ template <int M> ACQ_HD cf w25() {
                      : mk(-0.63742398974868952f, 0.77051324277578936f);
 }
 
+#ifndef ACQ_R25_TAN
+#define ACQ_R25_TAN 1  // -DACQ_R25_TAN=0: the radix-25's inner twiddles as 16 complex multiplies in front of plain butterflies (A/B runs)
+#endif
+// cos / sin of 2 pi m / 25 in double, for the compile-time constants of dft5_tw
+constexpr double w25cos(int m) {
+    return m == 1 ? 0.96858316112863108 : m == 2 ? 0.87630668004386358 : m == 3 ? 0.72896862742141155 : m == 4 ? 0.53582679497899655
+         : m == 6 ? 0.062790519529313527 : m == 8 ? -0.42577929156507272 : m == 9 ? -0.63742398974868975 : m == 12 ? -0.99211470131447776
+                                                                                                                    : -0.63742398974868952;  // 16
+}
+constexpr double w25sin(int m) {
+    return m == 1 ? 0.24868988716485479 : m == 2 ? 0.48175367410171532 : m == 3 ? 0.68454710592868862 : m == 4 ? 0.84432792550201508
+         : m == 6 ? 0.99802672842827156 : m == 8 ? 0.90482705246601947 : m == 9 ? 0.77051324277578925 : m == 12 ? 0.12533323356430454
+                                                                                                                  : -0.77051324277578936;  // 16
+}
+// Second-stage butterfly of the radix-25, inner twiddles included: the five-point transform of (x0, x1 w^1, x2 w^2, x3 w^3, x4 w^4)
+// with w^j = W_25^{K1 j} (conjugated for DIR > 0), in 19 packed instructions instead of 8 + 15.  A twiddle w = c (1 -+ i t), t = tan:
+// y_j = x_j -+ i t_j x_j is ONE packed FMA (fma_i / fms_i with both vector operands x_j) and leaves the real scale c_j pending; all
+// constants being known at compile time, the pending scales cost nothing in the butterfly -- every add of two differently scaled
+// terms was going to be an FMA or becomes one with the ratio of the scales as its constant:
+//   t1' = y1 + (c4/c1) y4, t3' = y1 - (c4/c1) y4 (= t1/c1, t3/c1);  t2' = y2 + (c3/c2) y3, t4' = y2 - (c3/c2) y3 (= t2/c2, t4/c2)
+//   u' = t1' + (c2/c1) t2';  X0 = x0 + c1 u';  w = x0 + (C2 c1) u';  m1 = w + (CD c1) t1';  m2 = w + (CD c2) t2'
+//   g1' = t3' + (SR c2/c1) t4';  g2' = (SR c1/c2) t3' - t4';  X1,4 = m1 +- i (S1 c1) g1';  X2,3 = m2 +- i (S1 c2) g2'
+// (C2, CD, SR, S1 as in dft5).  |t| <= 15.9 (m = 6): products stay within a few ulp of the plain form's (tests/emul, GPU parity).
+template <int DIR, int K1> ACQ_HD void dft5_tw(cf& x0, cf& x1, cf& x2, cf& x3, cf& x4) {
+    constexpr double c1 = w25cos(K1), c2 = w25cos(2 * K1), c3 = w25cos(3 * K1), c4 = w25cos(4 * K1);
+    constexpr double C2 = -0.8090169943749473, CD = 1.118033988749895, SR = 0.6180339887498949, S1 = 0.9510565162951535;
+    constexpr float T1 = (float)(w25sin(K1) / c1), T2 = (float)(w25sin(2 * K1) / c2), T3 = (float)(w25sin(3 * K1) / c3), T4 = (float)(w25sin(4 * K1) / c4);
+    constexpr float R14 = (float)(c4 / c1), R23 = (float)(c3 / c2), R21 = (float)(c2 / c1), K0 = (float)c1, KW = (float)(C2 * c1);
+    constexpr float KM1 = (float)(CD * c1), KM2 = (float)(CD * c2), KG1 = (float)(SR * c2 / c1), KG2 = (float)(SR * c1 / c2);
+    constexpr float KS1 = (float)(S1 * c1), KS2 = (float)(S1 * c2);
+    // forward: x w = c (x - i t x); backward: x conj(w) = c (x + i t x)
+    cf y1 = DIR < 0 ? fms_i(x1, x1, mk(T1, T1)) : fma_i(x1, x1, mk(T1, T1));
+    cf y2 = DIR < 0 ? fms_i(x2, x2, mk(T2, T2)) : fma_i(x2, x2, mk(T2, T2));
+    cf y3 = DIR < 0 ? fms_i(x3, x3, mk(T3, T3)) : fma_i(x3, x3, mk(T3, T3));
+    cf y4 = DIR < 0 ? fms_i(x4, x4, mk(T4, T4)) : fma_i(x4, x4, mk(T4, T4));
+    cf t1 = y1 + R14 * y4, t3 = y1 - R14 * y4, t2 = y2 + R23 * y3, t4 = y2 - R23 * y3;
+    cf u = t1 + R21 * t2;
+    cf w = x0 + KW * u;
+    x0 = x0 + K0 * u;
+    cf m1 = w + KM1 * t1;
+    cf m2 = w + KM2 * t2;
+    cf g1 = t3 + KG1 * t4;
+    cf g2 = KG2 * t3 - t4;
+    x1 = fma_di<DIR>(m1, g1, mk(KS1, KS1));
+    x4 = fms_di<DIR>(m1, g1, mk(KS1, KS1));
+    x2 = fma_di<DIR>(m2, g2, mk(KS2, KS2));
+    x3 = fms_di<DIR>(m2, g2, mk(KS2, KS2));
+}
+
 // 25 = 5 x 5 Cooley-Tukey butterfly: input n = 5 n1 + n2, output k = k1 + 5 k2.
 template <int DIR> ACQ_HD void radix25(const cf* x, cf* y) {
     cf v[5][5];  // v[k1][n2]
@@ -335,6 +384,17 @@ template <int DIR> ACQ_HD void radix25(const cf* x, cf* y) {
         dft5<DIR>(a, b, c, d, e);
         v[0][n2] = a; v[1][n2] = b; v[2][n2] = c; v[3][n2] = d; v[4][n2] = e;
     }
+#if ACQ_R25_TAN
+    dft5<DIR>(v[0][0], v[0][1], v[0][2], v[0][3], v[0][4]);
+    dft5_tw<DIR, 1>(v[1][0], v[1][1], v[1][2], v[1][3], v[1][4]);
+    dft5_tw<DIR, 2>(v[2][0], v[2][1], v[2][2], v[2][3], v[2][4]);
+    dft5_tw<DIR, 3>(v[3][0], v[3][1], v[3][2], v[3][3], v[3][4]);
+    dft5_tw<DIR, 4>(v[4][0], v[4][1], v[4][2], v[4][3], v[4][4]);
+#pragma unroll
+    for (int k1 = 0; k1 < 5; ++k1)
+#pragma unroll
+        for (int k2 = 0; k2 < 5; ++k2) y[k1 + 5 * k2] = v[k1][k2];
+#else
     v[1][1] = tw_u<DIR>(v[1][1], w25<1>());  v[1][2] = tw_u<DIR>(v[1][2], w25<2>());
     v[1][3] = tw_u<DIR>(v[1][3], w25<3>());  v[1][4] = tw_u<DIR>(v[1][4], w25<4>());
     v[2][1] = tw_u<DIR>(v[2][1], w25<2>());  v[2][2] = tw_u<DIR>(v[2][2], w25<4>());
@@ -349,6 +409,7 @@ template <int DIR> ACQ_HD void radix25(const cf* x, cf* y) {
 #pragma unroll
         for (int k2 = 0; k2 < 5; ++k2) y[k1 + 5 * k2] = v[k1][k2];
     }
+#endif
 }
 
 // ---------------------------------------------------------------------------------------
