@@ -15,6 +15,7 @@
 // are shared by all Doppler bins of a (block, PRN) pair and stay in the XCD's L2: cells of
 // one pair are mapped to one XCD.
 #include <hip/hip_runtime.h>
+#include <type_traits>
 
 #include <cstdlib>
 
@@ -193,6 +194,9 @@ __global__ __launch_bounds__(WG) void k_quirk_patch(QuirkArgs a) {
 // workgroups per CU).
 #ifndef ACQ_CORR_LAYOUT
 #define ACQ_CORR_LAYOUT LayC  // -DACQ_CORR_LAYOUT=LayB builds round 2's lane map for A/B runs (tools/build_variant.sh)
+#endif
+#ifndef ACQ_CORR_PEEL0
+#define ACQ_CORR_PEEL0 1  // the first sub-transform's outputs assigned to the accumulators instead of accumulated
 #endif
 #ifndef ACQ_CORR_FOLD22
 #define ACQ_CORR_FOLD22 true  // -DACQ_CORR_FOLD22=false: the 22-column coherent instance with round 3's rotation (A/B runs)
@@ -376,7 +380,8 @@ __global__ __launch_bounds__(WG, WPS) void k_corr(CorrArgs a) {
     }
     for (int k = 0; k < n_acc; ++k) {
         const cf* dk = dpp + (size_t)k * a.acc_step * a.sub * NPOLY * M_SUB;
-        for (int q = 0; q < NPOLY; ++q) {
+        // one sub-transform; `first` (a std::bool_constant): its outputs are the accumulators' first values
+        auto subtransform = [&](const int q, auto first) __attribute__((always_inline)) {
             cf b = mk(0.f, 0.f);
             cf wq_early[(!FOLD && MC <= 22) ? MC : 1];
             const cf* wqv = wq_early;
@@ -414,11 +419,20 @@ __global__ __launch_bounds__(WG, WPS) void k_corr(CorrArgs a) {
             ACQ_STAMP(3);
             __syncthreads();
             ACQ_STAMP(4);
-            if constexpr (FOLD) corr_phase3_fold<MC, L>(tid, rho, tqs, lds, acc);
-            else corr_phase3<MC, L>(tid, rho, b, wqv, lds, acc);
+            constexpr bool FIRST = decltype(first)::value;
+            if constexpr (FOLD) corr_phase3_fold<MC, L, FIRST>(tid, rho, tqs, lds, acc);
+            else corr_phase3<MC, L, FIRST>(tid, rho, b, wqv, lds, acc);
             ACQ_STAMP(5);
             __syncthreads();
             ACQ_STAMP(6);
+        };
+        // q = 0 carries unit factors (W^0): its iteration is peeled so that the radix-20 outputs land in the accumulators' registers
+        // (a branch inside the loop costs a register copy per column instead).  -DACQ_CORR_PEEL0=0: one loop (A/B runs)
+        if constexpr (ACQ_CORR_PEEL0) {
+            subtransform(0, std::true_type{});
+            for (int q = 1; q < NPOLY; ++q) subtransform(q, std::false_type{});
+        } else {
+            for (int q = 0; q < NPOLY; ++q) subtransform(q, std::false_type{});
         }
         if (NC && NCREG) corr_accumulate_power_reg<MC>(tid, acc, pw);
         else if (NC) {

@@ -141,11 +141,18 @@ ACQ_HD void corr_phase2_role(int role, int lane, const cf* t2, const cf* w25s, c
 // column of this pass, is a multiple of 20 so that column m0 + m reads radix-20 output m % 20):
 // W_N^{-q n} = conj(b) (per thread, b = bq[q][rho]) * conj(wqv[m]) (wave-uniform, wqv[m] = W_160^{q m}).
 // rho: the radix-20 butterfly this thread owns (pass3_rho<L>(tid); the kernels read LayC's table from device memory).
-template <int MC, class L = LayB>
+// FIRST (the sub-transform q = 0 of a block, peeled by the kernel): every factor is W^0 = (1, 0) exactly and the accumulators
+// start at zero, so acc[m] = y[m % 20] -- the rotation and the 2 MC accumulate FMAs are skipped, the same values result.
+template <int MC, class L = LayB, bool FIRST = false>
 ACQ_HD void corr_phase3(int tid, int rho, cf b, const cf* wqv, const cf* lds, cf* acc) {
     if (tid >= NBF3) return;
     cf y[RC];
     pass3_load<+1, L>(rho, lds, y);
+    if constexpr (FIRST) {
+#pragma unroll
+        for (int m = 0; m < MC; ++m) acc[m] = y[m % RC];
+        return;
+    }
 #pragma unroll
     for (int n = 0; n < RC; ++n) y[n] = cmulc(y[n], b);
     // The wave-uniform factors come as SGPR pairs (scalar loads from constant memory in the kernel).  More than ~14 columns
@@ -172,11 +179,16 @@ ACQ_HD void corr_phase3(int tid, int rho, cf b, const cf* wqv, const cf* lds, cf
 template <int MC> struct TqStride {  // even (16-byte reads), and {2 TQS alpha mod 64, alpha < 10} four banks apart
     static constexpr int value = MC <= 12 ? 14 : MC <= 22 ? 22 : MC <= 28 ? 30 : MC <= 33 ? 34 : 42;
 };
-template <int MC, class L = LayB>
+template <int MC, class L = LayB, bool FIRST = false>
 ACQ_HD void corr_phase3_fold(int tid, int rho, const cf* tqs, const cf* lds, cf* acc) {
     if (tid >= NBF3) return;
     cf y[RC];
     pass3_load<+1, L>(rho, lds, y);
+    if constexpr (FIRST) {  // q = 0: tqs holds (1, 0) throughout
+#pragma unroll
+        for (int m = 0; m < MC; ++m) acc[m] = y[m % RC];
+        return;
+    }
     const cf* wrow = tqs + (rho % RA) * TqStride<MC>::value;
     constexpr int CH = 8;  // factors fetched per chunk: 4 16-byte reads, 16 VGPRs (requesting a chunk ahead: 168 VGPRs, no gain)
 #pragma unroll

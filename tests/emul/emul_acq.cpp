@@ -171,11 +171,11 @@ static int emul_cell_l(const float* dspec, const float* cspec, int halo, int dop
                 cf* a = &acc[(size_t)tid * MC_MAX];
                 const int rho = pass3_rho<L>(tid < NBF3 ? tid : 0);
                 switch (mc) {
-                    case 12: if (!tid) fill(TqStride<12>::value); corr_phase3_fold<12, L>(tid, rho, tqs.data(), lds.data(), a); break;
-                    case 22: if (!tid) fill(TqStride<22>::value); corr_phase3_fold<22, L>(tid, rho, tqs.data(), lds.data(), a); break;
-                    case 28: if (!tid) fill(TqStride<28>::value); corr_phase3_fold<28, L>(tid, rho, tqs.data(), lds.data(), a); break;
-                    case 33: if (!tid) fill(TqStride<33>::value); corr_phase3_fold<33, L>(tid, rho, tqs.data(), lds.data(), a); break;
-                    case 40: if (!tid) fill(TqStride<40>::value); corr_phase3_fold<40, L>(tid, rho, tqs.data(), lds.data(), a); break;
+                    case 12: if (!tid) fill(TqStride<12>::value); if (q == 0) corr_phase3_fold<12, L, true>(tid, rho, tqs.data(), lds.data(), a); else corr_phase3_fold<12, L>(tid, rho, tqs.data(), lds.data(), a); break;
+                    case 22: if (!tid) fill(TqStride<22>::value); if (q == 0) corr_phase3_fold<22, L, true>(tid, rho, tqs.data(), lds.data(), a); else corr_phase3_fold<22, L>(tid, rho, tqs.data(), lds.data(), a); break;
+                    case 28: if (!tid) fill(TqStride<28>::value); if (q == 0) corr_phase3_fold<28, L, true>(tid, rho, tqs.data(), lds.data(), a); else corr_phase3_fold<28, L>(tid, rho, tqs.data(), lds.data(), a); break;
+                    case 33: if (!tid) fill(TqStride<33>::value); if (q == 0) corr_phase3_fold<33, L, true>(tid, rho, tqs.data(), lds.data(), a); else corr_phase3_fold<33, L>(tid, rho, tqs.data(), lds.data(), a); break;
+                    case 40: if (!tid) fill(TqStride<40>::value); if (q == 0) corr_phase3_fold<40, L, true>(tid, rho, tqs.data(), lds.data(), a); else corr_phase3_fold<40, L>(tid, rho, tqs.data(), lds.data(), a); break;
                     default: return -1;
                 }
             }
@@ -187,11 +187,11 @@ static int emul_cell_l(const float* dspec, const float* cspec, int halo, int dop
             const cf b = T.bq[(size_t)q * NBF3 + rho];
             const cf* wq = &T.wq[(size_t)q * WQ_STRIDE];
             switch (mc) {
-                case 12: corr_phase3<12, L>(tid, rho, b, wq, lds.data(), a); break;
-                case 22: corr_phase3<22, L>(tid, rho, b, wq, lds.data(), a); break;
-                case 28: corr_phase3<28, L>(tid, rho, b, wq, lds.data(), a); break;
-                case 33: corr_phase3<33, L>(tid, rho, b, wq, lds.data(), a); break;
-                case 40: corr_phase3<40, L>(tid, rho, b, wq, lds.data(), a); break;
+                case 12: if (q == 0) corr_phase3<12, L, true>(tid, rho, b, wq, lds.data(), a); else corr_phase3<12, L>(tid, rho, b, wq, lds.data(), a); break;
+                case 22: if (q == 0) corr_phase3<22, L, true>(tid, rho, b, wq, lds.data(), a); else corr_phase3<22, L>(tid, rho, b, wq, lds.data(), a); break;
+                case 28: if (q == 0) corr_phase3<28, L, true>(tid, rho, b, wq, lds.data(), a); else corr_phase3<28, L>(tid, rho, b, wq, lds.data(), a); break;
+                case 33: if (q == 0) corr_phase3<33, L, true>(tid, rho, b, wq, lds.data(), a); else corr_phase3<33, L>(tid, rho, b, wq, lds.data(), a); break;
+                case 40: if (q == 0) corr_phase3<40, L, true>(tid, rho, b, wq, lds.data(), a); else corr_phase3<40, L>(tid, rho, b, wq, lds.data(), a); break;
                 default: return -1;
             }
         }
