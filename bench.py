@@ -533,12 +533,19 @@ def main():
         import socket
         import torch.distributed as dist
         try:
-            if "MASTER_ADDR" not in os.environ or "MASTER_PORT" not in os.environ:
-                with socket.socket() as sk:
-                    sk.bind(("127.0.0.1", 0))
-                    os.environ["MASTER_PORT"] = str(sk.getsockname()[1])
-                os.environ["MASTER_ADDR"] = "127.0.0.1"
-            dist.init_process_group(backend="nccl", rank=0, world_size=1, device_id=torch.device("cuda", dev_index))
+            own_port = "MASTER_ADDR" not in os.environ or "MASTER_PORT" not in os.environ
+            for attempt in range(5):
+                if own_port:
+                    with socket.socket() as sk:
+                        sk.bind(("127.0.0.1", 0))
+                        os.environ["MASTER_PORT"] = str(sk.getsockname()[1])
+                    os.environ["MASTER_ADDR"] = "127.0.0.1"
+                try:
+                    dist.init_process_group(backend="nccl", rank=0, world_size=1, device_id=torch.device("cuda", dev_index))
+                    break
+                except Exception as ex:  # the port probed above can be taken again before the store binds it: pick another
+                    if not (own_port and attempt < 4 and ("EADDRINUSE" in str(ex) or "address already in use" in str(ex))):
+                        raise
             probe = torch.ones(1, dtype=torch.int64, device=torch.device("cuda", dev_index))
             dist.all_reduce(probe, op=dist.ReduceOp.MAX)  # the communicator is created lazily: bring it up before anything is timed
             torch.cuda.synchronize()
