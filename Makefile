@@ -24,7 +24,11 @@ $(LIBDIR)/libgpsacq.so: $(CSRC)/acq_kernels.hip $(CSRC)/key_kernels.hip $(CSRC)/
 	$(HIPCC) $(HIPFLAGS) -c $(CSRC)/gen_kernels.hip -o $(LIBDIR)/gen_kernels.o
 	$(HIPCC) --offload-arch=$(ARCH) -shared -fPIC -o $@ $(LIBDIR)/acq_kernels.o $(LIBDIR)/key_kernels.o $(LIBDIR)/iq_kernels.o $(LIBDIR)/gen_kernels.o $(LIBDIR)/gpsacq_engine.o $(LIBDIR)/gpsacq_multi.o -ldl -pthread
 
-host: $(LIBDIR)/libgps_search.so $(BINDIR)/gps_test $(BINDIR)/hip_floor
+host: $(LIBDIR)/libgps_search.so $(BINDIR)/gps_test $(BINDIR)/hip_floor $(BINDIR)/pk_fma_stream
+# measurement aid of bench.py's roofline: the rate of a pure v_pk_fma_f32 stream on this box (roofline.pk_fma_stream_TF)
+$(BINDIR)/pk_fma_stream: tools/ubench/pk_fma_stream.hip
+	@mkdir -p $(BINDIR)
+	$(HIPCC) --offload-arch=$(ARCH) -O2 -o $@ $<
 # measurement aid of bench.py's e2e_cli leg: the wall clock of a HIP process that does nothing (runtime start-up floor)
 $(BINDIR)/hip_floor: tools/ubench/hip_floor.hip
 	@mkdir -p $(BINDIR)
@@ -43,8 +47,10 @@ tests/emul/libemul_acq.so: tests/emul/emul_acq.cpp $(CSRC)/*.hpp
 	$(CLANGXX) -x c++ $(HOSTFLAGS) -shared -o $@ tests/emul/emul_acq.cpp
 
 # Drop-in check (authoring container only): the reference's own front end, compiled from where it lies and never copied,
-# linked against our SearchInit/SearchTask.  The binary goes to oracle/_ref/ (git-ignored; it travels to the GPU box, where
-# tests/test_gpu_parity.py::test_reference_main_against_our_library runs it).
+# linked against our SearchInit/SearchTask.  The binary goes to oracle/_ref/ (git-ignored).  It travels to the GPU box for ONE
+# consumer: tests/test_gpu_parity.py::test_reference_main_against_our_library, the only thing in the tree that opens it
+# (`grep -rn gps_test_refmain`: that test, this target) -- no product path, bench.py and smoke() never touch it.
+# It holds the reference's main() only (argument handling + the two calls); every search symbol it calls is ours.
 dropin-check: $(LIBDIR)/libgps_search.so
 	@mkdir -p oracle/_ref
 	$(CXX) -O2 -I/root/reference/c /root/reference/c/test_search_offline.cpp -o oracle/_ref/gps_test_refmain \

@@ -54,6 +54,7 @@ sys.path.insert(0, os.path.join(ROOT, "tests"))
 
 N_FFT = 40000
 FP32_VALU_PEAK_TF = 157.3        # MI355X_MICROARCH.md: peak FP32 vector (= FP32 MFMA) rate, dense
+FP32_PEAK_CLOCK_MHZ = 2400.0     # the clock that figure assumes: 256 CUs x 128 lanes x 2 flop x 2.4 GHz
 HBM_PEAK_GBS = 8000.0            # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec (6.29 TB/s measured copy)
 L2_PEAK_GBS = 34500.0            # MI355X_MICROARCH.md: aggregate L2 bandwidth
 ALG_BYTES_PER_CELL = 32 * N_FFT  # read signal + code spectra, write + read one IFFT intermediate
@@ -159,6 +160,178 @@ def soak(leg, cells_job, min_gpu_s=6.0, max_steps=2000):
             "note": "same step as the timed region, repeated after it; reported separately, `steps`/`ms_per_step`/`value` are the K timed steps"}
 
 
+def _drm_card(torch, dev_index):
+    """sysfs directory /sys/class/drm/cardN/device of the torch device (matched by PCI address when there are several)."""
+    import glob
+    cands = [d for d in sorted(glob.glob("/sys/class/drm/card[0-9]*/device")) if os.path.exists(os.path.join(d, "pp_dpm_sclk"))]
+    if len(cands) <= 1:
+        return cands[0] if cands else None
+    try:
+        pr = torch.cuda.get_device_properties(dev_index)
+        bdf = "%04x:%02x:%02x" % (pr.pci_domain_id, pr.pci_bus_id, pr.pci_device_id)
+        for d in cands:
+            if bdf in os.path.realpath(d):
+                return d
+    except Exception:
+        pass
+    return cands[min(dev_index, len(cands) - 1)]
+
+
+def read_clock_power(card):
+    """One reading of the shader clock (the level pp_dpm_sclk marks with '*' -- what rocm-smi --showclocks prints) and the package
+    power (hwmon, microwatts) straight from sysfs: a file read, cheap enough to repeat every 100 ms beside a timed leg."""
+    import glob
+    import re
+    out = {"sclk_mhz": None, "power_w": None}
+    try:
+        for ln in open(os.path.join(card, "pp_dpm_sclk")):
+            m = re.search(r"(\d+)\s*Mhz\s*\*", ln, re.I)
+            if m:
+                out["sclk_mhz"] = int(m.group(1))
+    except OSError:
+        pass
+    for name in ("power1_average", "power1_input"):
+        for f in glob.glob(os.path.join(card, "hwmon", "hwmon*", name)):
+            try:
+                out["power_w"] = float(open(f).read().strip()) * 1e-6
+                return out
+            except (OSError, ValueError):
+                pass
+    return out
+
+
+class ClockSampler:
+    """sclk / power readings every `period` seconds from a thread while a leg runs (sysfs; falls back to ONE rocm-smi call in
+    mid-leg when sysfs has no clock file).  stats(): medians over the readings taken between start() and stop()."""
+
+    def __init__(self, torch, dev_index, period=0.1):
+        import threading
+        self.card = _drm_card(torch, dev_index)
+        self.dev_index, self.period = dev_index, period
+        self.readings, self._stop, self._th = [], threading.Event(), None
+
+    def _loop(self):
+        if self.card is None:
+            if not self._stop.wait(0.3):
+                r = smi_sample(self.dev_index)
+                self.readings.append({"sclk_mhz": r.get("sclk_mhz"), "power_w": r.get("power_w"), "t": time.perf_counter()})
+            return
+        while not self._stop.wait(self.period):
+            r = read_clock_power(self.card)
+            r["t"] = time.perf_counter()
+            self.readings.append(r)
+
+    def start(self):
+        import threading
+        self.readings, self._stop = [], threading.Event()
+        self._th = threading.Thread(target=self._loop, daemon=True)
+        self.t0 = time.perf_counter()
+        self._th.start()
+
+    def stop(self):
+        self.t1 = time.perf_counter()
+        self._stop.set()
+        if self._th is not None:
+            self._th.join(timeout=30)
+
+    def stats(self):
+        inside = [r for r in self.readings if self.t0 <= r["t"] <= self.t1] or self.readings  # (a late rocm-smi reading: better than none)
+        clk = [r["sclk_mhz"] for r in inside if r.get("sclk_mhz")]
+        pw = [r["power_w"] for r in inside if r.get("power_w")]
+        return {"sclk_mhz": float(np.median(clk)) if clk else None, "power_w": float(np.median(pw)) if pw else None,
+                "sclk_mhz_min_max": [min(clk), max(clk)] if clk else None, "samples": len(inside),
+                "source": "sysfs pp_dpm_sclk / hwmon power1, every %.0f ms during the timed steps" % (1e3 * self.period) if self.card else "rocm-smi, one reading"}
+
+
+def pk_fma_stream(seconds=3.0):
+    """gnss-gps-sdr_amd/bin/pk_fma_stream (tools/ubench/pk_fma_stream.hip): the rate of a pure v_pk_fma_f32 stream at k_corr's
+    residency for `seconds` -- the practical ceiling of the fp32 vector pipe on this box under load.  Returns its JSON or {"error"}."""
+    import subprocess
+    exe = os.path.join(ROOT, "gnss-gps-sdr_amd", "bin", "pk_fma_stream")
+    if not os.path.exists(exe):
+        return {"error": "pk_fma_stream not built (make host)"}
+    try:
+        r = subprocess.run([exe, repr(seconds)], capture_output=True, text=True, timeout=60 + 2 * seconds)
+        for ln in r.stdout.splitlines():
+            if ln.startswith("{"):
+                return json.loads(ln)
+        return {"error": f"rc {r.returncode}: {(r.stderr or r.stdout)[-200:]}"}
+    except Exception as ex:
+        return {"error": str(ex)[:200]}
+
+
+PARITY_SNR_REL = 1e-4   # BASELINE.json north_star: correlator magnitudes within 1e-4 relative
+PARITY_PWR_REL = 2e-5   # what the GPU suite asserts per cell (tests/test_gpu_parity.py REL)
+PARITY_TIE_REL = 1e-5   # two candidates closer than this in the double-precision oracle are a float-rounding tie
+
+
+def parity_vs_gpu(cfg, eng, torch, d_bits, nblk, stride, gpu_peaks, cpu_peaks, host_bits, seed=5):
+    """The timed step's own results against the oracle (test infrastructure; c/search_offline.cpp:190-198,248), AFTER the timed
+    region: (1) the GPU's peak of every block the cpu_baseline leg pushed through the oracle's float build -- same capture, same
+    blocks, reference schedule block -> PRN block % 32 -- must carry the same ca_shift and lo_shift and an SNR within 1e-4; a
+    different (lo, ca) is accepted only as a PROVEN tie: in the double-precision oracle the two candidates' SNRs agree to 1e-5.
+    (2) three seeded random (block, PRN) rows of the WHOLE capture, all Doppler bins, cell by cell against liboracle_f64:
+    max_pwr / tot_pwr to 2e-5, the lag identical or a proven tie."""
+    import ctypes
+    from oracle_lib import CELL_DTYPE, PEAK_DTYPE, Oracle, _p
+    n = min(len(cpu_peaks), len(gpu_peaks))
+    g, o = gpu_peaks[:n], cpu_peaks[:n]
+    orc = Oracle(cfg["fc"], cfg["fs"], cfg["max_fo"], kind="f64")
+    S, dmax = orc.num_lags, orc.dmax
+
+    def lag_powers(block_bytes, sv, lo):
+        orc.L.oracle_sample(orc.h, _p(np.ascontiguousarray(block_bytes)))
+        pw = np.zeros(S, np.float32)
+        orc.L.oracle_cell_power(orc.h, sv, int(lo), _p(pw))
+        return pw
+
+    ca_eq, lo_eq = g["ca_shift"] == o["ca_shift"], g["lo_shift"] == o["lo_shift"]
+    ties, unproven = 0, []
+    for b in np.nonzero(~(ca_eq & lo_eq))[0]:
+        blk = np.frombuffer(host_bits, dtype=np.uint8)[b * 5120:(b + 1) * 5120]
+        snr2 = []
+        for pk in (g[b], o[b]):
+            pw = lag_powers(blk, int(b) % 32, pk["lo_shift"])
+            snr2.append(float(pw[pk["ca_shift"]]) / (float(pw.sum(dtype=np.float64)) / S))
+        if abs(snr2[0] - snr2[1]) <= PARITY_TIE_REL * snr2[1]:
+            ties += 1
+        else:
+            unproven.append(int(b))
+    with np.errstate(divide="ignore", invalid="ignore"):
+        snr_rel = np.abs(g["snr"].astype(np.float64) / o["snr"].astype(np.float64) - 1.0)
+    snr_max_rel = float(np.nanmax(snr_rel)) if n else 0.0
+    # (2) full rows of cells: GPU cells of three tasks through the same C ABI, device-resident capture
+    rng = np.random.default_rng(seed)
+    rows = sorted(int(b) for b in rng.choice(nblk, size=min(3, nblk), replace=False))
+    dev = d_bits.device
+    tasks = torch.tensor([[b, b % 32] for b in rows], dtype=torch.int32, device=dev)
+    d_cells = torch.zeros((len(rows), eng.num_doppler, 4), dtype=torch.int32, device=dev)
+    d_pk = torch.zeros((len(rows), 4), dtype=torch.int32, device=dev)
+    eng.search_device(d_bits.data_ptr(), nblk, d_pk.data_ptr(), stride=stride, d_tasks_ptr=tasks.data_ptr(), n_tasks=len(rows),
+                      d_cells_ptr=d_cells.data_ptr(), sync=True)
+    gc = d_cells.cpu().numpy().view(CELL_DTYPE).reshape(len(rows), eng.num_doppler)
+    pwr_max_rel, lag_ties, lag_bad, cells = 0.0, 0, [], 0
+    for r, b in enumerate(rows):
+        blk = d_bits[b * stride:b * stride + 5120].cpu().numpy()
+        oc, _ = orc.search_block(blk, b % 32)
+        cells += oc.size
+        pwr_max_rel = max(pwr_max_rel, float(np.max(np.abs(gc[r]["max_pwr"] / oc["max_pwr"] - 1.0))), float(np.max(np.abs(gc[r]["tot_pwr"] / oc["tot_pwr"] - 1.0))))
+        for d in np.nonzero(gc[r]["max_i"] != oc["max_i"])[0]:
+            pw = lag_powers(blk, b % 32, int(d) - dmax)
+            a, c = float(pw[gc[r]["max_i"][d]]), float(pw[oc["max_i"][d]])
+            if abs(a - c) <= PARITY_TIE_REL * c:
+                lag_ties += 1
+            else:
+                lag_bad.append([int(b), int(d) - dmax])
+    ok = (not unproven) and snr_max_rel <= PARITY_SNR_REL and pwr_max_rel <= PARITY_PWR_REL and not lag_bad
+    return {"ok": bool(ok), "blocks": int(n), "ca_equal": int(ca_eq.sum()), "lo_equal": int(lo_eq.sum()), "proven_ties": ties,
+            "unproven_mismatches": unproven[:8], "snr_max_rel": snr_max_rel, "cells": int(cells), "cell_rows_block_prn": [[b, b % 32] for b in rows],
+            "pwr_max_rel": pwr_max_rel, "cell_lag_ties": lag_ties, "cell_lag_mismatches": lag_bad[:8],
+            "tolerances": {"snr_rel": PARITY_SNR_REL, "pwr_rel": PARITY_PWR_REL, "tie_rel": PARITY_TIE_REL},
+            "what": "GPU peaks of the LAST TIMED STEP vs the oracle's float build on the blocks the cpu_baseline leg searched (ca_shift / lo_shift equal "
+                    "or a tie proven in the double-precision oracle, SNR to 1e-4) + 3 random full rows of cells vs liboracle_f64 (2e-5)"}
+
+
 def live_traffic(argv_tail, timeout_s=150):
     """HBM bytes of one k_corr launch measured IN THIS RUN: two short child runs of this file under `rocprofv3 --pmc FETCH_SIZE`
     and `--pmc WRITE_SIZE` (separate passes, as /opt/skills/guides/MI355X_MICROARCH.md prescribes; no trace domains beside
@@ -211,8 +384,9 @@ def cpu_baseline(cfg, bits, ndop, target_s=12.0):
     dt = time.perf_counter() - t0
     nblk = int(max(2, min(len(bits) // 5120, target_s / (dt / 2))))
     t0 = time.perf_counter()
-    cells, _ = orc.bench_blocks(bits[:nblk * 5120], nblk)
+    cells, peaks = orc.bench_blocks(bits[:nblk * 5120], nblk)
     dt = time.perf_counter() - t0
+    cpu_baseline.last_peaks = peaks  # the checker's answers for exactly these blocks: parity_vs_gpu compares the timed step's with them
     return {"value": cells / dt, "unit": "cells/s", "cores": 1, "kind": "port",
             "sample": f"{nblk} blocks x {ndop} bins = {cells} cells of the same capture, oracle f32 build (own FFT, -O3), "
                       f"{dt:.1f} s on {os.cpu_count()} core host ({cpu_model()}), 1 thread",
@@ -343,6 +517,10 @@ class Leg:
         # stream, ordered after it by an event, so step i's reduction / all-reduce overlaps step i+1's search
         # (two peak buffers; the engine stream waits for a buffer's previous reader).
         self.d_peaks = [torch.zeros((max(n_tasks, 1), 4), dtype=torch.int32, device=dev) for _ in range(2)]
+        # the merge keys (gpsacq_peak_keys_device: one launch on the engine's stream right behind the search): 32 per-PRN best keys
+        # on the block schedule, one per task on the grid; a rank without work keeps zeros (neutral for MAX)
+        self.d_keys = [torch.zeros(n_keys, dtype=torch.int64, device=dev) for _ in range(2)]
+        self.sampler = None  # ClockSampler: sclk / power readings during the timed steps of run()
         self.eng_stream = torch.cuda.ExternalStream(eng.stream_ptr, device=dev)
         self.reader_done = [None, None]
         self.step_no = 0
@@ -351,7 +529,7 @@ class Leg:
         torch, eng = self.torch, self.eng
         slot = self.step_no & 1
         self.step_no += 1
-        buf = self.d_peaks[slot]
+        buf, best = self.d_peaks[slot], self.d_keys[slot]
         if self.n_tasks > 0:
             if self.reader_done[slot] is not None:
                 self.eng_stream.wait_event(self.reader_done[slot])
@@ -361,24 +539,20 @@ class Leg:
                 eng.search_device(self.d_bits.data_ptr(), self.nblk, buf.data_ptr(), stride=self.stride,
                                   d_tasks_ptr=self.d_tasks.data_ptr() if self.d_tasks is not None else None,
                                   n_tasks=self.n_tasks, sync=False)
+            # best peak per PRN (block schedule) / per (block, PRN) (grid), packed so that integer MAX reproduces the reference's
+            # ordering (higher SNR; ties -> lower Doppler bin, :198): made by the library, one launch on the engine's stream
+            eng.peak_keys_device(buf.data_ptr(), self.n_tasks, best.data_ptr(), per_prn=not self.grid, sync=False)
             searched = torch.cuda.Event()
             searched.record(self.eng_stream)
             torch.cuda.current_stream().wait_event(searched)
-        # best peak per PRN (block schedule) / per (block, PRN) (grid), packed so that integer MAX reproduces
-        # the reference's ordering (higher SNR; ties -> lower Doppler bin, :198)
         # (a rank without work -- more ranks than runs / grid points -- contributes keys of 0, neutral for MAX)
-        if self.n_tasks > 0:
-            key = self.gdist.pack_keys(buf[:self.n_tasks], eng.kmax)
-            best = key if self.grid else self.gdist.per_prn_best(key)
-        else:
-            best = torch.zeros(self.n_keys, dtype=torch.int64, device=self.dev)
         if self.dist is not None:
             if self.backend == "nccl":
                 self.dist.all_reduce(best, op=self.dist.ReduceOp.MAX)  # RCCL over xGMI, 256 bytes
             else:
                 b = best.cpu()
                 self.dist.all_reduce(b, op=self.dist.ReduceOp.MAX)
-                best = b.to(self.dev)
+                best.copy_(b)
         self.reader_done[slot] = torch.cuda.Event()
         self.reader_done[slot].record(torch.cuda.current_stream())
         return best
@@ -399,6 +573,8 @@ class Leg:
             best = self.step()
         self.fence()
         corr_ms, self.sample_ms = [], []
+        if self.sampler is not None:
+            self.sampler.start()
         t0 = time.perf_counter()
         for i in range(steps):
             best = self.step()
@@ -412,10 +588,12 @@ class Leg:
             self.sample_ms.append(tm["ms_sample"])
         self.fence()
         elapsed = time.perf_counter() - t0
+        if self.sampler is not None:
+            self.sampler.stop()
         t = torch.tensor([elapsed], dtype=torch.float64, device=self.dev if self.backend == "nccl" else "cpu")
         if self.dist is not None:
             self.dist.all_reduce(t, op=self.dist.ReduceOp.MAX)
-        return float(t.item()), (float(np.mean(corr_ms)) if corr_ms else 0.0), best
+        return float(t.item()), (float(np.mean(corr_ms)) if corr_ms else 0.0), (best.clone() if best is not None else None)
 
 
 _REAL_STDOUT = None
@@ -462,9 +640,13 @@ def main():
     ap.add_argument("--no-dist", action="store_true", help="N = 1: do not create the one-rank nccl process group")
     ap.add_argument("--force-dist", action="store_true", help="N = 1: the one-rank nccl group must come up (no fallback)")
     ap.add_argument("--soak-seconds", type=float, default=6.0, help="GPU time of the soak leg after the timed steps (0: skip)")
-    ap.add_argument("--live-traffic", action="store_true", help="measure roofline.traffic in this run even with --no-cpu-baseline")
+    ap.add_argument("--live-traffic", action="store_true", help="(kept for old command lines: live traffic is on unless --no-live-traffic)")
     ap.add_argument("--no-live-traffic", action="store_true",
                     help="do not measure roofline.traffic in this run (two short rocprofv3 --pmc child runs); use profiles/traffic.json")
+    ap.add_argument("--parity-selftest", action="store_true",
+                    help="corrupt one GPU peak (ca_shift + 1) before cpu_baseline.parity_vs_gpu compares: the run must then exit 3 (tests)")
+    ap.add_argument("--pk-fma-seconds", type=float, default=3.0,
+                    help="N = 1, untimed part: seconds of the pure v_pk_fma_f32 stream that gives roofline.pk_fma_stream_TF (0: skip)")
     ap.add_argument("--no-e2e", action="store_true", help="skip the gps_test end-to-end leg")
     ap.add_argument("--spawn-check", action="store_true",
                     help="launcher check without a GPU: every rank joins a gloo group, rank 0 prints the ranks it saw, all exit")
@@ -693,8 +875,17 @@ def main():
 
     leg = Leg(torch, gpsacq, gdist, eng, dev, dist, backend, nblk, n_tasks, d_bits, d_tasks, stride, grid,
               n_keys=(tasks.shape[0] if grid else 32), iq=iq_in)
+    if rank == 0:
+        leg.sampler = ClockSampler(torch, dev_index)  # sclk / power during the K timed steps (roofline.sclk_mhz, .power_w)
     elapsed, kern_ms, best = leg.run(args.steps, args.warmup)
     timing = eng.last_timing() if n_tasks > 0 else None
+    clock = leg.sampler.stats() if leg.sampler is not None else None
+    leg.sampler = None
+    # the peaks of the LAST TIMED STEP, kept for the parity verdict (cpu_baseline.parity_vs_gpu) before any other leg runs
+    gpu_peaks = None
+    if rank == 0 and world == 1 and not grid and not iq8 and n_tasks > 0 and not args.no_cpu_baseline:
+        from oracle_lib import PEAK_DTYPE as _PK
+        gpu_peaks = leg.d_peaks[(leg.step_no - 1) & 1][:min(n_tasks, 1024)].cpu().numpy().view(_PK).reshape(-1)
 
     soak_leg = None
     if args.soak_seconds > 0 and world == 1 and n_tasks > 0:
@@ -715,6 +906,24 @@ def main():
                  "note": "one GPU running the largest per-rank share of the capture at N = 8 (same step, one-rank all-reduce included); "
                          "a prediction, not a measurement of 8 GPUs"}
 
+    # What the one-rank process group costs the N = 1 line (rounds stay comparable): the same step without it, a few times
+    no_coll = None
+    if world == 1 and dist is not None and n_tasks > 0 and args.soak_seconds > 0:
+        nleg = Leg(torch, gpsacq, gdist, eng, dev, None, backend, nblk, n_tasks, d_bits, d_tasks, stride, grid,
+                   n_keys=(tasks.shape[0] if grid else 32), iq=iq_in)
+        n_el, n_kern, _ = nleg.run(max(10, args.steps // 2), 2)
+        no_coll = {"ms_per_step_without_process_group": 1e3 * n_el / max(10, args.steps // 2), "kernel_ms": n_kern,
+                   "ms_per_step_with": 1e3 * elapsed / args.steps}
+    # the fp32 vector pipe's own ceiling on this box, a few seconds under load (untimed)
+    pk_stream, pk_clock = None, None
+    if rank == 0 and world == 1 and args.pk_fma_seconds > 0 and args.soak_seconds > 0:
+        leg.fence()
+        smp = ClockSampler(torch, dev_index)
+        smp.start()
+        pk_stream = pk_fma_stream(args.pk_fma_seconds)
+        smp.stop()
+        pk_clock = smp.stats()
+
     weak = None
     if iq8:
         weak_blocks = 0
@@ -727,6 +936,7 @@ def main():
                 "ms_per_step": 1e3 * w_elapsed / args.steps, "kernel_ms": w_kern_ms,
                 "kernel_cells_per_s": w_cells / (w_kern_ms * 1e-3) if w_kern_ms else None}
 
+    parity_failed = False
     if rank == 0:
         value = cells_job * args.steps / elapsed
         fl = flops_per_cell(eng.num_lags)
@@ -742,20 +952,26 @@ def main():
         except Exception:
             pass
         traffic_live = None
-        if (world == 1 and not args.no_live_traffic and (args.live_traffic or not args.no_cpu_baseline) and args.config == 1 and not iq8 and not args.capture
+        if (world == 1 and not args.no_live_traffic and args.config == 1 and not iq8 and not args.capture
                 and not any(k.startswith(("ROCP_", "ROCPROF")) for k in os.environ) and "rocprof" not in os.environ.get("LD_PRELOAD", "")):  # not under a profiler already
             # the default line: counters collected on THIS box, in this run (same capture size: the child generates the same data)
             traffic_live = live_traffic(["--blocks-total", str(args.blocks_total)])
             if "error" not in traffic_live:
                 traffic = traffic_live["read_bytes"] + traffic_live["write_bytes"]
-                traffic_src = ("measured in this run: rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE (separate child runs of this command, "
-                               "2 steps each), per k_corr launch; FETCH_SIZE KiB x 1024 x 2 (gfx950 correction), WRITE_SIZE KiB x 1024")
+                traffic_src = ("live (estimated correction): rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE (separate child runs of this command, "
+                               "2 steps each), per k_corr launch; FETCH_SIZE KiB x 1024 x 2 (the guide's gfx950 correction for wide reads), WRITE_SIZE KiB x 1024 (uncalibrated)")
         sha_now = kernel_source_sha()
         # counters belong to the kernel binary they were collected on: flagged when the sources changed since (or the
         # profile predates the hash), or when this run's kernel instance is not the profiled one
         live_ok = traffic_live is not None and "error" not in traffic_live
         traffic_stale = False if live_ok else ((traffic is not None) and (traffic_sha != sha_now or args.config not in (1, 4) or iq8))
         alg_gbs = cells_rank * ALG_BYTES_PER_CELL / (kern_ms * 1e-3) / 1e9 if kern_ms else 0.0
+        # Box-independent forms of the same measurement (the pool's boxes hold 2.09-2.20 GHz under this kernel): cycles one CU
+        # spends per cell at the clock read DURING the timed steps, and the fraction of the peak at that clock (157.3 TFLOP/s = 2.4 GHz).
+        sclk = clock["sclk_mhz"] if clock else None
+        cyc_cell_cu = (kern_ms * 1e-3 * sclk * 1e6 * eng.compute_units / cells_rank) if (sclk and kern_ms and cells_rank) else None
+        frac_at_clock = (achieved_tf / (FP32_VALU_PEAK_TF * sclk / FP32_PEAK_CLOCK_MHZ)) if (sclk and achieved_tf) else None
+        pk_tf = pk_stream.get("pk_fma_stream_TF") if pk_stream else None
         out = {
             "metric": "(PRN,Doppler) correlation cells/s, 32 PRN @ fs=5.456 MHz" if args.config in (1, 4) else
                       f"(PRN,Doppler) correlation cells/s, 32 PRN @ fs={fs / 1e6:.3f} MHz",
@@ -785,6 +1001,13 @@ def main():
                          "flops_per_cell": fl, "flops_definition": "SURVEY.md 8(d): 6N + 5N log2 N + 5S",
                          "kernel_ms": kern_ms, "cells_per_launch": cells_rank,
                          "kernel_cells_per_s": cells_rank / (kern_ms * 1e-3) if kern_ms else None,
+                         # clock / power read during the K timed steps; cycles = kernel_ms x sclk x CUs / cells
+                         "sclk_mhz": sclk, "power_w": clock["power_w"] if clock else None, "compute_units": eng.compute_units,
+                         "cycles_per_cell_per_cu": cyc_cell_cu, "frac_at_clock": frac_at_clock, "peak_clock_mhz": FP32_PEAK_CLOCK_MHZ,
+                         # a pure v_pk_fma_f32 stream on this box (3 waves per SIMD like k_corr, a few seconds): the pipe's practical ceiling
+                         "pk_fma_stream_TF": pk_tf, "frac_of_pk_fma_stream": (achieved_tf / pk_tf) if pk_tf else None,
+                         "pk_fma_stream_sclk_mhz": pk_clock["sclk_mhz"] if pk_clock else None,
+                         "clock_sampling": clock, "pk_fma_stream": pk_stream,
                          "traffic": traffic, "traffic_source": traffic_src, "traffic_stale": traffic_stale, "traffic_live": traffic_live,
                          "kernel_source_sha": sha_now, "traffic_kernel_source_sha": traffic_sha,
                          "hbm_secondary": {"algorithmic_bytes_per_cell": ALG_BYTES_PER_CELL, "algorithmic_GBs": alg_gbs,
@@ -797,6 +1020,14 @@ def main():
             "stage_ms": {k: timing[k] for k in ("ms_total", "ms_sample", "ms_correlate", "ms_peaks")} if timing else None,
             "device": eng.device_name,
         }
+        # which optional legs ran beside the K timed steps (none of them inside the timed region), so lines of different rounds
+        # / command lines can be told apart; `one_rank_collective`: what the one-rank nccl group costs the N = 1 step
+        out["extras"] = {"one_rank_process_group": dist is not None and world == 1, "soak": soak_leg is not None, "strong_share_at_8": share is not None,
+                         "weak_scaling": weak is not None, "live_traffic": traffic_live is not None, "pk_fma_stream": pk_stream is not None,
+                         "cpu_baseline": world == 1 and not args.no_cpu_baseline, "e2e_cli": world == 1 and not args.no_e2e,
+                         "keys": "gpsacq_peak_keys_device (library, engine stream)"}
+        if no_coll is not None:
+            out["one_rank_collective"] = no_coll
         if soak_leg is not None:
             out["soak"] = soak_leg
         if share is not None:
@@ -830,6 +1061,23 @@ def main():
                 out["cpu_baseline"] = ref or port
                 if ref:
                     out["cpu_baseline_port"] = port
+                # the line's own parity verdict at the configuration it measures: the timed step's peaks vs the oracle's, same blocks
+                if gpu_peaks is not None:
+                    if args.parity_selftest:
+                        gpu_peaks = gpu_peaks.copy()
+                        i_bad = min(7, len(gpu_peaks) - 1)
+                        gpu_peaks["ca_shift"][i_bad] = (gpu_peaks["ca_shift"][i_bad] + 1) % eng.num_lags
+                    try:
+                        par = parity_vs_gpu(cfg, eng, torch, d_bits, nblk, stride, gpu_peaks, cpu_baseline.last_peaks, host_bits)
+                    except Exception as ex:
+                        par = {"ok": False, "error": str(ex)[:300]}
+                    cb = out["cpu_baseline"]
+                    cb["parity_vs_gpu"] = par
+                    # (flat copies: a consumer that keeps scalars only still sees the verdict)
+                    cb.update({"parity_ok": par.get("ok"), "parity_blocks": par.get("blocks"), "parity_cells": par.get("cells"),
+                               "parity_ca_equal": par.get("ca_equal"), "parity_lo_equal": par.get("lo_equal"), "parity_proven_ties": par.get("proven_ties"),
+                               "parity_snr_max_rel": par.get("snr_max_rel"), "parity_pwr_max_rel": par.get("pwr_max_rel")})
+                    parity_failed = not par.get("ok")
                 try:
                     out["cpu_baseline_all_cores"] = cpu_baseline_all_cores(cfg, host_bits, ndop, port["value"])
                 except Exception as ex:  # the 1-thread figure is the contract; this one is informative
@@ -843,6 +1091,9 @@ def main():
         emit(json.dumps(out))
     if dist is not None:
         dist.destroy_process_group()
+    if parity_failed:  # the line is out (with the details); a GPU result the oracle contradicts is not a benchmark result
+        print("bench.py: the timed step's results DISAGREE with the oracle (cpu_baseline.parity_vs_gpu)", file=sys.stderr)
+        raise SystemExit(3)
 
 
 if __name__ == "__main__":

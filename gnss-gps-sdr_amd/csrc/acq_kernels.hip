@@ -412,6 +412,14 @@ __global__ __launch_bounds__(WG, WPS) void k_corr(CorrArgs a) {
             corr_phase1<NB, W1H, L>(tid, q, dop, dk, cpp, a.crow, a.halo, w1, lds);
             ACQ_PHASE1_PRIO(0);
             ACQ_STAMP(1);  // inputs loaded and multiplied, pass 1, its LDS stores drained (the stamp waits on lgkmcnt)
+#if defined(__HIP_DEVICE_COMPILE__)
+            // FOLD: the table image written by this wave's LDS-DMA must have landed before the barrier lets another wave's pass 2
+            // read it.  The barrier itself does not wait for vector-memory operations, and the only thing that made every wave
+            // drain its vmcnt here was that the phase-1 loads (issued after the DMA, returned in order) are consumed above -- a
+            // property of today's schedule, not of the source.  The wait is spelled out (it is free: the loads are consumed
+            // already) and tools/isa_census.py --assert-dma-wait checks that it is in the ISA.
+            if constexpr (FOLD) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#endif
             __syncthreads();  // also orders the t2s fill before its first use
             ACQ_STAMP(2);
             if constexpr (ROT) corr_phase2_role<L>((my_wave + q) & 3, tid & 63, t2s, w25s, lds);

@@ -180,6 +180,11 @@ enum FwdKind { FWD_REAL, FWD_BITS, FWD_IQ8, FWD_REALMIX };
 static int run_forward(gpsacq_engine* e, FwdKind kind, const void* src, size_t src_stride, size_t n_src, cf* out,
                        size_t item_stride, long row, int off, bool conj_out, int sub_override = 0, const Capture* cap = nullptr) {
     const int sub = (kind == FWD_REAL || kind == FWD_REALMIX) ? 1 : (sub_override > 0 ? sub_override : e->sub);
+    // k_fwd2 (the 1-bit / 8-bit IQ kernels) runs the backward transform on conjugated inputs: the conjugated spectrum is the
+    // only one it can write.  Every caller wants that one (Correlate() multiplies by conj(data), :183-184; the parity probe
+    // un-conjugates on the host); a future caller asking for the plain spectrum gets an error, not the wrong sign.
+    if ((kind == FWD_BITS || kind == FWD_IQ8) && !conj_out)
+        return fail(GPSACQ_ERR_UNSUPPORTED, "run_forward: the 1-bit / IQ forward kernels write the conjugated spectrum only");
     const size_t chunk = kFwdChunk / (size_t)sub;  // sources per launch
     for (size_t base = 0; base < n_src; base += chunk) {  // grid.y bound
         const size_t cnt = std::min(chunk, n_src - base) * (size_t)sub;
@@ -510,8 +515,8 @@ static int prepare_tasks(gpsacq_engine* e, const gpsacq_task* h_tasks, const voi
         if (quirks) launch_patches(e, (n_tasks + GPSACQ_NUM_SATS - 1) / GPSACQ_NUM_SATS, d_bits, stride);
         return GPSACQ_OK;
     }
+    e->sched_valid = false;  // before grow(): a failed reallocation must not leave a cached schedule pointing at freed memory
     if (int rc = grow(e->d_tasks, e->task_cap, n_tasks, e->stream)) return rc;
-    e->sched_valid = false;
     std::vector<gpsacq_task> tmp;
     if (!h_tasks && d_user_tasks) {
         if (!quirks) {  // same layout: {block, prn} == {spec, code}
@@ -948,8 +953,8 @@ extern "C" int gpsacq_reserve(gpsacq_engine* e, size_t n_blocks) {
         if (!(e->sched_valid && n_blocks <= e->sched_tasks))
             if (int rc = build_default_schedule(e, n_blocks)) return rc;
     } else {
+        e->sched_valid = false;  // (never valid in the non-coherent mode; the buffer may be about to move)
         if (int rc = grow(e->d_tasks, e->task_cap, n_blocks, e->stream)) return rc;
-        e->sched_valid = false;  // (never valid in the non-coherent mode; the buffer may just have moved)
     }
     return GPSACQ_OK;
 }
@@ -1036,6 +1041,19 @@ extern "C" int gpsacq_synchronize(gpsacq_engine* e) {
     if (!e) return fail(GPSACQ_ERR_ARG, "gpsacq_synchronize: null engine");
     HIPCHK(hipSetDevice(e->p.device));
     HIPCHK(hipStreamSynchronize(e->stream));
+    return GPSACQ_OK;
+}
+
+// Merge keys of a finished (or enqueued) device search, on the engine's stream: bench.py's / a multi-process caller's step is
+// then one search + this + one all-reduce(MAX), with nothing of it on another stream or in another framework's kernels.
+extern "C" int gpsacq_peak_keys_device(gpsacq_engine* e, const void* d_peaks, size_t n_peaks, int per_prn, void* d_keys, int sync) {
+    if (!e || !d_keys || (!d_peaks && n_peaks > 0)) return fail(GPSACQ_ERR_ARG, "gpsacq_peak_keys_device: null argument");
+    if (n_peaks > 0x7fffffffu) return fail(GPSACQ_ERR_ARG, "gpsacq_peak_keys_device: %zu peaks", n_peaks);
+    HIPCHK(hipSetDevice(e->p.device));
+    if (per_prn) launch_prn_keys((const Peak*)d_peaks, (int)n_peaks, e->kmax, (unsigned long long*)d_keys, e->stream);
+    else if (n_peaks > 0) launch_pack_keys((const Peak*)d_peaks, (unsigned long long*)d_keys, (int)n_peaks, e->kmax, e->stream);
+    HIPCHK(hipGetLastError());
+    if (sync) HIPCHK(hipStreamSynchronize(e->stream));
     return GPSACQ_OK;
 }
 

@@ -14,8 +14,9 @@
 // the very calls an 8-GPU node makes, executed on the one-GPU box (tests/test_gpu_round4.py::test_rccl_single_rank_*).
 //
 // The caller's thread is not the critical path: each engine's share of a call -- staging copy of its part of the (pageable)
-// capture into its own pinned buffer, upload, search, key packing, download of its peaks into pinned memory -- is enqueued by
-// its own host thread, so device i + 1 is searching while device i's copy is still running (round 3 did all of it on one
+// capture into its own pinned buffer (block decomposition; the grid decomposition, where every engine needs the whole capture,
+// stages it once in one portable pinned buffer), upload, search, key packing, download of its peaks into pinned memory -- is
+// enqueued by its own host thread, so device i + 1 is searching while device i's copy is still running (round 3 did all of it on one
 // thread through pageable hipMemcpyAsync, which blocks: every device waited for the ones before it).  gpsacq_multi_last_call_ms
 // reports how long the enqueue phase of the last call took on the host next to the whole call.
 //
@@ -117,6 +118,10 @@ struct gpsacq_multi {
     std::vector<size_t> h_bits_cap;
     std::vector<Peak*> h_peaks;
     std::vector<size_t> h_peaks_cap;
+    // grid decomposition: every engine uploads the SAME capture and task list -- staged once, in one pinned buffer that every
+    // device can read (hipHostMallocPortable), not once per engine
+    uint8_t* h_shared = nullptr;
+    size_t h_shared_cap = 0;
     bool force_rccl = false;         // GPSACQ_MULTI_FORCE_RCCL=1: communicator + all-reduce even with one distinct GPU
     long rccl_allreduces = 0;        // ncclAllReduce calls issued so far (all ranks of a group count once)
     double last_enqueue_ms = 0, last_total_ms = 0;
@@ -145,6 +150,7 @@ extern "C" void gpsacq_multi_destroy(gpsacq_multi* m) {
         if (m->h_peaks[i]) (void)hipHostFree(m->h_peaks[i]);
         gpsacq_destroy(m->eng[i]);
     }
+    if (m->h_shared) (void)hipHostFree(m->h_shared);
     delete m;
 }
 
@@ -427,6 +433,19 @@ static int search_grid_impl(gpsacq_multi* m, const uint8_t* bits, size_t n_block
     const size_t n = m->eng.size();
     const size_t nbytes = (n_blocks - 1) * stride + (stride < (size_t)GPSACQ_BLOCK_BYTES ? stride : (size_t)GPSACQ_BLOCK_BYTES);
     const int total = m->info.num_doppler_total, first = m->info.first_doppler_total, kmax = -first;
+    // capture and task list (tasks behind the capture, 16-byte aligned) staged ONCE for all engines: one host copy and one
+    // pinned buffer whatever the number of devices (calls are synchronous: nothing of an earlier call still reads it)
+    const size_t task_off = (nbytes + 15) & ~(size_t)15, shared_bytes = task_off + n_tasks * sizeof(Task);
+    if (shared_bytes > m->h_shared_cap) {
+        if (m->h_shared) HIPM(hipHostFree(m->h_shared));
+        m->h_shared = nullptr;
+        m->h_shared_cap = 0;
+        const size_t want = std::max(shared_bytes, (size_t)1 << 16);
+        HIPM(hipHostMalloc((void**)&m->h_shared, want, hipHostMallocPortable));
+        m->h_shared_cap = want;
+    }
+    memcpy(m->h_shared, bits, nbytes);
+    memcpy(m->h_shared + task_off, tasks, n_tasks * sizeof(Task));
     const int rc_enq = for_each_engine(m, [&](size_t i) -> int {
         // contiguous, balanced slab of the grid for device i (possibly empty when there are more devices than points)
         const int base = total / (int)n, rem = total % (int)n;
@@ -434,13 +453,8 @@ static int search_grid_impl(gpsacq_multi* m, const uint8_t* bits, size_t n_block
         hipStream_t st = (hipStream_t)gpsacq_stream(m->eng[i]);
         if (int rc = grow_dev(m, i, nbytes, n_tasks)) return rc;
         if (cnt > 0) {
-            // capture and task list through this engine's pinned staging (tasks behind the capture, 16-byte aligned)
-            const size_t task_off = (nbytes + 15) & ~(size_t)15;
-            if (int rc = grow_pinned(m, i, task_off + n_tasks * sizeof(Task), 0)) return rc;
-            memcpy(m->h_bits[i], bits, nbytes);
-            memcpy(m->h_bits[i] + task_off, tasks, n_tasks * sizeof(Task));
-            HIPM(hipMemcpyAsync(m->d_bits[i], m->h_bits[i], nbytes, hipMemcpyHostToDevice, st));
-            HIPM(hipMemcpyAsync(m->d_tasks[i], m->h_bits[i] + task_off, n_tasks * sizeof(Task), hipMemcpyHostToDevice, st));
+            HIPM(hipMemcpyAsync(m->d_bits[i], m->h_shared, nbytes, hipMemcpyHostToDevice, st));
+            HIPM(hipMemcpyAsync(m->d_tasks[i], m->h_shared + task_off, n_tasks * sizeof(Task), hipMemcpyHostToDevice, st));
             if (int rc = gpsacq_set_doppler_window(m->eng[i], first + off, cnt)) return rc;
             if (int rc = gpsacq_search_device(m->eng[i], m->d_bits[i], n_blocks, stride, m->d_tasks[i], n_tasks, nullptr, m->d_peaks[i], 0)) return rc;
             launch_pack_keys(m->d_peaks[i], m->d_keys[i], (int)n_tasks, kmax, st);

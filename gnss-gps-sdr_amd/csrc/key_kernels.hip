@@ -13,13 +13,34 @@ namespace acq {
 //   key = snr bits << 32 | (0xFFFF - (lo_shift + kmax)) << 16 | ca_shift
 // picks the higher SNR and, on equal SNR, the LOWER Doppler grid point -- the reference's strict '>' scan over
 // ascending dop (:196-198).  Non-negative IEEE floats order like their bit patterns.
+__device__ __forceinline__ unsigned long long peak_key(const Peak p, int kmax) {
+    const unsigned long long snr = (unsigned long long)__float_as_uint(p.snr > 0.f ? p.snr : 0.f);
+    const unsigned long long lo = (unsigned long long)(0xFFFF - (p.lo_shift + kmax)) & 0xFFFFull;
+    return (snr << 32) | (lo << 16) | ((unsigned long long)p.ca_shift & 0xFFFFull);
+}
 __global__ void k_pack_keys(const Peak* peaks, unsigned long long* keys, int n, int kmax) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
-    const Peak p = peaks[i];
-    const unsigned long long snr = (unsigned long long)__float_as_uint(p.snr > 0.f ? p.snr : 0.f);
-    const unsigned long long lo = (unsigned long long)(0xFFFF - (p.lo_shift + kmax)) & 0xFFFFull;
-    keys[i] = (snr << 32) | (lo << 16) | ((unsigned long long)p.ca_shift & 0xFFFFull);
+    keys[i] = peak_key(peaks[i], kmax);
+}
+
+// gpsacq_peak_keys_device(per_prn): peaks -> the 32 per-PRN best keys in ONE launch (reference schedule, task t <-> PRN t % 32):
+// what a rank of the block decomposition hands to the all-reduce (bench.py's step = one search + this + one all-reduce).
+// One workgroup; thread (r, sv) strides over the runs; n_tasks == 0 leaves 32 zero keys (neutral for MAX).
+__global__ __launch_bounds__(WG) void k_prn_keys(const Peak* peaks, int n_tasks, int kmax, unsigned long long* best) {
+    __shared__ unsigned long long part[WG];
+    const int sv = threadIdx.x & 31, lane_run = threadIdx.x >> 5;
+    unsigned long long k = 0;
+    for (int t = lane_run * 32 + sv; t < n_tasks; t += WG) {
+        const unsigned long long kt = peak_key(peaks[t], kmax);
+        k = kt > k ? kt : k;
+    }
+    part[threadIdx.x] = k;
+    __syncthreads();
+    if (threadIdx.x < 32) {
+        for (int r = 1; r < WG / 32; ++r) k = part[r * 32 + sv] > k ? part[r * 32 + sv] : k;
+        best[sv] = k;
+    }
 }
 
 // Reference schedule (task t <-> PRN t % 32): the best key of each PRN over all runs of this device -- what the one
@@ -72,6 +93,9 @@ __global__ void k_peak_pwr(const Peak* peaks, float* pwr, int n) {
 // launchers (host)
 void launch_pack_keys(const Peak* peaks, unsigned long long* keys, int n, int kmax, hipStream_t s) {
     hipLaunchKernelGGL(k_pack_keys, dim3((n + 255) / 256), dim3(256), 0, s, peaks, keys, n, kmax);
+}
+void launch_prn_keys(const Peak* peaks, int n_tasks, int kmax, unsigned long long* best, hipStream_t s) {
+    hipLaunchKernelGGL(k_prn_keys, dim3(1), dim3(WG), 0, s, peaks, n_tasks, kmax, best);
 }
 void launch_prn_best(const unsigned long long* keys, const Peak* peaks, int n_tasks, unsigned long long* best, float* best_pwr, hipStream_t s) {
     hipLaunchKernelGGL(k_prn_best, dim3(1), dim3(WG), 0, s, keys, peaks, n_tasks, best, best_pwr);

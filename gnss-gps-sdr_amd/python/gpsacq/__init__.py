@@ -67,7 +67,7 @@ EXPORTS = ["gpsacq_generate", "gpsacq_generate_device", "gpsacq_generate_sig", "
            "gpsacq_multi_set_doppler_step", "gpsacq_multi_get_info", "gpsacq_multi_search_grid", "gpsacq_multi_search_blocks",
            "gpsacq_pipe_buffer", "gpsacq_pipe_submit", "gpsacq_pipe_collect", "gpsacq_search_iq8", "gpsacq_search_iq8_device",
            "gpsacq_iq8_accumulate_sums", "gpsacq_handoff_step", "gpsacq_handoff_engine", "gpsacq_reserve", "gpsacq_multi_last_call_ms",
-           "gpsacq_sig_tx_samples", "gpsacq_generate_sig_tx"]
+           "gpsacq_sig_tx_samples", "gpsacq_generate_sig_tx", "gpsacq_peak_keys_device"]
 
 _lib = None
 
@@ -189,6 +189,8 @@ def load_library(path=None):
     lib.gpsacq_sig_tx_samples.restype = ctypes.c_uint64
     lib.gpsacq_generate_sig_tx.argtypes = [vp, ctypes.c_int, vp, ctypes.c_int, ctypes.c_int, ctypes.c_uint64, sz, vp]
     lib.gpsacq_generate_sig_tx.restype = ctypes.c_int
+    lib.gpsacq_peak_keys_device.argtypes = [vp, vp, sz, ctypes.c_int, vp, ctypes.c_int]
+    lib.gpsacq_peak_keys_device.restype = ctypes.c_int
     lib.gpsacq_multi_last_call_ms.argtypes = [vp, ctypes.POINTER(ctypes.c_double), ctypes.POINTER(ctypes.c_double), ctypes.POINTER(ctypes.c_int64)]
     lib.gpsacq_multi_last_call_ms.restype = ctypes.c_int
     if path is None:
@@ -391,6 +393,12 @@ class Engine:
         n_tasks = n_blocks if n_tasks is None else n_tasks
         _check(self._lib, self._lib.gpsacq_search_device(self._h, d_bits_ptr, n_blocks, stride, d_tasks_ptr, n_tasks,
                                                          d_cells_ptr, d_peaks_ptr, 1 if sync else 0))
+
+    def peak_keys_device(self, d_peaks_ptr, n_peaks, d_keys_ptr, per_prn=True, sync=False):
+        """gpsacq_peak_keys_device: the multi-GPU merge keys of a device search's peaks, on the engine's stream.  per_prn: 32 keys
+        (best per PRN, reference schedule); else one per peak.  d_keys: int64 / uint64 device memory."""
+        _check(self._lib, self._lib.gpsacq_peak_keys_device(self._h, d_peaks_ptr if n_peaks else None, int(n_peaks), 1 if per_prn else 0,
+                                                            d_keys_ptr, 1 if sync else 0))
 
     def synchronize(self):
         _check(self._lib, self._lib.gpsacq_synchronize(self._h))

@@ -15,6 +15,8 @@
  *                            for a batch of 5120-byte blocks (the body of the
  *                            SearchTask() loop, :239-246)
  *   gpsacq_search_device     same, capture already resident in HBM
+ *   gpsacq_peak_keys_device  Correlate()'s ordering of two results, :196-198 (strict '>' over ascending dop), as 64-bit keys whose
+ *                            integer MAX merges the per-PRN best of several GPUs / ranks
  *   gpsacq_pipe_*            same, batches in flight: the SearchTask() loop's fread of batch k+1 overlaps the search of batch k
  *   gpsacq_search_iq8        same on an 8-bit IQ capture: what proc_rtl_bin_for_gps.m / proc_hackrf_bin_for_gps.m + gps_test
  *                            do in two steps through a 1-bit file, fused into the forward transform
@@ -227,6 +229,19 @@ GPSACQ_API int gpsacq_set_creep_compensation(gpsacq_engine* e, int on);
  */
 GPSACQ_API int gpsacq_set_block_alignment(gpsacq_engine* e, int on);
 GPSACQ_API int gpsacq_aligned_stride(const gpsacq_engine* e);
+/*
+ * The merge keys of the multi-GPU reduction (the reference is one thread, c/search_offline.cpp has no
+ * counterpart), made from the peaks of a gpsacq_*_device search on the engine's stream, behind that search, without a host wait:
+ *   key = snr bits << 32 | (0xFFFF - (lo_shift + K)) << 16 | ca_shift,  K = -gpsacq_info.first_doppler_total
+ * so that integer MAX over keys = "higher SNR, ties to the LOWER Doppler point" -- the strict '>' scan of :196-198.  (SNR >= 0:
+ * the keys order the same as signed or unsigned 64-bit integers.)
+ *   per_prn != 0: d_keys[32] = the best key of every PRN over the peaks t with t % 32 == PRN (the reference schedule, task t
+ *                 <-> PRN t % 32, :239-246): what ONE all-reduce(MAX) of 256 bytes merges between the ranks of the block
+ *                 decomposition.  n_peaks == 0 (a rank without work) writes 32 zero keys, neutral for MAX.
+ *   per_prn == 0: d_keys[n_peaks], one key per peak (Doppler-slab decomposition: every rank holds every task).
+ * Device pointers; d_peaks as written by gpsacq_search_device / gpsacq_search_iq8_device on this engine.
+ */
+GPSACQ_API int gpsacq_peak_keys_device(gpsacq_engine* e, const void* d_peaks, size_t n_peaks, int per_prn, void* d_keys, int sync);
 GPSACQ_API int gpsacq_synchronize(gpsacq_engine* e);
 /* stage times of the most recent search (waits for it to finish) ... */
 GPSACQ_API int gpsacq_last_timing(const gpsacq_engine* e, gpsacq_timing* t);

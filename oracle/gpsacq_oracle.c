@@ -26,11 +26,11 @@
  *
  * PIN STATUS: parity UNPINNED at the level of FFTW's float rounding (no FFTW in this image; `make -C oracle ref` builds the
  * reference itself where FFTW exists and tests/test_ref_binary.py then pins this file to it).  Pinned to (0) the code phase of
- * PRN 8 in all 12 runs of gps_sig_tmp.bin as it follows from gps_sig_gen.m's own parameters (tests/test_oracle.py), (a) the
- * reference outputs recorded in BASELINE.md section 2 /
- * SURVEY.md section 8c (gps_test on gps_sig_tmp.bin, 12 runs: SNR, lo_shift, ca_shift of
- * sv 7 and the complete run-0 hit line), (b) the README known answer (PRN 8, Doppler 0),
- * (c) an independent float64 numpy restatement (tests/golden/make_golden.py).  At the
+ * PRN 8 in all 12 runs (and at all 384 blocks) of gps_sig_tmp.bin as it follows from gps_sig_gen.m's own parameters
+ * (tests/test_oracle.py), (a) the README known answer (PRN 8, Doppler 0), (b) an independent float64 numpy restatement
+ * (tests/golden/make_golden.py), (c) gps_sig_gen.m restated bit for bit (tests/test_siggen.py).  NOT a pin: the transcript in
+ * tests/golden/ref_known_answers.json (BASELINE.md section 2 / SURVEY.md section 8c) comes from the survey's MKL-shim build
+ * of the reference sources -- a stand-in build; it is compared as a regression transcript and pins nothing by itself.  At the
  * level of FFTW's own float rounding (~1e-7) parity is unpinned (no FFTW here).
  */
 #include <math.h>

@@ -151,3 +151,16 @@ def test_c99_client_on_gpu(tmp_path):
     assert "half-bin grid: 97 points of 102.30 Hz; multi (1 device) block 7 sv 7 snr 713.6 lo_shift 0 ca_shift 260" in r.stdout
     assert "pipeline: 16 + 16 peaks" in r.stdout and "multi blocks (2 engines on device 0): best sv 7 snr 713.6" in r.stdout
     assert "iq8: block 0 sv 7 snr" in r.stdout
+
+
+def test_lds_dma_wait_is_in_the_isa(tmp_path):
+    """k_corr<..., FOLD> refreshes its twiddle tables by LDS-DMA (`buffer_load ... lds`): every wave must drain its vmcnt before the
+    barrier that lets the other waves read them.  The source spells the wait out; this compiles the kernels to gfx950 assembly
+    (device side only, a few seconds) and checks that it is there, in front of the barrier, once per phase-1 copy."""
+    hipcc = "/opt/rocm/bin/hipcc" if os.path.exists("/opt/rocm/bin/hipcc") else "hipcc"
+    asm = str(tmp_path / "acq_kernels.s")
+    subprocess.check_call([hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-Wno-unused-function", "-Wno-unused-command-line-argument", "-S",
+                           "--cuda-device-only", os.path.join(ROOT, "gnss-gps-sdr_amd", "csrc", "acq_kernels.hip"), "-o", asm])
+    r = subprocess.run([os.sys.executable, os.path.join(ROOT, "tools", "isa_census.py"), asm, "--assert-dma-wait"], capture_output=True, text=True)
+    assert r.returncode == 0, r.stdout + r.stderr
+    assert "LDS-DMA waits in front of their barriers: ok" in r.stdout

@@ -18,7 +18,7 @@ def _bench(*args, env=None):
     e.update(env or {})
     if "--soak-seconds" not in args:
         args = ("--soak-seconds", "0") + tuple(args)  # the soak leg has its own test (tests/test_gpu_round4.py)
-    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "1", "--warmup", "1", "--no-cpu-baseline", *args],
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "1", "--warmup", "1", "--no-cpu-baseline", "--no-live-traffic", *args],
                        capture_output=True, text=True, timeout=600, env=e)
     assert r.returncode == 0, r.stderr[-2000:]
     lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
@@ -70,3 +70,32 @@ def test_two_self_spawned_ranks_share_the_capture():
     assert j["blocks_per_rank"] == [320, 320] and j["config"]["cells_per_step_job"] == 640 * 73
     assert set(j["detected_prns"]) >= set(j["injected_prns_all_ranks"])
 
+
+
+def test_eight_ranks_share_the_nottingham_sized_capture():
+    """The driver's N = 8 launch line (`python -m torch.distributed.run --nnodes=1 --nproc-per-node 8 ... bench.py --gpus 8`) on the
+    one-GPU box: gloo collectives, all eight ranks on device 0, the capture of the headline configuration (340 runs = 10 880
+    blocks).  Pins what the first real SCALE run must not trip over: the split of 340 runs over 8 ranks (43 x 4 + 42 x 4 runs),
+    eight ranks seen by the collective, the satellites of EVERY rank's part of the capture in the merged keys, and a stdout that
+    carries the JSON line and nothing else (seven other ranks and torchrun write elsewhere)."""
+    import socket
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    e = dict(os.environ, GPSACQ_DIST_BACKEND="gloo")
+    for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT"):
+        e.pop(k, None)
+    r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "8", "--master-addr", "127.0.0.1",
+                        "--master-port", str(port), os.path.join(ROOT, "bench.py"), "--gpus", "8", "--blocks-total", "10880", "--steps", "3",
+                        "--no-cpu-baseline", "--no-e2e"], capture_output=True, text=True, timeout=900, env=e)
+    assert r.returncode == 0, r.stderr[-3000:]
+    out_lines = [l for l in r.stdout.splitlines() if l.strip()]
+    assert len(out_lines) == 1 and out_lines[0].startswith("{"), r.stdout[-2000:]
+    j = json.loads(out_lines[0])
+    assert j["n_gpus"] == 8 and j["rccl_ranks_seen"] == 8 and j["dist_backend"] == "gloo" and j["steps"] == 3
+    assert j["blocks_per_rank"] == [1376] * 4 + [1344] * 4 and sum(j["blocks_per_rank"]) == 10880
+    assert j["config"]["cells_per_step_job"] == 10880 * 73 and j["config"]["blocks_rank0"] == 1376 and j["scaling"] == "strong"
+    assert len(j["injected_prns_all_ranks"]) > 8  # eight differently seeded parts
+    assert set(j["detected_prns"]) >= set(j["injected_prns_all_ranks"])
+    assert j["weak_scaling"]["blocks_per_gpu"] == 4096 and j["weak_scaling"]["value"] > 0
+    assert j["value"] > 0 and 0 < j["roofline"]["frac"] < 1 and "cpu_baseline" not in j

@@ -162,7 +162,9 @@ def test_full_run_with_reference_quirk(gpsacq_mod, golden_dir):
         gcells, gpeaks = eng.search(buf)
     orc = Oracle(4.092e6, 5.456e6, 5000.0, ref_quirks=True)
     ocells, opeaks = orc.search(buf, tasks)
-    _cmp_cells(gcells, ocells, "quirk run")  # (no tie helper: oracle_cell_power would need the patched code[0])
+    # tie helper on the SAME (quirk) oracle: oracle_sample() of the task's block re-applies that block's patch to code[0][0..959]
+    # (c/search_offline.cpp:61,135-157) before oracle_cell_power() reads it, so PRN index 0's per-lag powers are the patched ones
+    _cmp_cells(gcells, ocells, "quirk run", _tie_fn(orc, buf, tasks))
     assert np.array_equal(gpeaks["ca_shift"], opeaks["ca_shift"]) and np.array_equal(gpeaks["lo_shift"], opeaks["lo_shift"])
     # the quirk matters: without it PRN index 0 reads differently
     with gpsacq_mod.Engine(4.092e6, 5.456e6, 5000.0) as eng:
@@ -224,7 +226,10 @@ def assert_report_equal_up_to_printf_edges(got, want, opeaks):
 
 
 def test_gps_sig_tmp_known_answers(gpsacq_mod, golden_dir):
-    """gps_test gps_sig_tmp.bin 2.046e6 8.184e6 5000 -- reference outputs recorded in BASELINE.md."""
+    """gps_test gps_sig_tmp.bin 2.046e6 8.184e6 5000 with ref_quirks.  What is PINNED here comes from the reference's own generator
+    script (PRN 8, Doppler bin 0, ca_shift = (40960 b - 20) mod 8184: gps_sig_gen.m's parameters) and from the oracle, line by
+    line a restatement of c/search_offline.cpp.  tests/golden/ref_known_answers.json is the survey's MKL-shim transcript -- a
+    stand-in build of the reference sources, which pins nothing by itself; it is compared as a regression transcript only."""
     from oracle_lib import Oracle
     known = json.load(open(os.path.join(golden_dir, "ref_known_answers.json")))["gps_sig_tmp"]
     path = os.path.join(golden_dir, "gps_sig_tmp.bin")

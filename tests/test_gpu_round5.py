@@ -1,0 +1,97 @@
+"""Round 5 on the GPU box: the bench line verifies itself against the oracle at the configuration it measures and carries a
+box-independent roofline; the multi-GPU merge keys are made by the library."""
+import json
+import os
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _run_bench(*args):
+    e = dict(os.environ)
+    for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT", "GPSACQ_DIST_BACKEND"):
+        e.pop(k, None)
+    return subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), *args], capture_output=True, text=True, timeout=900, env=e)
+
+
+def _line(r):
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, r.stdout[-2000:] + r.stderr[-2000:]
+    return json.loads(lines[0])
+
+
+def test_default_line_carries_its_own_parity_verdict_and_clock():
+    """cpu_baseline.parity_vs_gpu: the peaks of the last timed step against the oracle's float build on the blocks the cpu_baseline
+    leg searches anyway (c/search_offline.cpp:190-198: same code phase, same Doppler bin, SNR to 1e-4, ties proven in double),
+    plus three full rows of cells against liboracle_f64; roofline.sclk_mhz / cycles_per_cell_per_cu / frac_at_clock from readings
+    taken DURING the timed steps; roofline.pk_fma_stream_TF from the micro-benchmark run in the untimed part."""
+    r = _run_bench("--steps", "8", "--warmup", "2", "--blocks-total", "640", "--weak-blocks", "0", "--no-e2e", "--no-live-traffic",
+                   "--soak-seconds", "0.5", "--pk-fma-seconds", "1.0")
+    assert r.returncode == 0, r.stderr[-3000:]
+    j = _line(r)
+    cb = j["cpu_baseline"]
+    par = cb["parity_vs_gpu"]
+    assert par["ok"] is True and cb["parity_ok"] is True, par
+    assert par["blocks"] >= 200 and par["ca_equal"] + par["proven_ties"] >= par["blocks"] and not par["unproven_mismatches"]
+    assert par["lo_equal"] + par["proven_ties"] >= par["blocks"]
+    assert par["snr_max_rel"] <= 1e-4 and par["pwr_max_rel"] <= 2e-5 and par["cells"] == 3 * 73 and not par["cell_lag_mismatches"]
+    assert cb["parity_blocks"] == par["blocks"] and cb["parity_snr_max_rel"] == par["snr_max_rel"] and cb["parity_pwr_max_rel"] == par["pwr_max_rel"]
+    rf = j["roofline"]
+    assert rf["clock_sampling"]["samples"] >= 1, rf["clock_sampling"]
+    assert 500 <= rf["sclk_mhz"] <= 3000 and rf["power_w"] is None or rf["power_w"] > 50
+    want = rf["kernel_ms"] * 1e-3 * rf["sclk_mhz"] * 1e6 * rf["compute_units"] / rf["cells_per_launch"]
+    assert abs(rf["cycles_per_cell_per_cu"] / want - 1) < 1e-9 and 10000 < rf["cycles_per_cell_per_cu"] < 100000
+    assert abs(rf["frac_at_clock"] - rf["achieved"] / (157.3 * rf["sclk_mhz"] / 2400.0)) < 1e-9 and rf["frac"] < rf["frac_at_clock"] < 1
+    assert 60 < rf["pk_fma_stream_TF"] < 158 and 0 < rf["frac_of_pk_fma_stream"] < 1, rf["pk_fma_stream"]
+    ex = j["extras"]
+    assert ex["one_rank_process_group"] and ex["pk_fma_stream"] and ex["cpu_baseline"] and not ex["live_traffic"] and not ex["e2e_cli"]
+    oc = j["one_rank_collective"]
+    assert oc["ms_per_step_without_process_group"] > 0 and oc["ms_per_step_with"] == j["ms_per_step"]
+
+
+def test_a_wrong_gpu_result_fails_the_bench_run():
+    """--parity-selftest moves one GPU peak by one lag before the comparison: the line still comes out, says so, and the exit code is 3."""
+    r = _run_bench("--steps", "2", "--warmup", "1", "--blocks-total", "640", "--weak-blocks", "0", "--no-e2e", "--no-live-traffic",
+                   "--soak-seconds", "0", "--parity-selftest")
+    assert r.returncode == 3, (r.returncode, r.stderr[-1500:])
+    j = _line(r)
+    par = j["cpu_baseline"]["parity_vs_gpu"]
+    assert par["ok"] is False and par["unproven_mismatches"] == [7] and j["cpu_baseline"]["parity_ok"] is False
+    assert "DISAGREE" in r.stderr
+
+
+def test_peak_keys_device_equals_the_torch_packing(golden_dir):
+    """gpsacq_peak_keys_device (one launch on the engine's stream) = gpsacq.dist.pack_keys / per_prn_best bit for bit: per-PRN best
+    keys of the reference schedule, per-task keys, and 32 zero keys for a rank without work."""
+    import torch
+    import gpsacq
+    from gpsacq import dist as D
+    buf = np.frombuffer(open(os.path.join(golden_dir, "synth_nott_fs5456.bin"), "rb").read(), dtype=np.uint8)
+    nblk = buf.size // 5120
+    nblk -= nblk % 32
+    dev = torch.device("cuda", 0)
+    with gpsacq.Engine(4.092e6, 5.456e6, 5000.0) as eng:
+        d_bits = torch.from_numpy(buf[:nblk * 5120].copy()).to(dev)
+        d_peaks = torch.zeros((nblk, 4), dtype=torch.int32, device=dev)
+        eng.search_device(d_bits.data_ptr(), nblk, d_peaks.data_ptr(), sync=False)
+        k32 = torch.full((32,), -1, dtype=torch.int64, device=dev)
+        kall = torch.full((nblk,), -1, dtype=torch.int64, device=dev)
+        eng.peak_keys_device(d_peaks.data_ptr(), nblk, k32.data_ptr(), per_prn=True)
+        eng.peak_keys_device(d_peaks.data_ptr(), nblk, kall.data_ptr(), per_prn=False, sync=True)
+        want_all = D.pack_keys(d_peaks, eng.kmax)
+        assert torch.equal(kall, want_all) and torch.equal(k32, D.per_prn_best(want_all))
+        snr, lo, ca = D.unpack_keys(k32.cpu(), eng.kmax)
+        assert [int(p) + 1 for p in torch.nonzero(snr >= 25).flatten()] == [1, 21, 29, 30, 31]
+        # a partial last run: tasks 0 .. 39 -> PRNs 0..7 see two candidates, the others one
+        eng.peak_keys_device(d_peaks.data_ptr(), 40, k32.data_ptr(), per_prn=True, sync=True)
+        w = torch.zeros(32, dtype=torch.int64, device=dev)
+        w[:] = want_all[:32]
+        w[:8] = torch.maximum(w[:8], want_all[32:40])
+        assert torch.equal(k32, w)
+        eng.peak_keys_device(0, 0, k32.data_ptr(), per_prn=True, sync=True)  # a rank without work
+        assert int(k32.abs().sum()) == 0

@@ -74,9 +74,11 @@ def test_cells_vs_numpy_golden(golden_dir, name, fc, fs, file):
         assert np.array_equal(cells["max_i"], z[f"max_i_{b}_{sv}"])
 
 
-def test_reference_known_answers_gps_sig_tmp(golden_dir):
-    """gps_test gps_sig_tmp.bin 2.046e6 8.184e6 5000: the oracle must print what the reference
-    printed.  First 3 runs here (the full 12 run in the GPU suite)."""
+def test_survey_transcript_gps_sig_tmp(golden_dir):
+    """gps_test gps_sig_tmp.bin 2.046e6 8.184e6 5000: the oracle against the survey's transcript -- the
+    survey's MKL-shim build of the reference sources, a STAND-IN (no FFTW in the image): it pins nothing by itself and is kept
+    as a regression transcript; the pins of this file are test_code_phase_follows_from_gps_sig_gen (the generator script's own
+    parameters) and the README's known answer below.  First 3 runs here (the full 12 run in the GPU suite)."""
     known = json.load(open(os.path.join(golden_dir, "ref_known_answers.json")))["gps_sig_tmp"]
     orc = Oracle(2.046e6, 8.184e6, 5000.0, ref_quirks=True)
     n, text, peaks = orc.search_file(os.path.join(golden_dir, "gps_sig_tmp.bin"), max_runs=3)

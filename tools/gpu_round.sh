@@ -9,11 +9,11 @@ mkdir -p $OUT
 cd $R
 timeout 1700 python -m pytest tests -m gpu -q > $OUT/pytest_gpu.log 2>&1; echo "pytest rc $?" >> $OUT/pytest_gpu.log; tail -4 $OUT/pytest_gpu.log
 python bench.py > $OUT/bench_default.json 2> $OUT/bench_default.err
-python bench.py --config 2 --no-cpu-baseline --no-e2e --soak-seconds 0 > $OUT/bench_config2.json 2> $OUT/bench_config2.err
-python bench.py --config 3 --doppler-step 250 --no-cpu-baseline --steps 5 --soak-seconds 0 > $OUT/bench_config3.json 2> $OUT/bench_config3.err
-python bench.py --config 4 --doppler-step 50 --no-cpu-baseline --steps 5 --soak-seconds 0 > $OUT/bench_config4.json 2> $OUT/bench_config4.err
-python bench.py --config 1 --input iq8 --steps 5 --no-cpu-baseline --no-e2e --soak-seconds 0 > $OUT/bench_iq8_config1.json 2> $OUT/bench_iq8_config1.err
-python bench.py --config 3 --input iq8 --blocks-total 1024 --steps 3 --no-cpu-baseline --no-e2e --soak-seconds 0 > $OUT/bench_iq8_config3.json 2> $OUT/bench_iq8_config3.err
+python bench.py --config 2 --no-cpu-baseline --no-live-traffic --no-e2e --soak-seconds 0 > $OUT/bench_config2.json 2> $OUT/bench_config2.err
+python bench.py --config 3 --doppler-step 250 --no-cpu-baseline --no-live-traffic --steps 5 --soak-seconds 0 > $OUT/bench_config3.json 2> $OUT/bench_config3.err
+python bench.py --config 4 --doppler-step 50 --no-cpu-baseline --no-live-traffic --steps 5 --soak-seconds 0 > $OUT/bench_config4.json 2> $OUT/bench_config4.err
+python bench.py --config 1 --input iq8 --steps 5 --no-cpu-baseline --no-live-traffic --no-e2e --soak-seconds 0 > $OUT/bench_iq8_config1.json 2> $OUT/bench_iq8_config1.err
+python bench.py --config 3 --input iq8 --blocks-total 1024 --steps 3 --no-cpu-baseline --no-live-traffic --no-e2e --soak-seconds 0 > $OUT/bench_iq8_config3.json 2> $OUT/bench_iq8_config3.err
 GPSACQ_DIST_BACKEND=gloo python bench.py --gpus 2 --steps 5 --warmup 2 --no-e2e 2> $OUT/bench_two_rank_selfspawn.err | grep '^{' > $OUT/bench_two_rank_selfspawn.json
 GPSACQ_DIST_BACKEND=gloo python -m torch.distributed.run --nnodes=1 --nproc-per-node 2 --master-addr 127.0.0.1 --master-port 29517 \
     bench.py --gpus 2 --steps 5 --warmup 2 --no-e2e 2> $OUT/bench_two_rank_gloo.err | grep '^{' > $OUT/bench_two_rank_gloo.json

@@ -3,7 +3,8 @@
 labels, s_barrier and branches into segments, each segment's instructions are counted by class.  For k_corr the segments of the
 q loop ARE the barrier-delimited phases of one 5000-point sub-transform (phase 1: loads + product + radix-10 + pass-1 stores;
 pass 2: radix-25; pass 3: radix-20 + rotation + accumulate).
-Usage: tools/isa_census.py build/isa/acq_kernels.s <kernel-symbol-substring> [--segments]"""
+Usage: tools/isa_census.py build/isa/acq_kernels.s <kernel-symbol-substring> [--segments]
+       tools/isa_census.py build/isa/acq_kernels.s --assert-dma-wait"""
 import collections
 import re
 import sys
@@ -43,7 +44,47 @@ def kernel_body(path, needle):
     return lines[start].split(":")[0], body
 
 
+def assert_dma_wait(path):
+    """Every kernel that refreshes an LDS table by LDS-DMA (`buffer_load ... lds`, k_corr<..., FOLD>) must drain its vector-memory
+    counter before the barrier that publishes the table to the other waves: the source spells the wait out (inline asm after
+    phase 1, acq_kernels.hip), this checks it reached the ISA -- one `s_waitcnt vmcnt(0)` in an inline-asm block per phase-1 copy
+    (phase 1 ends in `s_setprio 0`), each followed by the s_barrier with no vector-memory instruction in between."""
+    lines = open(path).read().splitlines()
+    starts = [i for i, l in enumerate(lines) if re.match(r"^_Z\w+:", l)]
+    checked = 0
+    for a in starts:
+        body = []
+        for l in lines[a + 1:]:
+            if l.startswith(".Lfunc_end"):
+                break
+            body.append(l.strip())
+        if not any(re.match(r"buffer_load\w* .*\blds$", t) for t in body):
+            continue
+        name = lines[a].split(":")[0]
+        waits = [i for i, t in enumerate(body) if t == "s_waitcnt vmcnt(0)" and i > 0 and body[i - 1].startswith(";;#ASMSTART")]
+        n_phase1 = sum(1 for t in body if t == "s_setprio 0")
+        if not waits or len(waits) != n_phase1:
+            raise SystemExit(f"{name}: {len(waits)} explicit vmcnt(0) waits for {n_phase1} phase-1 copies")
+        for w in waits:
+            ok = False
+            for t in body[w + 1:w + 12]:
+                op = t.split()[0] if t and not t.startswith((";", ".")) else ""
+                if op == "s_barrier":
+                    ok = True
+                    break
+                if re.match(r"(buffer_|global_|flat_|scratch_)", op):
+                    break
+            if not ok:
+                raise SystemExit(f"{name}: the explicit vmcnt(0) wait at body line {w} is not followed by the barrier")
+        checked += 1
+        print(f"{name}: {len(waits)} LDS-DMA waits in front of their barriers: ok")
+    if not checked:
+        raise SystemExit("no kernel with LDS-DMA found")
+
+
 def main():
+    if "--assert-dma-wait" in sys.argv:
+        return assert_dma_wait(sys.argv[1])
     path, needle = sys.argv[1], sys.argv[2]
     name, body = kernel_body(path, needle)
     segs = []  # (label, Counter)

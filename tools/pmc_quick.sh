@@ -9,7 +9,7 @@ for set in "SQ_WAVES SQ_WAVE_CYCLES SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_ACTIVE_
            "SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_ACTIVE_INST_LDS SQ_WAIT_INST_LDS SQ_INSTS_VMEM_RD SQ_INSTS_SALU SQ_INSTS_SMEM SQ_BUSY_CYCLES" \
            "TCP_TCC_READ_REQ_sum GRBM_GUI_ACTIVE"; do
   i=$((i+1))
-  env "$@" rocprofv3 --pmc $set --output-format csv -d $OUT/p$i -o p -- python $R/bench.py --steps 2 --warmup 1 --blocks-total 1024 --weak-blocks 0 --no-cpu-baseline --no-e2e > $OUT/log$i.txt 2>&1
+  env "$@" rocprofv3 --pmc $set --output-format csv -d $OUT/p$i -o p -- python $R/bench.py --steps 2 --warmup 1 --blocks-total 1024 --weak-blocks 0 --no-cpu-baseline --no-live-traffic --no-e2e > $OUT/log$i.txt 2>&1
 done
 python - <<PY
 import csv,collections,glob

@@ -2,7 +2,7 @@
 # tools/power_probe.sh -- board power, clocks and temperature sampled every 0.5 s while the default bench leg runs
 # (is k_corr's ~2.16 GHz the power cap or a fixed DVFS state?).  Output: gpurun_out/power_samples.txt
 mkdir -p gpurun_out
-( python bench.py --steps 200 --warmup 2 --no-e2e --no-cpu-baseline 2>/dev/null | grep '^{' | cut -c1-220 > gpurun_out/power_bench.txt ) &
+( python bench.py --steps 200 --warmup 2 --no-e2e --no-cpu-baseline --no-live-traffic 2>/dev/null | grep '^{' | cut -c1-220 > gpurun_out/power_bench.txt ) &
 BP=$!
 : > gpurun_out/power_samples.txt
 while kill -0 $BP 2>/dev/null; do
