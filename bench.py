@@ -216,10 +216,12 @@ class ClockSampler:
                 r = smi_sample(self.dev_index)
                 self.readings.append({"sclk_mhz": r.get("sclk_mhz"), "power_w": r.get("power_w"), "t": time.perf_counter()})
             return
-        while not self._stop.wait(self.period):
+        wait = min(0.01, self.period)  # a first reading 10 ms in (a leg of a few steps still gets one), then one per period
+        while not self._stop.wait(wait):
             r = read_clock_power(self.card)
             r["t"] = time.perf_counter()
             self.readings.append(r)
+            wait = self.period
 
     def start(self):
         import threading
