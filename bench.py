@@ -32,6 +32,20 @@ runs -- the per-step all-reduce(MAX) of the packed keys on torch's stream, `dist
 all-reduce of the elapsed time -- executes on every run of this file (`dist_backend: "nccl"`, `rccl_ranks_seen: 1`);
 `--no-dist` skips it, `--force-dist` makes a failure to create the group fatal instead of falling back.
 
+The line verifies itself and is comparable across boxes (round 5):
+  cpu_baseline.parity_vs_gpu  the peaks of the LAST TIMED STEP against the oracle (test infrastructure, the checker) at the configuration
+        measured: every block the cpu_baseline leg pushes through the oracle's float build must carry the same ca_shift / lo_shift
+        (or a tie proven in the double-precision oracle) and an SNR within 1e-4, and three seeded random full rows of cells of the
+        whole capture must agree with liboracle_f64 to 2e-5 (c/search_offline.cpp:190-198,248).  Flat copies (parity_ok,
+        parity_blocks, ...) sit beside it.  A disagreement makes the run EXIT 3 after the line is printed.
+  roofline.sclk_mhz / power_w   median of sysfs readings (pp_dpm_sclk, hwmon power1) taken every 100 ms DURING the K timed steps
+  roofline.cycles_per_cell_per_cu = kernel_ms x sclk x CUs / cells, roofline.frac_at_clock = achieved / (157.3 TFLOP/s x sclk / 2.4 GHz)
+  roofline.pk_fma_stream_TF     a pure v_pk_fma_f32 stream at k_corr's residency for 3 s in the untimed part (gnss-gps-sdr_amd/bin/
+        pk_fma_stream): what the fp32 vector pipe sustains on this box, next to the datasheet's 157.3
+  extras / one_rank_collective  which optional legs ran beside the timed steps, and the N = 1 step with and without its process group
+The per-step merge keys are made by the library (gpsacq_peak_keys_device, one launch on the engine's stream): a step is one search,
+the keys, one all-reduce.
+
 After the K timed steps a `soak` leg repeats the same step until >= 6 s of GPU time have passed (reported separately; `steps`
 and `ms_per_step` are untouched) with one sclk / package-power sample taken in mid-leg, so that a coarse SMI sampler beside
 the run sees the GPU busy at the rate the line claims.
@@ -902,7 +916,12 @@ def main():
         sleg = Leg(torch, gpsacq, gdist, eng, dev, dist, backend, share_runs * 32, share_runs * 32, d_bits, None, stride, False)
         s_elapsed, s_kern_ms, _ = sleg.run(max(20, args.steps // 2), 3)
         s_ms = 1e3 * s_elapsed / max(20, args.steps // 2)
+        s_tm = eng.last_timing()
         share = {"ranks_emulated": 8, "blocks_per_step": share_runs * 32, "ms_per_step": s_ms, "kernel_ms": s_kern_ms,
+                 # the step's own three kernels (forward transforms, correlator, peak scan; HIP events) and what is left over: launch
+                 # gaps, the key kernel, the event hand-over to torch's stream, the one-rank all-reduce
+                 "stage_ms": {k: s_tm[k] for k in ("ms_sample", "ms_correlate", "ms_peaks")},
+                 "non_kernel_ms": s_ms - (s_tm["ms_sample"] + s_tm["ms_correlate"] + s_tm["ms_peaks"]),
                  "cells_per_s_this_gpu": share_runs * 32 * eng.num_doppler / (s_ms * 1e-3),
                  "predicted_speedup_at_8_gpus": (1e3 * elapsed / args.steps) / s_ms,
                  "note": "one GPU running the largest per-rank share of the capture at N = 8 (same step, one-rank all-reduce included); "

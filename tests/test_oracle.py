@@ -1,6 +1,8 @@
-"""CPU tests of the oracle (the C restatement under oracle/): pinned against the reference
-outputs recorded in BASELINE.md, the bundled capture, and an independent float64 numpy
-restatement (tests/golden/make_golden.py)."""
+"""CPU tests of the oracle (the C restatement under oracle/): pinned against the reference-held capture gps_sig_tmp.bin through
+the parameters of the script that made it (gps_sig_gen.m: PRN 8, Doppler 0, the code phase of every block), the README's known
+answer, IS-GPS-200 chips, and an independent float64 numpy restatement (tests/golden/make_golden.py).  The transcript recorded
+in BASELINE.md section 2 (tests/golden/ref_known_answers.json) is the survey's MKL-shim build of the reference sources -- a
+stand-in build that pins nothing by itself -- and is compared as a regression transcript only."""
 import json
 import sys
 import os

@@ -28,6 +28,7 @@ if os.path.exists(ks):
                          f"{float(r['MaxNs'])/1e3:.1f} | {float(r['Percentage']):.2f} |")
     lines.append("")
 cells_per_launch = None
+clock_lines = []  # the box-independent figures (round 5): cycles one CU spends per cell, fraction of the peak at the clock held
 for name, what in (("bench_traced.log", "traced"), ("bench_unprofiled.log", "un-profiled")):
     bl = os.path.join(src, name)
     if os.path.exists(bl):
@@ -38,7 +39,19 @@ for name, what in (("bench_traced.log", "traced"), ("bench_unprofiled.log", "un-
                 r = j.get("roofline", {})
                 lines += [f"bench line of the {what} run of the same command: " + json.dumps(
                     {"value": j.get("value"), "ms_per_step": j.get("ms_per_step"), "stage_ms": j.get("stage_ms"),
-                     "roofline": {k: r.get(k) for k in ("bound", "kernel", "achieved", "peak", "unit", "frac", "kernel_ms", "cells_per_launch", "flops_per_cell")}}), ""]
+                     "roofline": {k: r.get(k) for k in ("bound", "kernel", "achieved", "peak", "unit", "frac", "kernel_ms", "cells_per_launch", "flops_per_cell",
+                                                        "sclk_mhz", "power_w", "cycles_per_cell_per_cu", "frac_at_clock")}}), ""]
+                if r.get("sclk_mhz") and r.get("cycles_per_cell_per_cu"):
+                    clock_lines.append(f"- {what} run, HIP events: kernel_ms {r['kernel_ms']:.3f} x sclk {r['sclk_mhz']:.0f} MHz (sysfs, median over the timed steps; "
+                                       f"{r.get('power_w')} W) x {r.get('compute_units')} CUs / {r['cells_per_launch']} cells = **{r['cycles_per_cell_per_cu']:.0f} cycles per cell per CU**, "
+                                       f"frac {r['frac']:.4f} of 157.3 TFLOP/s, **frac_at_clock {r['frac_at_clock']:.4f}**")
+                    if what == "traced" and os.path.exists(ks):
+                        for row in csv.DictReader(open(ks)):
+                            if "k_corr" in row["Name"]:
+                                avg_ms = float(row["AverageNs"]) / 1e6
+                                cyc = avg_ms * 1e-3 * r["sclk_mhz"] * 1e6 * r.get("compute_units", 256) / r["cells_per_launch"]
+                                clock_lines.append(f"- rocprofv3 trace of that run: k_corr avg {avg_ms:.3f} ms x the same sclk = **{cyc:.0f} cycles per cell per CU**")
+                                break
 pp = os.path.join(src, "phase_profile.log")
 if os.path.exists(pp):
     ph = [l.strip() for l in open(pp) if "k_corr profile" in l and not l.strip().endswith("total 0")]  # (only the 22-column instance carries the profiler)
@@ -91,6 +104,11 @@ try:
                     onchip[name] = d[key] / d["SQ_WAVE_CYCLES"]
         if "GRBM_GUI_ACTIVE" in d and "TCP_TCC_READ_REQ_sum" in d:
             onchip["l2_to_l1_bytes_per_cell"] = d["TCP_TCC_READ_REQ_sum"] * 64.0 / cells
+        if "GRBM_GUI_ACTIVE" in d:
+            # GRBM_GUI_ACTIVE: shader-clock cycles the kernel kept the GPU busy, summed over the 8 XCDs -- a duration in CYCLES, no clock reading needed
+            cyc = d["GRBM_GUI_ACTIVE"] / 8.0 * 256.0 / cells
+            onchip["cycles_per_cell_per_cu_grbm"] = cyc
+            clock_lines.append(f"- PMC pass: GRBM_GUI_ACTIVE {d['GRBM_GUI_ACTIVE']:.6g} / 8 XCDs x 256 CUs / {cells:.0f} cells = **{cyc:.0f} cycles per cell per CU** (counted in cycles: independent of the box's clock)")
         # ties the counters to the kernel sources they were collected on: bench.py recomputes the hash and flags a mismatch
         # ("traffic_stale").  The summary is made in the authoring container from the GPU box's output of the SAME tree.
         import hashlib
@@ -110,5 +128,7 @@ try:
                   open(os.path.join(dst, "traffic.json"), "w"), indent=1)
 except Exception as ex:  # noqa
     print("traffic.json not written:", ex)
+if clock_lines:
+    lines += ["## Box-independent roofline of k_corr (what makes this profile comparable with a bench line from another box)", ""] + clock_lines + [""]
 open(os.path.join(dst, f"{tag}_summary.md"), "w").write("\n".join(lines))
 print("\n".join(lines))
