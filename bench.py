@@ -589,8 +589,14 @@ class Leg:
             best = self.step()
         self.fence()
         corr_ms, self.sample_ms = [], []
+        stamps = ev = None
         if self.sampler is not None:
             self.sampler.start()
+            if self.n_tasks > 0:  # shader-cycle stamps + HIP events on the engine's stream around the timed steps: the clock the GPU itself counted
+                stamps = torch.zeros(2, dtype=torch.int64, device=self.dev)
+                ev = [torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)]
+                self.eng.cycle_stamp_device(stamps[0:1].data_ptr())
+                ev[0].record(self.eng_stream)
         t0 = time.perf_counter()
         for i in range(steps):
             best = self.step()
@@ -602,8 +608,17 @@ class Leg:
             tm = self.eng.last_timing(0)
             corr_ms.append(tm["ms_correlate"])
             self.sample_ms.append(tm["ms_sample"])
+        if stamps is not None:
+            self.eng.cycle_stamp_device(stamps[1:2].data_ptr())
+            ev[1].record(self.eng_stream)
         self.fence()
         elapsed = time.perf_counter() - t0
+        self.memtime_mhz = None
+        if stamps is not None:
+            st = stamps.cpu().tolist()
+            ms = ev[0].elapsed_time(ev[1])
+            mhz = (st[1] - st[0]) / (ms * 1e3) if ms > 0 else 0.0
+            self.memtime_mhz = mhz if 300.0 < mhz < 4000.0 else None  # (two stamps from different counters would not land here)
         if self.sampler is not None:
             self.sampler.stop()
         t = torch.tensor([elapsed], dtype=torch.float64, device=self.dev if self.backend == "nccl" else "cpu")
@@ -896,6 +911,15 @@ def main():
     elapsed, kern_ms, best = leg.run(args.steps, args.warmup)
     timing = eng.last_timing() if n_tasks > 0 else None
     clock = leg.sampler.stats() if leg.sampler is not None else None
+    if clock is not None:
+        # the clock of the roofline: the GPU's own cycle count over the timed steps (s_memtime stamps / HIP events on the engine's stream);
+        # the sysfs readings (a firmware average that lags by about a second) stay beside it and take over only if the stamps are unusable
+        clock["sclk_mhz_sysfs"] = clock["sclk_mhz"]
+        mt = getattr(leg, "memtime_mhz", None)
+        clock["sclk_mhz_cycle_counter"] = mt
+        if mt:
+            clock["sclk_mhz"] = mt
+            clock["source"] = "shader-cycle counter (s_memtime stamps around the timed steps / HIP-event time between them); sysfs beside it: " + clock["source"]
     leg.sampler = None
     # the peaks of the LAST TIMED STEP, kept for the parity verdict (cpu_baseline.parity_vs_gpu) before any other leg runs
     gpu_peaks = None

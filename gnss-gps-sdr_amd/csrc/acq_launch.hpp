@@ -89,6 +89,7 @@ hipError_t upload_wq8(const cf* host);
 void launch_scan_power(const float* pdump, Cell* cells, size_t n_cells, int nlags, hipStream_t s);
 void launch_merge_cells(const Cell* parts, Cell* cells, size_t n_cells, int n_parts, int nlags, hipStream_t s);
 void launch_pack_keys(const Peak* peaks, unsigned long long* keys, int n, int kmax, hipStream_t s);
+void launch_cycle_stamp(unsigned long long* out, hipStream_t s);
 void launch_prn_keys(const Peak* peaks, int n_tasks, int kmax, unsigned long long* best, hipStream_t s);
 void launch_prn_best(const unsigned long long* keys, const Peak* peaks, int n_tasks, unsigned long long* best, float* best_pwr, hipStream_t s);
 void launch_max_u64(unsigned long long* dst, const unsigned long long* src, int n, hipStream_t s);

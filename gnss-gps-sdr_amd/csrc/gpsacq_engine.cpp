@@ -1057,6 +1057,15 @@ extern "C" int gpsacq_peak_keys_device(gpsacq_engine* e, const void* d_peaks, si
     return GPSACQ_OK;
 }
 
+extern "C" int gpsacq_cycle_stamp_device(gpsacq_engine* e, void* d_stamp, int sync) {
+    if (!e || !d_stamp) return fail(GPSACQ_ERR_ARG, "gpsacq_cycle_stamp_device: null argument");
+    HIPCHK(hipSetDevice(e->p.device));
+    launch_cycle_stamp((unsigned long long*)d_stamp, e->stream);
+    HIPCHK(hipGetLastError());
+    if (sync) HIPCHK(hipStreamSynchronize(e->stream));
+    return GPSACQ_OK;
+}
+
 extern "C" int gpsacq_timing_ago(const gpsacq_engine* e, int n_back, gpsacq_timing* t) {
     if (!e || !t) return fail(GPSACQ_ERR_ARG, "gpsacq_timing_ago: null argument");
     if (n_back < 0 || n_back >= gpsacq_engine::kTimingRing || (long)n_back >= e->searches)

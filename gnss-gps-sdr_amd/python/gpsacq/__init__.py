@@ -67,7 +67,7 @@ EXPORTS = ["gpsacq_generate", "gpsacq_generate_device", "gpsacq_generate_sig", "
            "gpsacq_multi_set_doppler_step", "gpsacq_multi_get_info", "gpsacq_multi_search_grid", "gpsacq_multi_search_blocks",
            "gpsacq_pipe_buffer", "gpsacq_pipe_submit", "gpsacq_pipe_collect", "gpsacq_search_iq8", "gpsacq_search_iq8_device",
            "gpsacq_iq8_accumulate_sums", "gpsacq_handoff_step", "gpsacq_handoff_engine", "gpsacq_reserve", "gpsacq_multi_last_call_ms",
-           "gpsacq_sig_tx_samples", "gpsacq_generate_sig_tx", "gpsacq_peak_keys_device"]
+           "gpsacq_sig_tx_samples", "gpsacq_generate_sig_tx", "gpsacq_peak_keys_device", "gpsacq_cycle_stamp_device"]
 
 _lib = None
 
@@ -191,6 +191,8 @@ def load_library(path=None):
     lib.gpsacq_generate_sig_tx.restype = ctypes.c_int
     lib.gpsacq_peak_keys_device.argtypes = [vp, vp, sz, ctypes.c_int, vp, ctypes.c_int]
     lib.gpsacq_peak_keys_device.restype = ctypes.c_int
+    lib.gpsacq_cycle_stamp_device.argtypes = [vp, vp, ctypes.c_int]
+    lib.gpsacq_cycle_stamp_device.restype = ctypes.c_int
     lib.gpsacq_multi_last_call_ms.argtypes = [vp, ctypes.POINTER(ctypes.c_double), ctypes.POINTER(ctypes.c_double), ctypes.POINTER(ctypes.c_int64)]
     lib.gpsacq_multi_last_call_ms.restype = ctypes.c_int
     if path is None:
@@ -399,6 +401,10 @@ class Engine:
         (best per PRN, reference schedule); else one per peak.  d_keys: int64 / uint64 device memory."""
         _check(self._lib, self._lib.gpsacq_peak_keys_device(self._h, d_peaks_ptr if n_peaks else None, int(n_peaks), 1 if per_prn else 0,
                                                             d_keys_ptr, 1 if sync else 0))
+
+    def cycle_stamp_device(self, d_stamp_ptr, sync=False):
+        """gpsacq_cycle_stamp_device: the shader-cycle counter written to 8 bytes of device memory, on the engine's stream."""
+        _check(self._lib, self._lib.gpsacq_cycle_stamp_device(self._h, d_stamp_ptr, 1 if sync else 0))
 
     def synchronize(self):
         _check(self._lib, self._lib.gpsacq_synchronize(self._h))

@@ -41,4 +41,4 @@ for f in sorted(glob.glob("$OUT/bench_*.json")):
     except Exception as ex:
         print(f, "unreadable:", ex)
 PY
-tail -3 $OUT/*.err | cut -c1-300
+tail -n 3 $OUT/*.err | cut -c1-300

@@ -9,7 +9,7 @@ R=${GRAFT_REPO_ROOT:-/root/repo}
 OUT=$R/gpurun_out/prof_$TAG
 mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
-ARGS="--steps 5 --warmup 1 --weak-blocks 0 --no-cpu-baseline --no-live-traffic --no-e2e --soak-seconds 0 --no-dist $@"
+ARGS="--steps 20 --warmup 5 --weak-blocks 0 --no-cpu-baseline --no-live-traffic --no-e2e --soak-seconds 0 --no-dist $@"
 (cd $R && python -c "import bench; print(bench.kernel_source_sha())") > $OUT/kernel_source_sha.txt  # what the counters belong to
 echo "bench.py $ARGS" > $OUT/command.txt
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace -o t -- python $R/bench.py $ARGS > $OUT/bench_traced.log 2>&1
