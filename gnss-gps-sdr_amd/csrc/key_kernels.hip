@@ -26,19 +26,20 @@ __global__ void k_pack_keys(const Peak* peaks, unsigned long long* keys, int n, 
 
 // gpsacq_peak_keys_device(per_prn): peaks -> the 32 per-PRN best keys in ONE launch (reference schedule, task t <-> PRN t % 32):
 // what a rank of the block decomposition hands to the all-reduce (bench.py's step = one search + this + one all-reduce).
-// One workgroup; thread (r, sv) strides over the runs; n_tasks == 0 leaves 32 zero keys (neutral for MAX).
-__global__ __launch_bounds__(WG) void k_prn_keys(const Peak* peaks, int n_tasks, int kmax, unsigned long long* best) {
-    __shared__ unsigned long long part[WG];
+// One workgroup of 1024; thread (r, sv) strides over the runs; n_tasks == 0 leaves 32 zero keys (neutral for MAX).
+constexpr int KEYS_WG = 1024;  // 32 PRNs x 32 runs in flight: the kernel sits on the engine's stream between two searches
+__global__ __launch_bounds__(KEYS_WG) void k_prn_keys(const Peak* peaks, int n_tasks, int kmax, unsigned long long* best) {
+    __shared__ unsigned long long part[KEYS_WG];
     const int sv = threadIdx.x & 31, lane_run = threadIdx.x >> 5;
     unsigned long long k = 0;
-    for (int t = lane_run * 32 + sv; t < n_tasks; t += WG) {
+    for (int t = lane_run * 32 + sv; t < n_tasks; t += KEYS_WG) {
         const unsigned long long kt = peak_key(peaks[t], kmax);
         k = kt > k ? kt : k;
     }
     part[threadIdx.x] = k;
     __syncthreads();
     if (threadIdx.x < 32) {
-        for (int r = 1; r < WG / 32; ++r) k = part[r * 32 + sv] > k ? part[r * 32 + sv] : k;
+        for (int r = 1; r < KEYS_WG / 32; ++r) k = part[r * 32 + sv] > k ? part[r * 32 + sv] : k;
         best[sv] = k;
     }
 }
@@ -102,7 +103,7 @@ void launch_pack_keys(const Peak* peaks, unsigned long long* keys, int n, int km
     hipLaunchKernelGGL(k_pack_keys, dim3((n + 255) / 256), dim3(256), 0, s, peaks, keys, n, kmax);
 }
 void launch_prn_keys(const Peak* peaks, int n_tasks, int kmax, unsigned long long* best, hipStream_t s) {
-    hipLaunchKernelGGL(k_prn_keys, dim3(1), dim3(WG), 0, s, peaks, n_tasks, kmax, best);
+    hipLaunchKernelGGL(k_prn_keys, dim3(1), dim3(KEYS_WG), 0, s, peaks, n_tasks, kmax, best);
 }
 void launch_prn_best(const unsigned long long* keys, const Peak* peaks, int n_tasks, unsigned long long* best, float* best_pwr, hipStream_t s) {
     hipLaunchKernelGGL(k_prn_best, dim3(1), dim3(WG), 0, s, keys, peaks, n_tasks, best, best_pwr);
