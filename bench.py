@@ -281,19 +281,15 @@ PARITY_PWR_REL = 2e-5   # what the GPU suite asserts per cell (tests/test_gpu_pa
 PARITY_TIE_REL = 1e-5   # two candidates closer than this in the double-precision oracle are a float-rounding tie
 
 
-def parity_vs_gpu(cfg, eng, torch, d_bits, nblk, stride, gpu_peaks, cpu_peaks, host_bits, seed=5):
-    """The timed step's own results against the oracle (test infrastructure; c/search_offline.cpp:190-198,248), AFTER the timed
-    region: (1) the GPU's peak of every block the cpu_baseline leg pushed through the oracle's float build -- same capture, same
-    blocks, reference schedule block -> PRN block % 32 -- must carry the same ca_shift and lo_shift and an SNR within 1e-4; a
-    different (lo, ca) is accepted only as a PROVEN tie: in the double-precision oracle the two candidates' SNRs agree to 1e-5.
-    (2) three seeded random (block, PRN) rows of the WHOLE capture, all Doppler bins, cell by cell against liboracle_f64:
-    max_pwr / tot_pwr to 2e-5, the lag identical or a proven tie."""
-    import ctypes
-    from oracle_lib import CELL_DTYPE, PEAK_DTYPE, Oracle, _p
+def compare_peaks(cfg, gpu_peaks, cpu_peaks, host_bits):
+    """Part (1) of parity_vs_gpu, host only: the GPU's peaks against the oracle's for the same blocks of the same capture (reference
+    schedule: block b against PRN b % 32).  Returns (dict, oracle_f64, lag_powers) -- the double-precision oracle and its per-lag
+    power probe are reused by part (2)."""
+    from oracle_lib import Oracle, _p
     n = min(len(cpu_peaks), len(gpu_peaks))
     g, o = gpu_peaks[:n], cpu_peaks[:n]
     orc = Oracle(cfg["fc"], cfg["fs"], cfg["max_fo"], kind="f64")
-    S, dmax = orc.num_lags, orc.dmax
+    S = orc.num_lags
 
     def lag_powers(block_bytes, sv, lo):
         orc.L.oracle_sample(orc.h, _p(np.ascontiguousarray(block_bytes)))
@@ -307,6 +303,9 @@ def parity_vs_gpu(cfg, eng, torch, d_bits, nblk, stride, gpu_peaks, cpu_peaks, h
         blk = np.frombuffer(host_bits, dtype=np.uint8)[b * 5120:(b + 1) * 5120]
         snr2 = []
         for pk in (g[b], o[b]):
+            if not (-orc.dmax <= int(pk["lo_shift"]) <= orc.dmax and 0 <= int(pk["ca_shift"]) < S):
+                snr2.append(float("nan"))  # a result outside the search grid is never a tie
+                continue
             pw = lag_powers(blk, int(b) % 32, pk["lo_shift"])
             snr2.append(float(pw[pk["ca_shift"]]) / (float(pw.sum(dtype=np.float64)) / S))
         if abs(snr2[0] - snr2[1]) <= PARITY_TIE_REL * snr2[1]:
@@ -316,6 +315,20 @@ def parity_vs_gpu(cfg, eng, torch, d_bits, nblk, stride, gpu_peaks, cpu_peaks, h
     with np.errstate(divide="ignore", invalid="ignore"):
         snr_rel = np.abs(g["snr"].astype(np.float64) / o["snr"].astype(np.float64) - 1.0)
     snr_max_rel = float(np.nanmax(snr_rel)) if n else 0.0
+    return ({"blocks": int(n), "ca_equal": int(ca_eq.sum()), "lo_equal": int(lo_eq.sum()), "proven_ties": ties, "unproven_mismatches": unproven[:8],
+             "n_unproven": len(unproven), "snr_max_rel": snr_max_rel}, orc, lag_powers)
+
+
+def parity_vs_gpu(cfg, eng, torch, d_bits, nblk, stride, gpu_peaks, cpu_peaks, host_bits, seed=5):
+    """The timed step's own results against the oracle (test infrastructure; c/search_offline.cpp:190-198,248), AFTER the timed
+    region: (1) the GPU's peak of every block the cpu_baseline leg pushed through the oracle's float build -- same capture, same
+    blocks, reference schedule block -> PRN block % 32 -- must carry the same ca_shift and lo_shift and an SNR within 1e-4; a
+    different (lo, ca) is accepted only as a PROVEN tie: in the double-precision oracle the two candidates' SNRs agree to 1e-5.
+    (2) three seeded random (block, PRN) rows of the WHOLE capture, all Doppler bins, cell by cell against liboracle_f64:
+    max_pwr / tot_pwr to 2e-5, the lag identical or a proven tie."""
+    from oracle_lib import CELL_DTYPE
+    part1, orc, lag_powers = compare_peaks(cfg, gpu_peaks, cpu_peaks, host_bits)
+    dmax = orc.dmax
     # (2) full rows of cells: GPU cells of three tasks through the same C ABI, device-resident capture
     rng = np.random.default_rng(seed)
     rows = sorted(int(b) for b in rng.choice(nblk, size=min(3, nblk), replace=False))
@@ -339,9 +352,9 @@ def parity_vs_gpu(cfg, eng, torch, d_bits, nblk, stride, gpu_peaks, cpu_peaks, h
                 lag_ties += 1
             else:
                 lag_bad.append([int(b), int(d) - dmax])
-    ok = (not unproven) and snr_max_rel <= PARITY_SNR_REL and pwr_max_rel <= PARITY_PWR_REL and not lag_bad
-    return {"ok": bool(ok), "blocks": int(n), "ca_equal": int(ca_eq.sum()), "lo_equal": int(lo_eq.sum()), "proven_ties": ties,
-            "unproven_mismatches": unproven[:8], "snr_max_rel": snr_max_rel, "cells": int(cells), "cell_rows_block_prn": [[b, b % 32] for b in rows],
+    ok = part1["n_unproven"] == 0 and part1["snr_max_rel"] <= PARITY_SNR_REL and pwr_max_rel <= PARITY_PWR_REL and not lag_bad
+    return {"ok": bool(ok), "blocks": part1["blocks"], "ca_equal": part1["ca_equal"], "lo_equal": part1["lo_equal"], "proven_ties": part1["proven_ties"],
+            "unproven_mismatches": part1["unproven_mismatches"], "snr_max_rel": part1["snr_max_rel"], "cells": int(cells), "cell_rows_block_prn": [[b, b % 32] for b in rows],
             "pwr_max_rel": pwr_max_rel, "cell_lag_ties": lag_ties, "cell_lag_mismatches": lag_bad[:8],
             "tolerances": {"snr_rel": PARITY_SNR_REL, "pwr_rel": PARITY_PWR_REL, "tie_rel": PARITY_TIE_REL},
             "what": "GPU peaks of the LAST TIMED STEP vs the oracle's float build on the blocks the cpu_baseline leg searched (ca_shift / lo_shift equal "

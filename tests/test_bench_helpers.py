@@ -57,3 +57,30 @@ def test_flops_and_peak_constants():
     assert abs(b.flops_per_cell(5456) - (6 * 40000 + 5 * 40000 * 15.287712379549449 + 5 * 5456)) < 1.0
     # 157.3 TFLOP/s = 256 CUs x 128 FMA lanes x 2 flop x 2.4 GHz: the clock frac_at_clock normalises to
     assert abs(256 * 128 * 2 * b.FP32_PEAK_CLOCK_MHZ * 1e6 / 1e12 - b.FP32_VALU_PEAK_TF) < 0.05
+
+
+def test_compare_peaks_verdict_logic(monkeypatch):
+    """The host half of cpu_baseline.parity_vs_gpu on the oracle alone (no GPU): the double-precision oracle's peaks stand in for the
+    GPU's.  Equal results pass; a peak moved to another lag is an UNPROVEN mismatch (the bench run then exits 3); the same move is
+    accepted as a tie only when the two candidates' double-precision SNRs agree to the tie tolerance (forced here by widening it);
+    a result outside the search grid is never a tie."""
+    import numpy as np
+    from oracle_lib import Oracle
+    b = _bench()
+    cfg = b.CONFIGS[1]
+    bits = np.frombuffer(open(os.path.join(ROOT, "tests", "golden", "synth_nott_fs5456.bin"), "rb").read()[:6 * 5120], dtype=np.uint8)
+    _, cpu = Oracle(cfg["fc"], cfg["fs"], cfg["max_fo"], kind="f32").bench_blocks(bits, 6)
+    _, gpu = Oracle(cfg["fc"], cfg["fs"], cfg["max_fo"], kind="f64").search(bits.tobytes())
+    r, _, _ = b.compare_peaks(cfg, gpu, cpu, bits)
+    assert r["blocks"] == 6 and r["ca_equal"] == 6 and r["lo_equal"] == 6 and r["n_unproven"] == 0 and r["snr_max_rel"] < 1e-4
+    moved = gpu.copy()
+    moved["ca_shift"][3] = (moved["ca_shift"][3] + 7) % 5456
+    r, _, _ = b.compare_peaks(cfg, moved, cpu, bits)
+    assert r["ca_equal"] == 5 and r["unproven_mismatches"] == [3] and r["proven_ties"] == 0
+    monkeypatch.setattr(b, "PARITY_TIE_REL", 10.0)  # "anything is a tie": the proven-tie branch itself
+    r, _, _ = b.compare_peaks(cfg, moved, cpu, bits)
+    assert r["proven_ties"] == 1 and r["n_unproven"] == 0
+    off_grid = gpu.copy()
+    off_grid["lo_shift"][2] = 500
+    r, _, _ = b.compare_peaks(cfg, off_grid, cpu, bits)
+    assert r["unproven_mismatches"] == [2]
