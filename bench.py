@@ -38,7 +38,9 @@ The line verifies itself and is comparable across boxes (round 5):
         (or a tie proven in the double-precision oracle) and an SNR within 1e-4, and three seeded random full rows of cells of the
         whole capture must agree with liboracle_f64 to 2e-5 (c/search_offline.cpp:190-198,248).  Flat copies (parity_ok,
         parity_blocks, ...) sit beside it.  A disagreement makes the run EXIT 3 after the line is printed.
-  roofline.sclk_mhz / power_w   median of sysfs readings (pp_dpm_sclk, hwmon power1) taken every 100 ms DURING the K timed steps
+  roofline.sclk_mhz / power_w   the clock over the K timed steps from the GPU's own cycle counters (s_memtime of all 8 XCDs, stamped on the
+        engine's stream before and after; mean over the XCDs -- they run up to 5 % apart under the power cap: sclk_mhz_xcd_min / _max),
+        with the sysfs readings (pp_dpm_sclk -- XCD 0's clock --, hwmon power1; every 100 ms during the steps) beside it
   roofline.cycles_per_cell_per_cu = kernel_ms x sclk x CUs / cells, roofline.frac_at_clock = achieved / (157.3 TFLOP/s x sclk / 2.4 GHz)
   roofline.pk_fma_stream_TF     a pure v_pk_fma_f32 stream at k_corr's residency for 3 s in the untimed part (gnss-gps-sdr_amd/bin/
         pk_fma_stream): what the fp32 vector pipe sustains on this box, next to the datasheet's 157.3
@@ -606,9 +608,9 @@ class Leg:
         if self.sampler is not None:
             self.sampler.start()
             if self.n_tasks > 0:  # shader-cycle stamps + HIP events on the engine's stream around the timed steps: the clock the GPU itself counted
-                stamps = torch.zeros(2, dtype=torch.int64, device=self.dev)
+                stamps = torch.zeros((2, 8), dtype=torch.int64, device=self.dev)  # [before / after][XCD]
                 ev = [torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)]
-                self.eng.cycle_stamp_device(stamps[0:1].data_ptr())
+                self.eng.cycle_stamp_device(stamps[0].data_ptr())
                 ev[0].record(self.eng_stream)
         t0 = time.perf_counter()
         for i in range(steps):
@@ -622,16 +624,19 @@ class Leg:
             corr_ms.append(tm["ms_correlate"])
             self.sample_ms.append(tm["ms_sample"])
         if stamps is not None:
-            self.eng.cycle_stamp_device(stamps[1:2].data_ptr())
+            self.eng.cycle_stamp_device(stamps[1].data_ptr())
             ev[1].record(self.eng_stream)
         self.fence()
         elapsed = time.perf_counter() - t0
-        self.memtime_mhz = None
+        self.memtime_mhz = self.memtime_per_xcd = None
         if stamps is not None:
             st = stamps.cpu().tolist()
             ms = ev[0].elapsed_time(ev[1])
-            mhz = (st[1] - st[0]) / (ms * 1e3) if ms > 0 else 0.0
-            self.memtime_mhz = mhz if 300.0 < mhz < 4000.0 else None  # (two stamps from different counters would not land here)
+            # per XCD: its own counter, its own clock (an XCD no stamp workgroup reached keeps a zero and is left out)
+            per_xcd = [(b - a) / (ms * 1e3) if (ms > 0 and a > 0 and b > a) else None for a, b in zip(st[0], st[1])]
+            good = [m for m in per_xcd if m is not None and 300.0 < m < 4000.0]
+            self.memtime_per_xcd = [round(m, 1) if m is not None else None for m in per_xcd]
+            self.memtime_mhz = float(np.mean(good)) if len(good) >= 4 else None  # the chip's clock: the mean over its XCDs
         if self.sampler is not None:
             self.sampler.stop()
         t = torch.tensor([elapsed], dtype=torch.float64, device=self.dev if self.backend == "nccl" else "cpu")
@@ -925,14 +930,18 @@ def main():
     timing = eng.last_timing() if n_tasks > 0 else None
     clock = leg.sampler.stats() if leg.sampler is not None else None
     if clock is not None:
-        # the clock of the roofline: the GPU's own cycle count over the timed steps (s_memtime stamps / HIP events on the engine's stream);
-        # the sysfs readings (a firmware average that lags by about a second) stay beside it and take over only if the stamps are unusable
+        # the clock of the roofline: the GPU's own cycle counts over the timed steps (s_memtime stamps of all 8 XCDs / HIP events on the
+        # engine's stream), averaged over the XCDs -- under the power cap they run up to 5 % apart, and the sysfs reading follows XCD 0
+        # alone (profiles/r05_experiments/e_xcd_clocks.log).  The sysfs readings stay beside it and take over only if the stamps are unusable
         clock["sclk_mhz_sysfs"] = clock["sclk_mhz"]
         mt = getattr(leg, "memtime_mhz", None)
         clock["sclk_mhz_cycle_counter"] = mt
+        clock["sclk_mhz_per_xcd"] = getattr(leg, "memtime_per_xcd", None)
+        good = [m for m in (clock["sclk_mhz_per_xcd"] or []) if m]
+        clock["sclk_mhz_xcd_min_max"] = [min(good), max(good)] if good else None
         if mt:
             clock["sclk_mhz"] = mt
-            clock["source"] = "shader-cycle counter (s_memtime stamps around the timed steps / HIP-event time between them); sysfs beside it: " + clock["source"]
+            clock["source"] = "shader-cycle counters of the 8 XCDs, mean (s_memtime stamps around the timed steps / HIP-event time between them); sysfs beside it: " + clock["source"]
     leg.sampler = None
     # the peaks of the LAST TIMED STEP, kept for the parity verdict (cpu_baseline.parity_vs_gpu) before any other leg runs
     gpu_peaks = None
@@ -1060,7 +1069,9 @@ def main():
                          "kernel_ms": kern_ms, "cells_per_launch": cells_rank,
                          "kernel_cells_per_s": cells_rank / (kern_ms * 1e-3) if kern_ms else None,
                          # clock / power read during the K timed steps; cycles = kernel_ms x sclk x CUs / cells
-                         "sclk_mhz": sclk, "power_w": clock["power_w"] if clock else None, "compute_units": eng.compute_units,
+                         "sclk_mhz": sclk, "sclk_mhz_xcd_min": (clock.get("sclk_mhz_xcd_min_max") or [None])[0] if clock else None,
+                         "sclk_mhz_xcd_max": (clock.get("sclk_mhz_xcd_min_max") or [None, None])[1] if clock else None,
+                         "power_w": clock["power_w"] if clock else None, "compute_units": eng.compute_units,
                          "cycles_per_cell_per_cu": cyc_cell_cu, "frac_at_clock": frac_at_clock, "peak_clock_mhz": FP32_PEAK_CLOCK_MHZ,
                          # a pure v_pk_fma_f32 stream on this box (3 waves per SIMD like k_corr, a few seconds): the pipe's practical ceiling
                          "pk_fma_stream_TF": pk_tf, "frac_of_pk_fma_stream": (achieved_tf / pk_tf) if pk_tf else None,

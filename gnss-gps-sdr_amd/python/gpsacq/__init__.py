@@ -403,7 +403,8 @@ class Engine:
                                                             d_keys_ptr, 1 if sync else 0))
 
     def cycle_stamp_device(self, d_stamp_ptr, sync=False):
-        """gpsacq_cycle_stamp_device: the shader-cycle counter written to 8 bytes of device memory, on the engine's stream."""
+        """gpsacq_cycle_stamp_device: the shader-cycle counters of the 8 XCDs written to d_stamp[XCC id] (8 x 8 bytes of device memory),
+        on the engine's stream."""
         _check(self._lib, self._lib.gpsacq_cycle_stamp_device(self._h, d_stamp_ptr, 1 if sync else 0))
 
     def synchronize(self):

@@ -46,6 +46,9 @@ def test_default_line_carries_its_own_parity_verdict_and_clock():
     assert cs["samples"] >= 1 and cs["sclk_mhz_sysfs"] is not None, cs
     # the roofline's clock is the GPU's own cycle count over the timed steps (gpsacq_cycle_stamp_device), not the lagging sysfs average
     assert cs["sclk_mhz_cycle_counter"] == rf["sclk_mhz"] and 500 <= rf["sclk_mhz"] <= 2500, cs
+    per = cs["sclk_mhz_per_xcd"]  # every XCD has its own counter and clock: all eight stamped, within 15 % of each other
+    assert len(per) == 8 and all(p is not None for p in per) and max(per) / min(per) < 1.15, per
+    assert rf["sclk_mhz_xcd_min"] == min(per) and rf["sclk_mhz_xcd_max"] == max(per) and min(per) <= rf["sclk_mhz"] <= max(per)
     assert rf["power_w"] is None or rf["power_w"] > 50
     want = rf["kernel_ms"] * 1e-3 * rf["sclk_mhz"] * 1e6 * rf["compute_units"] / rf["cells_per_launch"]
     assert abs(rf["cycles_per_cell_per_cu"] / want - 1) < 1e-9 and 10000 < rf["cycles_per_cell_per_cu"] < 100000

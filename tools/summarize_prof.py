@@ -40,11 +40,11 @@ for name, what in (("bench_traced.log", "traced"), ("bench_unprofiled.log", "un-
                 lines += [f"bench line of the {what} run of the same command: " + json.dumps(
                     {"value": j.get("value"), "ms_per_step": j.get("ms_per_step"), "stage_ms": j.get("stage_ms"),
                      "roofline": {k: r.get(k) for k in ("bound", "kernel", "achieved", "peak", "unit", "frac", "kernel_ms", "cells_per_launch", "flops_per_cell",
-                                                        "sclk_mhz", "power_w", "cycles_per_cell_per_cu", "frac_at_clock")}}), ""]
+                                                        "sclk_mhz", "sclk_mhz_xcd_min", "sclk_mhz_xcd_max", "power_w", "cycles_per_cell_per_cu", "frac_at_clock")}}), ""]
                 r = dict(r, compute_units=r.get("compute_units", 256))
                 if r.get("sclk_mhz") and r.get("cycles_per_cell_per_cu"):
-                    clock_lines.append(f"- {what} run, HIP events: kernel_ms {r['kernel_ms']:.3f} x sclk {r['sclk_mhz']:.0f} MHz (the GPU's cycle counter over the timed steps, gpsacq_cycle_stamp_device; "
-                                       f"sysfs median {(r.get('clock_sampling') or {}).get('sclk_mhz_sysfs')} MHz, {r.get('power_w')} W) x {r.get('compute_units')} CUs / {r['cells_per_launch']} cells = **{r['cycles_per_cell_per_cu']:.0f} cycles per cell per CU**, "
+                    clock_lines.append(f"- {what} run, HIP events: kernel_ms {r['kernel_ms']:.3f} x sclk {r['sclk_mhz']:.0f} MHz (mean of the 8 XCDs' cycle counters over the timed steps, gpsacq_cycle_stamp_device: "
+                                       f"{(r.get('clock_sampling') or {}).get('sclk_mhz_per_xcd')}; sysfs = XCD 0: {(r.get('clock_sampling') or {}).get('sclk_mhz_sysfs')} MHz, {r.get('power_w')} W) x {r.get('compute_units')} CUs / {r['cells_per_launch']} cells = **{r['cycles_per_cell_per_cu']:.0f} cycles per cell per CU**, "
                                        f"frac {r['frac']:.4f} of 157.3 TFLOP/s, **frac_at_clock {r['frac_at_clock']:.4f}**")
                     if what == "traced" and os.path.exists(ks):
                         for row in csv.DictReader(open(ks)):
