@@ -216,6 +216,27 @@ def read_clock_power(card):
     return out
 
 
+STAMP_SLOTS = 512  # gpsacq.h GPSACQ_STAMP_SLOTS
+
+
+def cu_clocks(stamps, ms):
+    """stamps[2][STAMP_SLOTS]: every compute unit's shader-cycle counter before / after a stretch of busy work (gpsacq_cycle_stamp_device;
+    slot = xcc << 6 | se << 4 | cu, 0 = not reached), ms: the time between the two stamp kernels.  Each CU's counter has its own offset
+    and stands still while the CU is gated, so only same-slot differences count.  Returns (chip MHz = mean of the per-XCD medians,
+    [per-XCD median MHz], CUs that gave a reading); (None, None, n) when fewer than half of the XCDs can be read."""
+    a, b = stamps[0].astype(np.int64), stamps[1].astype(np.int64)
+    ok = (a > 0) & (b > a) & (ms > 0)
+    mhz = np.where(ok, (b - a) / max(ms * 1e3, 1e-9), np.nan)
+    mhz[(mhz < 300.0) | (mhz > 4000.0)] = np.nan
+    per_xcd = []
+    for x in range(8):
+        v = mhz[64 * x:64 * (x + 1)]
+        v = v[~np.isnan(v)]
+        per_xcd.append(round(float(np.median(v)), 1) if v.size >= 4 else None)
+    good = [m for m in per_xcd if m is not None]
+    return (float(np.mean(good)) if len(good) >= 4 else None), (per_xcd if good else None), int(np.count_nonzero(~np.isnan(mhz)))
+
+
 class ClockSampler:
     """sclk / power readings every `period` seconds from a thread while a leg runs (sysfs; falls back to ONE rocm-smi call in
     mid-leg when sysfs has no clock file).  stats(): medians over the readings taken between start() and stop()."""
@@ -608,7 +629,7 @@ class Leg:
         if self.sampler is not None:
             self.sampler.start()
             if self.n_tasks > 0:  # shader-cycle stamps + HIP events on the engine's stream around the timed steps: the clock the GPU itself counted
-                stamps = torch.zeros((2, 8), dtype=torch.int64, device=self.dev)  # [before / after][XCD]
+                stamps = torch.zeros((2, STAMP_SLOTS), dtype=torch.int64, device=self.dev)  # [before / after][xcc << 6 | se << 4 | cu]
                 ev = [torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)]
                 self.eng.cycle_stamp_device(stamps[0].data_ptr())
                 ev[0].record(self.eng_stream)
@@ -628,15 +649,10 @@ class Leg:
             ev[1].record(self.eng_stream)
         self.fence()
         elapsed = time.perf_counter() - t0
-        self.memtime_mhz = self.memtime_per_xcd = None
+        self.memtime_mhz = self.memtime_per_xcd = self.memtime_cus = None
         if stamps is not None:
-            st = stamps.cpu().tolist()
             ms = ev[0].elapsed_time(ev[1])
-            # per XCD: its own counter, its own clock (an XCD no stamp workgroup reached keeps a zero and is left out)
-            per_xcd = [(b - a) / (ms * 1e3) if (ms > 0 and a > 0 and b > a) else None for a, b in zip(st[0], st[1])]
-            good = [m for m in per_xcd if m is not None and 300.0 < m < 4000.0]
-            self.memtime_per_xcd = [round(m, 1) if m is not None else None for m in per_xcd]
-            self.memtime_mhz = float(np.mean(good)) if len(good) >= 4 else None  # the chip's clock: the mean over its XCDs
+            self.memtime_mhz, self.memtime_per_xcd, self.memtime_cus = cu_clocks(stamps.cpu().numpy(), ms)
         if self.sampler is not None:
             self.sampler.stop()
         t = torch.tensor([elapsed], dtype=torch.float64, device=self.dev if self.backend == "nccl" else "cpu")
@@ -937,11 +953,12 @@ def main():
         mt = getattr(leg, "memtime_mhz", None)
         clock["sclk_mhz_cycle_counter"] = mt
         clock["sclk_mhz_per_xcd"] = getattr(leg, "memtime_per_xcd", None)
+        clock["cycle_counter_cus"] = getattr(leg, "memtime_cus", None)
         good = [m for m in (clock["sclk_mhz_per_xcd"] or []) if m]
         clock["sclk_mhz_xcd_min_max"] = [min(good), max(good)] if good else None
         if mt:
             clock["sclk_mhz"] = mt
-            clock["source"] = "shader-cycle counters of the 8 XCDs, mean (s_memtime stamps around the timed steps / HIP-event time between them); sysfs beside it: " + clock["source"]
+            clock["source"] = "shader-cycle counters of every CU (s_memtime stamps around the timed steps / HIP-event time between them): mean of the per-XCD medians; sysfs beside it: " + clock["source"]
     leg.sampler = None
     # the peaks of the LAST TIMED STEP, kept for the parity verdict (cpu_baseline.parity_vs_gpu) before any other leg runs
     gpu_peaks = None

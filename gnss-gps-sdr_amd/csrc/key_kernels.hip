@@ -5,6 +5,7 @@
 // kernel_source_sha) only moves when those kernels do.
 #include <hip/hip_runtime.h>
 
+#include "../../include/gpsacq.h"
 #include "acq_launch.hpp"
 
 namespace acq {
@@ -91,19 +92,19 @@ __global__ void k_peak_pwr(const Peak* peaks, float* pwr, int n) {
     if (i < n) pwr[i] = peaks[i].max_pwr;
 }
 
-// gpsacq_cycle_stamp_device: the shader-cycle counter (s_memtime: one tick per shader clock) of each of the 8 XCDs, written to
-// out[XCC_ID].  Every XCD has its own counter and -- under the package's power management -- its own clock: one XCD's stamps alone
-// are not the chip's clock (measured: XCD 0 at 2378 MHz while the average sat at 2250).  64 one-thread workgroups are dealt round
-// robin over the XCDs, each writes its XCD's slot (several writers per slot, a few cycles apart: immaterial over a timed region).
-// Two calls around a stretch of work, divided by the time between them (HIP events at the same two points of the stream), give
-// the average clock each XCD held in between, measured by the GPU, no firmware averaging window in the way.
+// gpsacq_cycle_stamp_device: the shader-cycle counter (s_memtime) of every compute unit, written to out[__smid()] -- slot =
+// XCC_ID << 6 | SE_ID << 4 | CU_ID (512 slots).  The counter is PER COMPUTE UNIT: each CU's starts from its own offset (two CUs
+// of one XCD read values tens of millions of ticks apart) and stands still while the CU is clock-gated, so only two readings of
+// the SAME CU make a difference that means anything.  4096 single-wave workgroups reach every CU of an idle or a busy GPU; the
+// waves that land on one CU write the same counter a few cycles apart.  Two calls around a stretch of work that keeps the CUs
+// busy, divided by the time between them (HIP events at the same two points of the stream), give the average clock each CU
+// held in between -- measured by the GPU, no firmware averaging window in the way.
 __global__ void k_cycle_stamp(unsigned long long* out) {
-    const unsigned xcc = __builtin_amdgcn_s_getreg((3 << 11) | 20) & 7u;  // HW_REG_XCC_ID (id 20), bits 3:0
-    out[xcc] = __builtin_amdgcn_s_memtime();
+    if (threadIdx.x == 0) out[__smid() & (GPSACQ_STAMP_SLOTS - 1)] = __builtin_amdgcn_s_memtime();
 }
 
 // launchers (host)
-void launch_cycle_stamp(unsigned long long* out, hipStream_t s) { hipLaunchKernelGGL(k_cycle_stamp, dim3(64), dim3(1), 0, s, out); }
+void launch_cycle_stamp(unsigned long long* out, hipStream_t s) { hipLaunchKernelGGL(k_cycle_stamp, dim3(4096), dim3(64), 0, s, out); }
 void launch_pack_keys(const Peak* peaks, unsigned long long* keys, int n, int kmax, hipStream_t s) {
     hipLaunchKernelGGL(k_pack_keys, dim3((n + 255) / 256), dim3(256), 0, s, peaks, keys, n, kmax);
 }

@@ -18,6 +18,7 @@ FFT_LEN = 40000
 NUM_SATS = 32
 BLOCK_BYTES = 5120
 THRESHOLD = 25.0  # c/search_offline.cpp:248
+STAMP_SLOTS = 512  # GPSACQ_STAMP_SLOTS: one cycle-counter slot per (XCD, shader engine, compute unit)
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("GPSACQ_LIB") or os.path.normpath(os.path.join(_HERE, "..", "..", "lib", "libgpsacq.so"))
@@ -403,8 +404,8 @@ class Engine:
                                                             d_keys_ptr, 1 if sync else 0))
 
     def cycle_stamp_device(self, d_stamp_ptr, sync=False):
-        """gpsacq_cycle_stamp_device: the shader-cycle counters of the 8 XCDs written to d_stamp[XCC id] (8 x 8 bytes of device memory),
-        on the engine's stream."""
+        """gpsacq_cycle_stamp_device: every compute unit's shader-cycle counter written to d_stamp[xcc << 6 | se << 4 | cu]
+        (STAMP_SLOTS x 8 bytes of zeroed device memory), on the engine's stream."""
         _check(self._lib, self._lib.gpsacq_cycle_stamp_device(self._h, d_stamp_ptr, 1 if sync else 0))
 
     def synchronize(self):

@@ -249,11 +249,12 @@ GPSACQ_API int gpsacq_last_timing(const gpsacq_engine* e, gpsacq_timing* t);
  * that enqueues searches with sync = 0 read a finished search's times while the next one runs */
 GPSACQ_API int gpsacq_timing_ago(const gpsacq_engine* e, int n_back, gpsacq_timing* t);
 /* Measurement aid next to gpsacq_last_timing (no reference counterpart): enqueues, on the engine's stream, a small kernel that writes
- * the shader-cycle counter (s_memtime) of each of the GPU's 8 XCDs to d_stamp[XCC id] (device memory, GPSACQ_NUM_XCDS x 8 bytes; zero it
- * first: an XCD that was not reached leaves its slot alone).  Two calls around a stretch of work, divided by the time between them, give
- * the average shader clock every XCD held over that stretch -- what bench.py's box-independent roofline (cycles per cell) is made of;
- * the XCDs of one package do not run at one clock under the power cap. */
-#define GPSACQ_NUM_XCDS 8
+ * the shader-cycle counter (s_memtime) of every compute unit to d_stamp[XCC id << 6 | SE id << 4 | CU id] (device memory,
+ * GPSACQ_STAMP_SLOTS x 8 bytes; zero it first: a slot no wave reached keeps its zero).  The counter is per compute unit -- its own
+ * offset, and it stands still while the CU is clock-gated -- so only differences of the same slot mean anything.  Two calls around
+ * a stretch of work that keeps the CUs busy, divided by the time between them, give the average shader clock every CU held over
+ * that stretch: what bench.py's box-independent roofline (cycles per cell) is made of. */
+#define GPSACQ_STAMP_SLOTS 512
 GPSACQ_API int gpsacq_cycle_stamp_device(gpsacq_engine* e, void* d_stamp, int sync);
 /* the engine's HIP stream (a hipStream_t) for callers that order their own device work after an
  * asynchronous gpsacq_*_device call with an event instead of a host wait; NULL for a NULL engine */
