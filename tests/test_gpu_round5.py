@@ -149,3 +149,19 @@ def test_headline_size_properties_on_the_device_path():
     # per cent for a random seed -- the seed is fixed, but the bound leaves that much room instead of asserting a coin flip
     noise = peaks[:, absent]["snr"]
     assert (noise >= 25).sum() <= 1 and noise.max() < 30, float(noise.max())
+
+
+def test_parity_verdict_on_the_references_own_capture(golden_dir):
+    """`bench.py --config 2 --capture gps_sig_tmp.bin` with the CPU baseline on: the verdict covers every one of the 384 blocks of the
+    reference-held file (12 runs x 32 PRN x 49 bins at fs 8.184 MHz, 8184 lags; the k_corr<33> instance) -- same code phase and Doppler
+    bin as the oracle in all of them, three rows of cells to 2e-5 -- and PRN 8 is the file's satellite (README.md:45,57)."""
+    r = _run_bench("--config", "2", "--capture", os.path.join(golden_dir, "gps_sig_tmp.bin"), "--steps", "2", "--warmup", "1", "--no-e2e",
+                   "--no-live-traffic", "--soak-seconds", "0", "--weak-blocks", "0")
+    assert r.returncode == 0, r.stderr[-3000:]
+    j = _line(r)
+    par = j["cpu_baseline"]["parity_vs_gpu"]
+    assert par["ok"] is True and par["blocks"] == 384 and par["ca_equal"] + par["proven_ties"] == 384 and par["cells"] == 3 * 49
+    assert par["snr_max_rel"] <= 1e-4 and par["pwr_max_rel"] <= 2e-5
+    best = {d["prn"]: d for d in j["detected"]}
+    assert 8 in best and best[8]["lo_shift"] == 0 and best[8]["snr"] > 500
+    assert j["roofline"]["kernel"] == "k_corr<33>"
