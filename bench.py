@@ -153,6 +153,12 @@ def soak(leg, cells_job, min_gpu_s=6.0, max_steps=2000):
     readings = []
     th = None
     done_s, steps, slices = 0.0, 0, []
+    torch = leg.torch
+    stamps = torch.zeros((2, STAMP_SLOTS), dtype=torch.int64, device=leg.dev)  # every CU's cycle counter around the whole leg
+    ev = [torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)]
+    leg.fence()
+    leg.eng.cycle_stamp_device(stamps[0].data_ptr())
+    ev[0].record(leg.eng_stream)
     while done_s < min_gpu_s and steps < max_steps:
         n = 20
         leg.fence()
@@ -169,9 +175,14 @@ def soak(leg, cells_job, min_gpu_s=6.0, max_steps=2000):
         steps += n
     if th is not None:
         th.join()
+    leg.eng.cycle_stamp_device(stamps[1].data_ptr())
+    ev[1].record(leg.eng_stream)
+    leg.fence()
+    chip_mhz, per_xcd, _ = cu_clocks(stamps.cpu().numpy(), ev[0].elapsed_time(ev[1]))
     ms = 1e3 * done_s / max(steps, 1)
     return {"steps": steps, "seconds": done_s, "ms_per_step": ms, "cells_per_s": cells_job / (ms * 1e-3) if ms else None,
             "ms_per_step_slices_min_max": [min(slices), max(slices)] if slices else None,
+            "sclk_mhz": chip_mhz, "sclk_mhz_per_xcd": per_xcd,  # over the whole leg, from the CUs' own cycle counters (mean of the XCDs' medians)
             "smi_mid_leg": readings[0] if readings else None,
             "note": "same step as the timed region, repeated after it; reported separately, `steps`/`ms_per_step`/`value` are the K timed steps"}
 
