@@ -1,3 +1,6 @@
+"""tools/stamp_probe.py -- what gpsacq_cycle_stamp_device measures (GPU box): per-XCD clocks from the CUs' cycle counters over busy windows of
+1 .. 400 steps of a 640-block search, idle windows (the counters stand still), and two back-to-back stamps (a few thousand ticks on every CU).
+Output: profiles/r05_experiments/e_xcd_clocks.log, block 1."""
 import sys, os, time, json
 sys.path.insert(0, "gnss-gps-sdr_amd/python"); sys.path.insert(0, ".")
 import torch, gpsacq, numpy as np
