@@ -56,13 +56,7 @@ dropin-check: $(LIBDIR)/libgps_search.so
 	$(CXX) -O2 -I/root/reference/c /root/reference/c/test_search_offline.cpp -o oracle/_ref/gps_test_refmain \
 	    -L$(LIBDIR) -lgps_search -lgpsacq -Wl,-rpath,'$$ORIGIN/../../$(LIBDIR)'
 
-# The experiment library (not the product): libgpsacq with the 8-wave correlator k_corr8 (GPSACQ_CORR8=2|3) and the s_memtime phase
-# profiler of k_corr (GPSACQ_PROF=1) compiled in -- build/var_exp/libgpsacq.so, selected with GPSACQ_LIB= for A/B runs
-# (tools/check_corr8.py, tools/profile.sh).  profiles/r03_experiments/ holds what they measured.
-experiments:
-	bash tools/build_variant.sh exp -DACQ_EXPERIMENTS
-
 clean:
 	rm -rf $(LIBDIR) $(BINDIR) build tests/emul/libemul_acq.so
 	$(MAKE) -C oracle clean
-.PHONY: all lib host oracle emul clean dropin-check experiments
+.PHONY: all lib host oracle emul clean dropin-check

@@ -62,37 +62,19 @@ __device__ __forceinline__ void fwd_convert_iq8(int tid, const uint8_t* __restri
     }
 }
 
+// Float sources (init-time code replicas; multi-bit samples): plain pruned radix-8, forward direction, slot map LayA.
 template <int SRC>
 __global__ __launch_bounds__(WG) void k_fwd(FwdArgs a) {
-    constexpr bool BITS = SRC == SRC_BITS || SRC == SRC_IQ8;
+    static_assert(SRC == SRC_REAL || SRC == SRC_REALMIX, "k_fwd takes float sources; the 1-bit / IQ captures go through k_fwd2");
     __shared__ cf lds[M_SUB];
-    __shared__ uint64_t ib[BITS ? USED_BYTES / NPOLY : 1], qb[BITS ? USED_BYTES / NPOLY : 1];
-    __shared__ cf lut[BITS ? 256 : 1];
     const int tid = threadIdx.x, item = blockIdx.x;
-    const int srci = item / a.sub, r = item - srci * a.sub;
-    // once per workgroup: the bit-transposed block and the row-independent pass-1 twiddles
-    if (SRC == SRC_BITS) fwd_stage_bits(tid, (const uint8_t*)a.src + (size_t)srci * a.src_stride, a.cos_t, a.sin_t, ib, qb);
-    if (SRC == SRC_IQ8) {
-        uint8_t* stage = reinterpret_cast<uint8_t*>(lds);
-        fwd_convert_iq8(tid, (const uint8_t*)a.src + (size_t)srci * a.src_stride, a.iq_first + (size_t)srci * (a.src_stride / 2), a.iq_total, a.iq, stage);
-        __syncthreads();
-        fwd_stage_bits(tid, stage, a.cos_t, a.sin_t, ib, qb);
-    }
     cf w[2][RA - 1];
-    load_tw1(tid, a.t1, w);
+    load_tw1(tid, a.t1, w);  // row-independent pass-1 twiddles, once per workgroup
     for (int kappa = 0; kappa < NPOLY; ++kappa) {
-        const cf* tn_row = a.tn + ((size_t)r * NPOLY + kappa) * M_SUB;
-        if (BITS) {
-            fwd_build_lut(tid, a.rot8 + (r * NPOLY + kappa) * NPOLY, lut);
-            __syncthreads();  // table (and, first time, the staged bits) ready; previous row's pass-3 reads finished
-            fwd_phase1(tid, kappa, BitsSrc{reinterpret_cast<const uint8_t*>(ib), reinterpret_cast<const uint8_t*>(qb), lut}, tn_row, w, lds);
-        } else if (SRC == SRC_REALMIX) {
-            __syncthreads();
-            fwd_phase1(tid, kappa, CplxSrc{(const cf*)a.src + (size_t)srci * a.src_stride}, tn_row, w, lds);
-        } else {
-            __syncthreads();
-            fwd_phase1(tid, kappa, RealSrc{(const float*)a.src + (size_t)srci * a.src_stride}, tn_row, w, lds);
-        }
+        const cf* tn_row = a.tn + (size_t)kappa * M_SUB;
+        __syncthreads();  // the previous row's pass-3 reads are done
+        if (SRC == SRC_REALMIX) fwd_phase1(tid, kappa, CplxSrc{(const cf*)a.src + (size_t)item * a.src_stride}, tn_row, w, lds);
+        else fwd_phase1(tid, kappa, RealSrc{(const float*)a.src + (size_t)item * a.src_stride}, tn_row, w, lds);
         __syncthreads();
         fwd_phase2(tid, a.t2, lds);
         __syncthreads();
@@ -187,42 +169,22 @@ __global__ __launch_bounds__(WG) void k_quirk_patch(QuirkArgs a) {
 // grid point; 0 = plain sum) and by the code phase between block starts that are not whole code periods apart (a.lag_step samples
 // per block; 0 = none): power of lag n goes to lag (n - round(k * creep * point) - k * lag_step) mod S.
 // W1H: half of the pass-1 twiddles derived instead of held (acq_math.hpp): 18 registers for 18 packed multiplies.
-// PROF: s_memtime stamps per segment, summed over the launch into a.prof[1024][16] (GPSACQ_PROF=1; costs a few per cent): instantiated
-// in the variant build only (-DACQ_EXPERIMENTS).
 // L: LDS slot map and lane map (acq_math.hpp): LayC (LayB's slots, conflict-free lane assignment) everywhere except the two
 // widest non-coherent instances, whose per-lag power array leaves room for the 40 KB map LayA only (33 columns: 77 KB -> still two
 // workgroups per CU).
-#ifndef ACQ_CORR_LAYOUT
-#define ACQ_CORR_LAYOUT LayC  // -DACQ_CORR_LAYOUT=LayB builds round 2's lane map for A/B runs (tools/build_variant.sh)
-#endif
-#ifndef ACQ_CORR_PEEL0
-#define ACQ_CORR_PEEL0 1  // the first sub-transform's outputs assigned to the accumulators instead of accumulated
-#endif
-#ifndef ACQ_CORR_FOLD22
-#define ACQ_CORR_FOLD22 true  // -DACQ_CORR_FOLD22=false: the 22-column coherent instance with round 3's rotation (A/B runs)
-#endif
-#ifndef ACQ_CORR_ROT22
-#define ACQ_CORR_ROT22 false  // -DACQ_CORR_ROT22=true: pass 2 by rotating roles (below): bit-identical cells, -8.9 % wave-instructions,
-                              // -0.3 % kernel time (profiles/r04_experiments/g_pass2_roles.log): measured, not in the product
-#endif
 // Wave priority (round 3, profiles/r03_experiments/b_priority_stagger.log): a wave runs the first phase of a sub-transform --
 // input loads, product, radix-10 pair, pass-1 stores: the short, latency-bound part that ends in the barrier its three
 // partner waves wait at -- one priority level above the long radix-25 / radix-20 phases of the waves of OTHER workgroups it
 // shares the SIMD with.  Measured -1.9 % kernel time, repeatably (16.36 vs 16.67 ms per 299 008 cells, same box, two passes);
 // levels 1, 2, 3 are equivalent; raising it only while the loads are issued, or also in pass 3, the scan or pass 2, gains
-// nothing or less.  -DACQ_NO_PHASE1_PRIO builds the kernel without it (tools/build_kvariant.sh).
-#ifdef ACQ_NO_PHASE1_PRIO
-#define ACQ_PHASE1_PRIO(level) ((void)0)
-#else
+// nothing or less.
 #define ACQ_PHASE1_PRIO(level) __builtin_amdgcn_s_setprio(level)
-#endif
 // Peak / sum reduction over the 64 lanes of a wave: inside the four rows of 16 lanes by DPP row shifts (VALU latency), the four
-// row results through v_readlane -- instead of six rounds of ds_bpermute (each an LDS-crossbar round trip; -DACQ_NO_DPP_REDUCE
-// builds that form): -0.5 % kernel time (profiles/r03_experiments/g_dpp_reduction.log).
+// row results through v_readlane -- instead of six rounds of ds_bpermute (each an LDS-crossbar round trip): -0.5 % kernel time
+// (profiles/r03_experiments/g_dpp_reduction.log).
 // peak_merge is associative and commutative (larger power, ties to the lower lag), so the order of the merges is free.
 template <int CTRL> __device__ __forceinline__ int dpp_mov(int old, int v) { return __builtin_amdgcn_update_dpp(old, v, CTRL, 0xf, 0xf, false); }
 __device__ __forceinline__ void wave_reduce_peak(float& mx, int& mi, float& sum) {
-#ifndef ACQ_NO_DPP_REDUCE
 #define ACQ_DPP_STEP(CTRL)                                                          \
     {                                                                               \
         const float omx = __int_as_float(dpp_mov<CTRL>(0, __float_as_int(mx)));     \
@@ -248,16 +210,6 @@ __device__ __forceinline__ void wave_reduce_peak(float& mx, int& mi, float& sum)
     mx = rmx;
     mi = rmi;
     sum = rs;
-#else
-#pragma unroll
-    for (int off = 32; off > 0; off >>= 1) {
-        const float omx = __shfl_down(mx, off, 64);
-        const int omi = __shfl_down(mi, off, 64);
-        const float os = __shfl_down(sum, off, 64);
-        peak_merge(mx, mi, omx, omi);
-        sum += os;
-    }
-#endif
 }
 // Non-coherent mode, creep re-alignment, more lags than one pass covers (fs > 10 MHz): a lag's re-aligned destination can lie in
 // another pass's column window, so the per-lag sums live in device memory instead of this pass's LDS array.  One writer per
@@ -290,11 +242,8 @@ template <class L> __device__ __forceinline__ int corr_rho(const CorrArgs& a, in
 // tables of the sub-transform in flight are one LDS image refreshed by LDS-DMA (buffer_load ... lds: 1 KB = 64 lanes x 16 bytes per
 // wave-instruction, no VGPRs, no ds_write; six of them per sub-transform, spread over the four waves): -1.4 % kernel time on
 // configs[1] and [4] (profiles/r04_experiments/a_fold_bq.log; with per-thread copies instead of the DMA it was -0.6 %).
-// ROT (round 4; with FOLD): pass 2 by roles (acq_phases.hpp corr_phase2_role): the wave that would run the radix-25 for 8 of its 64
-// lanes does those 8 butterflies as 2 x 40 five-point transforms instead, and the role rotates over the waves with q.
-template <int MC, int WPS, int NB, bool NC, bool W1H = false, bool PROF = false, class L = ACQ_CORR_LAYOUT, bool NCREG = false, bool FOLD = false, bool ROT = false>
+template <int MC, int WPS, int NB, bool NC, bool W1H = false, class L = LayC, bool NCREG = false, bool FOLD = false>
 __global__ __launch_bounds__(WG, WPS) void k_corr(CorrArgs a) {
-    static_assert(!ROT || L::REMAP, "the light role is written for LayC's pass-2 lane map");
     __shared__ __attribute__((aligned(16))) cf lds[L::SIZE];  // transform buffer
     // pass 2's 500 twiddles; with FOLD followed by the accumulate factors [alpha][column], in whole 1 KB chunks (the DMA's unit)
     constexpr int TQS = TqStride<MC>::value;
@@ -304,7 +253,6 @@ __global__ __launch_bounds__(WG, WPS) void k_corr(CorrArgs a) {
     const cf* const tqs = tabs + NT2;
     __shared__ float red[4 * (WG / 64)];
     __shared__ float pws[NC && !NCREG ? MC * NBF3 : 1];  // non-coherent power per lag of this pass
-    __shared__ cf w25s[ROT ? 25 : 1];  // ROT: W_25^{k1 n2} by lane of the light role
     const int tid = threadIdx.x;
     const int g = blockIdx.x, xcd = g & 7, slot = g >> 3;
     const int grp = slot / a.ndop, di = slot - grp * a.ndop;
@@ -331,9 +279,6 @@ __global__ __launch_bounds__(WG, WPS) void k_corr(CorrArgs a) {
     // q-independent twiddles: pass 2's table into LDS (16-byte copies), pass 1's into registers
     if constexpr (!FOLD)
         for (int i = tid; i < NT2; i += WG) t2s[i] = a.t2[i];
-    if constexpr (ROT)
-        if (tid < 25) w25s[tid] = w25_of(tid / 5, tid % 5);  // (read two barriers on at the earliest)
-    const int my_wave = ROT ? __builtin_amdgcn_readfirstlane(tid >> 6) : 0;
     cf w1[2][RA - 1];
     load_tw1<W1H, L>(tid, a.t1, w1);
 
@@ -349,13 +294,6 @@ __global__ __launch_bounds__(WG, WPS) void k_corr(CorrArgs a) {
     if (NCREG) {
 #pragma unroll
         for (int m = 0; m < MC; ++m) pw[m] = 0.f;
-    }
-    unsigned long long tprof[8] = {0, 0, 0, 0, 0, 0, 0, 0}, tm = PROF ? __builtin_amdgcn_s_memtime() : 0;
-#define ACQ_STAMP(k)                                                  \
-    if (PROF) {                                                       \
-        const unsigned long long now_ = __builtin_amdgcn_s_memtime(); \
-        tprof[k] += now_ - tm;                                        \
-        tm = now_;                                                    \
     }
     const int t3 = tid < NBF3 ? tid : 0;
     const int rho = corr_rho<L>(a, t3);  // the radix-20 butterfly (output residue) this thread owns
@@ -411,7 +349,6 @@ __global__ __launch_bounds__(WG, WPS) void k_corr(CorrArgs a) {
             ACQ_PHASE1_PRIO(1);
             corr_phase1<NB, W1H, L>(tid, q, dop, dk, cpp, a.crow, a.halo, w1, lds);
             ACQ_PHASE1_PRIO(0);
-            ACQ_STAMP(1);  // inputs loaded and multiplied, pass 1, its LDS stores drained (the stamp waits on lgkmcnt)
 #if defined(__HIP_DEVICE_COMPILE__)
             // FOLD: the table image written by this wave's LDS-DMA must have landed before the barrier lets another wave's pass 2
             // read it.  The barrier itself does not wait for vector-memory operations, and the only thing that made every wave
@@ -421,27 +358,17 @@ __global__ __launch_bounds__(WG, WPS) void k_corr(CorrArgs a) {
             if constexpr (FOLD) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 #endif
             __syncthreads();  // also orders the t2s fill before its first use
-            ACQ_STAMP(2);
-            if constexpr (ROT) corr_phase2_role<L>((my_wave + q) & 3, tid & 63, t2s, w25s, lds);
-            else corr_phase2<L>(tid, t2s, lds);
-            ACQ_STAMP(3);
+            corr_phase2<L>(tid, t2s, lds);
             __syncthreads();
-            ACQ_STAMP(4);
             constexpr bool FIRST = decltype(first)::value;
             if constexpr (FOLD) corr_phase3_fold<MC, L, FIRST>(tid, rho, tqs, lds, acc);
             else corr_phase3<MC, L, FIRST>(tid, rho, b, wqv, lds, acc);
-            ACQ_STAMP(5);
             __syncthreads();
-            ACQ_STAMP(6);
         };
         // q = 0 carries unit factors (W^0): its iteration is peeled so that the radix-20 outputs land in the accumulators' registers
-        // (a branch inside the loop costs a register copy per column instead).  -DACQ_CORR_PEEL0=0: one loop (A/B runs)
-        if constexpr (ACQ_CORR_PEEL0) {
-            subtransform(0, std::true_type{});
-            for (int q = 1; q < NPOLY; ++q) subtransform(q, std::false_type{});
-        } else {
-            for (int q = 0; q < NPOLY; ++q) subtransform(q, std::false_type{});
-        }
+        // (a branch inside the loop costs a register copy per column instead)
+        subtransform(0, std::true_type{});
+        for (int q = 1; q < NPOLY; ++q) subtransform(q, std::false_type{});
         if (NC && NCREG) corr_accumulate_power_reg<MC>(tid, acc, pw);
         else if (NC) {
             // every lag has one owner per block, so the scatter needs no atomics; successive blocks'
@@ -484,101 +411,7 @@ __global__ __launch_bounds__(WG, WPS) void k_corr(CorrArgs a) {
         c.snr = (sum > 0.f) ? mx / ave : 0.f;    // :196; 0/0 of the reference defined as 0
         a.cells[(size_t)task * a.ndop + di] = c;
     }
-    ACQ_STAMP(7);  // scan + reduction
-#undef ACQ_STAMP
-    if (PROF && a.prof && (tid & 63) == 0 && (wave == 0 || wave == 3)) {
-        // 1024 buckets of 16 counters (summed by the host): 16 addresses for the whole launch would serialise ~13 M atomics in L2
-        unsigned long long* bucket = a.prof + (size_t)(blockIdx.x & 1023) * 16 + (wave == 0 ? 0 : 8);
-        for (int k = 0; k < 8; ++k) atomicAdd(bucket + k, tprof[k]);
-    }
 }
-
-#ifdef ACQ_EXPERIMENTS  // not in the product library: `make experiments` builds build/var_exp/libgpsacq.so with it (GPSACQ_CORR8=2|3)
-// ---------------------------------------------------------------------------------------
-// The 8-wave correlator (acq_corr8.hpp): the same cell as k_corr<MC> (coherent, one pass, up to 10000 lags) with the
-// 5000-point sub-transforms as 5 x 10 x 10 x 10 on 500 threads.  Same blockIdx -> cell map, same outputs.
-__constant__ cf c_wq8[NPOLY * WQ8_STRIDE];
-hipError_t upload_wq8(const cf* host) { return hipMemcpyToSymbol(HIP_SYMBOL(c_wq8), host, sizeof(cf) * NPOLY * WQ8_STRIDE); }
-
-template <int MC, int WPS>
-__global__ __launch_bounds__(WG8, WPS) void k_corr8(CorrArgs a) {
-    __shared__ __attribute__((aligned(16))) cf lds[Lay8::SIZE];
-    __shared__ cf t2s[NT8_T2];
-    __shared__ cf t3s[NT8_T3];
-    __shared__ float red[4 * (WG8 / 64)];
-    const int tid = threadIdx.x;
-    const int g = blockIdx.x, xcd = g & 7, slot = g >> 3;
-    const int grp = slot / a.ndop, di = slot - grp * a.ndop;
-    const int task = grp * 8 + xcd;
-    if (task >= a.n_tasks) return;
-    const Task tk = a.tasks[task];
-    if (tk.spec < 0 || tk.spec >= a.n_spec || tk.code < 0 || tk.code >= a.n_code) {  // device task lists are not seen by the host
-        if (tid == 0) {
-            Cell c;
-            c.max_pwr = 0.f;
-            c.max_i = -1;
-            c.tot_pwr = 0.f;
-            c.snr = 0.f;
-            a.cells[(size_t)task * a.ndop + di] = c;
-        }
-        return;
-    }
-    int dop, rsub;
-    grid_point(di + a.dop_first, a.sub, a.dstride, dop, rsub);
-    const cf* dpp = a.dpp + ((size_t)tk.spec * a.sub + rsub) * NPOLY * M_SUB;
-    const cf* cpp = a.cpp + (size_t)tk.code * NPOLY * a.crow;
-    for (int i = tid; i < NT8_T2; i += WG8) t2s[i] = a.t2_8[i];
-    if (tid < NT8_T3) t3s[tid] = a.t3_8[tid];
-    constexpr bool W1H = WPS >= 6;  // three workgroups per CU: 80 VGPRs -- half of the pass-1 twiddles derived
-    cf w1[2][R8A - 1];
-    load_tw8<W1H>(tid, a.t1_8, w1);
-    cf acc[MC];
-#pragma unroll
-    for (int m = 0; m < MC; ++m) acc[m] = mk(0.f, 0.f);
-    const int t4 = tid < NT8 ? tid : 0;
-    for (int q = 0; q < NPOLY; ++q) {
-        const cf b = a.bq8[q * NT8 + t4];
-        cf wqv[MC];
-#pragma unroll
-        for (int m = 0; m < MC; ++m) wqv[m] = c_wq8[q * WQ8_STRIDE + m];
-        ACQ_PHASE1_PRIO(1);
-        corr8_phase1<W1H>(tid, q, dop, dpp, cpp, a.crow, a.halo, w1, lds);
-        ACQ_PHASE1_PRIO(0);
-        __syncthreads();  // also orders the table fills before their first use
-        corr8_phase2(tid, t2s, lds);
-        __syncthreads();
-        corr8_phase3(tid, t3s, lds);
-        __syncthreads();
-        corr8_phase4<MC>(tid, b, wqv, lds, acc);
-        __syncthreads();
-    }
-    float mx, sum;
-    int mi;
-    corr8_scan<MC>(tid, a.nlags, acc, mx, mi, sum);
-    wave_reduce_peak(mx, mi, sum);
-    const int wave = tid >> 6;
-    if ((tid & 63) == 0) {
-        red[wave * 4 + 0] = mx;
-        red[wave * 4 + 1] = __int_as_float(mi);
-        red[wave * 4 + 2] = sum;
-    }
-    __syncthreads();
-    if (tid == 0) {
-        for (int w = 1; w < WG8 / 64; ++w) {
-            peak_merge(mx, mi, red[w * 4 + 0], __float_as_int(red[w * 4 + 1]));
-            sum += red[w * 4 + 2];
-        }
-        Cell c;
-        c.max_pwr = mx;
-        c.max_i = mi;
-        c.tot_pwr = sum;
-        const float ave = sum / (float)a.nlags;  // :195 tot_pwr / i
-        c.snr = (sum > 0.f) ? mx / ave : 0.f;    // :196; 0/0 of the reference defined as 0
-        a.cells[(size_t)task * a.ndop + di] = c;
-    }
-}
-
-#endif  // ACQ_EXPERIMENTS
 
 // More than 10000 lags (fs > 10 MHz) take several k_corr passes of 40 columns each; this folds the
 // partial cells (ascending lag ranges, so strict '>' keeps the first maximum) and sets the SNR.
@@ -677,24 +510,11 @@ __global__ __launch_bounds__(WG) void k_peaks(const Cell* cells, Peak* peaks, in
 
 // ---------------------------------------------------------------------------------------
 // launchers (host)
-// (the 1-bit / IQ paths always ask for the conjugated spectrum.  Round 3's form of them, k_fwd<SRC_BITS> / <SRC_IQ8>, is built into
-// the experiment library only and selected there with GPSACQ_FWD1=1 for A/B runs: profiles/r04_experiments/d_kfwd2.log)
-#ifdef ACQ_EXPERIMENTS
-static bool fwd_v1() {
-    static const bool v1 = [] { const char* v = getenv("GPSACQ_FWD1"); return v && *v && atoi(v) != 0; }();
-    return v1;
-}
-#endif
+// (the 1-bit / IQ kernels write the conjugated spectrum, the only one their callers want: run_forward checks)
 void launch_fwd_bits(const FwdArgs& a, int n_items, hipStream_t s) {
-#ifdef ACQ_EXPERIMENTS
-    if (fwd_v1()) { hipLaunchKernelGGL(k_fwd<SRC_BITS>, dim3(n_items), dim3(WG), 0, s, a); return; }
-#endif
     hipLaunchKernelGGL(k_fwd2<SRC_BITS>, dim3(n_items), dim3(WG), 0, s, a);
 }
 void launch_fwd_iq8(const FwdArgs& a, int n_items, hipStream_t s) {
-#ifdef ACQ_EXPERIMENTS
-    if (fwd_v1()) { hipLaunchKernelGGL(k_fwd<SRC_IQ8>, dim3(n_items), dim3(WG), 0, s, a); return; }
-#endif
     hipLaunchKernelGGL(k_fwd2<SRC_IQ8>, dim3(n_items), dim3(WG), 0, s, a);
 }
 void launch_fwd_realmix(const FwdArgs& a, int n_items, hipStream_t s) {
@@ -719,15 +539,6 @@ int corr_columns(int nlags) {  // accumulator columns of the smallest instance t
 int launch_corr(const CorrArgs& a, int mc, hipStream_t s) {
     const int groups = (a.n_tasks + 7) / 8;
     const dim3 grid((unsigned)groups * 8u * (unsigned)a.ndop), block(WG);
-#ifdef ACQ_EXPERIMENTS
-    // residency experiment (experiment library only): GPSACQ_CORR_LDS_PAD=<bytes> of unused dynamic LDS per workgroup of the
-    // 22-column coherent instance -- 31000 leaves two workgroups per CU, 60000 one (tools/residency_curve.py)
-    static const int lds_pad = [] { const char* v = getenv("GPSACQ_CORR_LDS_PAD"); return v && *v ? atoi(v) : 0; }();
-    if (lds_pad > 0 && mc == 22 && a.n_acc == 1 && !a.prof) {
-        hipLaunchKernelGGL((k_corr<22, 3, 2, false, false, false, ACQ_CORR_LAYOUT, false, ACQ_CORR_FOLD22, ACQ_CORR_ROT22>), grid, block, (size_t)lds_pad, s, a);
-        return 0;
-    }
-#endif
     // <columns, waves per SIMD the register allocator is held to (k workgroups per CU <=> k waves per SIMD), load batches,
     // non-coherent, W1H>.  LDS (49 KB per workgroup) admits 3 workgroups per CU; 12, 22 and 28 columns fit 168 VGPRs,
     // 28 and 33 columns do with half the pass-1 twiddles derived (W1H); 40 columns then spill 40 bytes per lane and are still
@@ -736,58 +547,30 @@ int launch_corr(const CorrArgs& a, int mc, hipStream_t s) {
         case 12:
             // non-coherent: without creep re-alignment the per-lag sums stay in registers and three workgroups fit a CU (BASELINE
             // configs[3]); with it they go through a per-lag LDS array (61 KB: two per CU)
-            if (a.n_acc > 1 && a.creep == 0.f && a.lag_step == 0) hipLaunchKernelGGL((k_corr<12, 3, 2, true, false, false, ACQ_CORR_LAYOUT, true>), grid, block, 0, s, a);
+            if (a.n_acc > 1 && a.creep == 0.f && a.lag_step == 0) hipLaunchKernelGGL((k_corr<12, 3, 2, true, false, LayC, true>), grid, block, 0, s, a);
             else if (a.n_acc > 1) hipLaunchKernelGGL((k_corr<12, 2, 2, true>), grid, block, 0, s, a);
             else hipLaunchKernelGGL((k_corr<12, 3, 2, false>), grid, block, 0, s, a);
             break;
         case 22:
             if (a.n_acc > 1) hipLaunchKernelGGL((k_corr<22, 2, 2, true>), grid, block, 0, s, a);
-#ifdef ACQ_EXPERIMENTS
-            else if (a.prof) hipLaunchKernelGGL((k_corr<22, 3, 2, false, false, true, ACQ_CORR_LAYOUT, false, ACQ_CORR_FOLD22, ACQ_CORR_ROT22>), grid, block, 0, s, a);
-#endif
-            else hipLaunchKernelGGL((k_corr<22, 3, 2, false, false, false, ACQ_CORR_LAYOUT, false, ACQ_CORR_FOLD22, ACQ_CORR_ROT22>), grid, block, 0, s, a);
+            else hipLaunchKernelGGL((k_corr<22, 3, 2, false, false, LayC, false, true>), grid, block, 0, s, a);  // FOLD
             break;
         case 28:
             if (a.n_acc > 1) hipLaunchKernelGGL((k_corr<28, 2, 2, true>), grid, block, 0, s, a);
             else hipLaunchKernelGGL((k_corr<28, 3, 2, false, true>), grid, block, 0, s, a);
             break;
         case 33:
-            if (a.n_acc > 1) hipLaunchKernelGGL((k_corr<33, 2, 2, true, false, false, LayA>), grid, block, 0, s, a);
+            if (a.n_acc > 1) hipLaunchKernelGGL((k_corr<33, 2, 2, true, false, LayA>), grid, block, 0, s, a);
             else hipLaunchKernelGGL((k_corr<33, 3, 2, false, true>), grid, block, 0, s, a);
             break;
         case 40:
-            if (a.n_acc > 1) hipLaunchKernelGGL((k_corr<40, 1, 2, true, false, false, LayA>), grid, block, 0, s, a);  // 84 KB of LDS: one workgroup per CU
+            if (a.n_acc > 1) hipLaunchKernelGGL((k_corr<40, 1, 2, true, false, LayA>), grid, block, 0, s, a);  // 84 KB of LDS: one workgroup per CU
             else hipLaunchKernelGGL((k_corr<40, 3, 2, false, true>), grid, block, 0, s, a);  // 40 bytes of spills: still 7 % faster than 2 per CU
             break;
         default: return -1;
     }
     return 0;
 }
-#ifdef ACQ_EXPERIMENTS
-int corr8_columns(int nlags) {
-    const int need = (nlags + NT8 - 1) / NT8;
-    const int have[] = {6, 11, 14, 17, 20};
-    for (int m : have)
-        if (need <= m) return m;
-    return 0;
-}
-// wgs_per_cu: 2 -> the register allocator is held to 4 waves per SIMD (128 VGPRs), 3 -> 6 waves per SIMD (80 VGPRs)
-int launch_corr8(const CorrArgs& a, int mc8, int wgs_per_cu, hipStream_t s) {
-    const int groups = (a.n_tasks + 7) / 8;
-    const dim3 grid((unsigned)groups * 8u * (unsigned)a.ndop), block(WG8);
-#define K8(MCV)                                                                             \
-    case MCV:                                                                               \
-        if (wgs_per_cu >= 3) hipLaunchKernelGGL((k_corr8<MCV, 6>), grid, block, 0, s, a);   \
-        else hipLaunchKernelGGL((k_corr8<MCV, 4>), grid, block, 0, s, a);                   \
-        break;
-    switch (mc8) {
-        K8(6) K8(11) K8(14) K8(17) K8(20)
-        default: return -1;
-    }
-#undef K8
-    return 0;
-}
-#endif  // ACQ_EXPERIMENTS
 void launch_scan_power(const float* pdump, Cell* cells, size_t n_cells, int nlags, hipStream_t s) {
     hipLaunchKernelGGL(k_scan_power, dim3((unsigned)n_cells), dim3(256), 0, s, pdump, cells, nlags);
 }

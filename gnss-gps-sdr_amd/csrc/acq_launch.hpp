@@ -3,9 +3,6 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
-#ifdef ACQ_EXPERIMENTS  // the variant build (`make experiments`): the 8-wave correlator and the phase profiler, DESIGN.md section 4
-#include "acq_corr8.hpp"
-#endif
 #include "acq_phases.hpp"
 #include "iq_convert.hpp"
 
@@ -23,7 +20,6 @@ struct FwdArgs {
     const cf* t1;
     const cf* t2;
     const cf* tn;        // [sub][8][5000] W_N^{n' (kappa + r/sub)}
-    const cf* rot8;      // [sub][8][8]    exp(-2 pi i nu (kappa + r/sub) / 8)   (bits source only)
     const cf* lutc;      // [sub][8][256]  conjugated radix-8 sums by transposed byte (k_fwd2; acq_tables.hpp forward_tables)
     int sub;             // spectra per source item (sub-bin Doppler offsets r/sub, r < sub); item i -> (source i / sub, r = i % sub)
     cf* out;             // [n_items][item_stride], polyphase rows
@@ -61,12 +57,8 @@ struct CorrArgs {
                           // block samples) mod S, when the blocks are not whole code periods apart and re-alignment is asked for (0 = off)
     int n_spec, n_code;   // rows of dpp / cpp: tasks pointing outside get an empty cell (max_i = -1)
     int sub, dstride;     // Doppler grid (acq_phases.hpp grid_point): dop_first/ndop count grid points; spectrum of (block, r) at row block*sub + r
-#ifdef ACQ_EXPERIMENTS
-    const cf *t1_8, *t2_8, *t3_8, *bq8;  // tables of the 8-wave correlator (acq_corr8.hpp, Tables8)
-#endif
     float* pdump;      // non-coherent mode with creep re-alignment over several column passes (fs > 10 MHz): per-lag power sums in
                        // device memory, [n_tasks * ndop][nlags], zeroed by the caller; the cells then come from launch_scan_power.  Else NULL
-    unsigned long long* prof;  // variant build only (k_corr<..., PROF>): [1024][16] accumulated s_memtime deltas per segment (bucket = workgroup % 1024) (GPSACQ_PROF=1 diagnostic); NULL in the product
 };
 
 // sets this thread's gpsacq_last_error() text and returns `code` (gpsacq_engine.cpp)
@@ -81,11 +73,6 @@ void launch_quirk_patch(const QuirkArgs& a, int n_patch, hipStream_t s);
 int corr_columns(int nlags);
 hipError_t upload_wq(const cf* host);  // fills the __constant__ copy of wq on the current device
 int launch_corr(const CorrArgs& a, int mc, hipStream_t s);
-#ifdef ACQ_EXPERIMENTS
-int corr8_columns(int nlags);  // accumulator columns of the smallest k_corr8 instance that covers nlags, 0 if none
-int launch_corr8(const CorrArgs& a, int mc8, int wgs_per_cu, hipStream_t s);
-hipError_t upload_wq8(const cf* host);
-#endif
 void launch_scan_power(const float* pdump, Cell* cells, size_t n_cells, int nlags, hipStream_t s);
 void launch_merge_cells(const Cell* parts, Cell* cells, size_t n_cells, int n_parts, int nlags, hipStream_t s);
 void launch_pack_keys(const Peak* peaks, unsigned long long* keys, int n, int kmax, hipStream_t s);

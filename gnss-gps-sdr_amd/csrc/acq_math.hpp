@@ -197,9 +197,6 @@ ACQ_HD cf fms_i(cf a, cf b, cf s) {
 template <int DIR> ACQ_HD cf fma_di(cf a, cf b, cf s) { return DIR > 0 ? fma_i(a, b, s) : fms_i(a, b, s); }
 template <int DIR> ACQ_HD cf fms_di(cf a, cf b, cf s) { return DIR > 0 ? fms_i(a, b, s) : fma_i(a, b, s); }
 
-#ifndef ACQ_DFT5_FMA
-#define ACQ_DFT5_FMA 1  // -DACQ_DFT5_FMA=0: round 1-3's form of the five-point butterfly (18 packed instructions; A/B runs)
-#endif
 // Five-point butterfly.  With c1 = cos(2 pi/5), c2 = cos(4 pi/5), s1 = sin(2 pi/5), s2 = sin(4 pi/5):
 //   X0 = x0 + t1 + t2,  X1,4 = m1 +- i DIR sg1,  X2,3 = m2 +- i DIR sg2,
 //   m1 = x0 + c1 t1 + c2 t2,  m2 = x0 + c2 t1 + c1 t2,  sg1 = s1 t3 + s2 t4,  sg2 = s2 t3 - s1 t4.
@@ -210,7 +207,6 @@ template <int DIR> ACQ_HD cf fms_di(cf a, cf b, cf s) { return DIR > 0 ? fms_i(a
 template <int DIR> ACQ_HD void dft5(cf& x0, cf& x1, cf& x2, cf& x3, cf& x4) {
     constexpr float C2 = -0.8090169943749473f, S1 = 0.9510565162951535f;
     cf t1 = x1 + x4, t2 = x2 + x3, t3 = x1 - x4, t4 = x2 - x3;
-#if ACQ_DFT5_FMA
     constexpr float CD = 1.118033988749895f;   // c1 - c2 = sqrt(5)/2
     constexpr float SR = 0.6180339887498949f;  // s2 / s1
     const cf s1v = mk(S1, S1);
@@ -225,18 +221,6 @@ template <int DIR> ACQ_HD void dft5(cf& x0, cf& x1, cf& x2, cf& x3, cf& x4) {
     x4 = fms_di<DIR>(m1, g1, s1v);
     x2 = fma_di<DIR>(m2, g2, s1v);
     x3 = fms_di<DIR>(m2, g2, s1v);
-#else
-    constexpr float C1 = 0.30901699437494745f, S2 = 0.5877852522924732f;
-    cf m1 = x0 + C1 * t1 + C2 * t2;
-    cf m2 = x0 + C2 * t1 + C1 * t2;
-    cf s1 = S1 * t3 + S2 * t4;
-    cf s2 = S2 * t3 - S1 * t4;
-    x0 = x0 + t1 + t2;
-    x1 = add_di<DIR>(m1, s1);
-    x4 = sub_di<DIR>(m1, s1);
-    x2 = add_di<DIR>(m2, s2);
-    x3 = sub_di<DIR>(m2, s2);
-#endif
 }
 
 // forward value of W_8^m = exp(-2 pi i m / 8), m taken mod 8
@@ -312,23 +296,6 @@ template <int DIR> ACQ_HD void radix20(const cf* x, cf* y) {
     }
 }
 
-// forward value of W_25^m = exp(-2 pi i m / 25) for the m = n2*k1 products that occur
-template <int M> ACQ_HD cf w25() {
-    static_assert(M == 1 || M == 2 || M == 3 || M == 4 || M == 6 || M == 8 || M == 9 || M == 12 || M == 16, "w25");
-    return M == 1    ? mk(0.96858316112863108f, -0.24868988716485479f)
-           : M == 2  ? mk(0.87630668004386358f, -0.48175367410171532f)
-           : M == 3  ? mk(0.72896862742141155f, -0.68454710592868862f)
-           : M == 4  ? mk(0.53582679497899655f, -0.84432792550201508f)
-           : M == 6  ? mk(0.062790519529313527f, -0.99802672842827156f)
-           : M == 8  ? mk(-0.42577929156507272f, -0.90482705246601947f)
-           : M == 9  ? mk(-0.63742398974868975f, -0.77051324277578925f)
-           : M == 12 ? mk(-0.99211470131447776f, -0.12533323356430454f)
-                     : mk(-0.63742398974868952f, 0.77051324277578936f);
-}
-
-#ifndef ACQ_R25_TAN
-#define ACQ_R25_TAN 1  // -DACQ_R25_TAN=0: the radix-25's inner twiddles as 16 complex multiplies in front of plain butterflies (A/B runs)
-#endif
 // cos / sin of 2 pi m / 25 in double, for the compile-time constants of dft5_tw
 constexpr double w25cos(int m) {
     return m == 1 ? 0.96858316112863108 : m == 2 ? 0.87630668004386358 : m == 3 ? 0.72896862742141155 : m == 4 ? 0.53582679497899655
@@ -384,7 +351,6 @@ template <int DIR> ACQ_HD void radix25(const cf* x, cf* y) {
         dft5<DIR>(a, b, c, d, e);
         v[0][n2] = a; v[1][n2] = b; v[2][n2] = c; v[3][n2] = d; v[4][n2] = e;
     }
-#if ACQ_R25_TAN
     dft5<DIR>(v[0][0], v[0][1], v[0][2], v[0][3], v[0][4]);
     dft5_tw<DIR, 1>(v[1][0], v[1][1], v[1][2], v[1][3], v[1][4]);
     dft5_tw<DIR, 2>(v[2][0], v[2][1], v[2][2], v[2][3], v[2][4]);
@@ -394,22 +360,6 @@ template <int DIR> ACQ_HD void radix25(const cf* x, cf* y) {
     for (int k1 = 0; k1 < 5; ++k1)
 #pragma unroll
         for (int k2 = 0; k2 < 5; ++k2) y[k1 + 5 * k2] = v[k1][k2];
-#else
-    v[1][1] = tw_u<DIR>(v[1][1], w25<1>());  v[1][2] = tw_u<DIR>(v[1][2], w25<2>());
-    v[1][3] = tw_u<DIR>(v[1][3], w25<3>());  v[1][4] = tw_u<DIR>(v[1][4], w25<4>());
-    v[2][1] = tw_u<DIR>(v[2][1], w25<2>());  v[2][2] = tw_u<DIR>(v[2][2], w25<4>());
-    v[2][3] = tw_u<DIR>(v[2][3], w25<6>());  v[2][4] = tw_u<DIR>(v[2][4], w25<8>());
-    v[3][1] = tw_u<DIR>(v[3][1], w25<3>());  v[3][2] = tw_u<DIR>(v[3][2], w25<6>());
-    v[3][3] = tw_u<DIR>(v[3][3], w25<9>());  v[3][4] = tw_u<DIR>(v[3][4], w25<12>());
-    v[4][1] = tw_u<DIR>(v[4][1], w25<4>());  v[4][2] = tw_u<DIR>(v[4][2], w25<8>());
-    v[4][3] = tw_u<DIR>(v[4][3], w25<12>()); v[4][4] = tw_u<DIR>(v[4][4], w25<16>());
-#pragma unroll
-    for (int k1 = 0; k1 < 5; ++k1) {
-        dft5<DIR>(v[k1][0], v[k1][1], v[k1][2], v[k1][3], v[k1][4]);
-#pragma unroll
-        for (int k2 = 0; k2 < 5; ++k2) y[k1 + 5 * k2] = v[k1][k2];
-    }
-#endif
 }
 
 // ---------------------------------------------------------------------------------------
@@ -566,58 +516,6 @@ template <int DIR, class L = LayA> ACQ_HD void pass2_inplace(int e, const cf* __
     p[0] = y[0];
 #pragma unroll
     for (int be = 1; be < RB; ++be) p[L::SB * be] = tw<DIR>(y[be], t2[be * RC + jpp]);
-}
-
-// ---- pass 2, the light role (round 4).  200 radix-25 butterflies on 256 lanes leave the fourth wave 8 of them: 262 instructions for
-// 8 lanes.  Those 8 butterflies (LayC lanes 192..199: alpha = 8 + (i >> 2), j'' = 16 + (i & 3)) = 200 elements are instead done as two
-// rounds of 40 five-point transforms on 40 lanes of that wave -- the same dft5 calls, the same twiddle products in the same order
-// as radix25(), hence the same bits -- exchanging through the butterflies' own LDS slots (a wave's LDS operations complete in
-// order: no barrier between the rounds).  ~54 packed instructions instead of 262; the kernel rotates the role over the four waves
-// from sub-transform to sub-transform so that every SIMD is relieved equally.
-// forward value of W_25^{k1 n2} as radix25() applies it ((1, 0) where it applies none: that product is exact)
-ACQ_HD cf w25_of(int k1, int n2) {
-    switch (k1 * n2) {
-        case 1: return w25<1>();
-        case 2: return w25<2>();
-        case 3: return w25<3>();
-        case 4: return w25<4>();
-        case 6: return w25<6>();
-        case 8: return w25<8>();
-        case 9: return w25<9>();
-        case 12: return w25<12>();
-        case 16: return w25<16>();
-        default: return mk(1.f, 0.f);
-    }
-}
-// round A, lane l < 40 = (butterfly i = l / 5, n2 = l % 5): five-point transform over n1 of elements b = 5 n1 + n2, times W_25^{k1 n2},
-// written back to slot b = 5 k1 + n2.  w25s[k1 * 5 + n2] = w25_of(k1, n2) (a 25-entry LDS table).
-template <int DIR, class L> ACQ_HD void pass2_light_a(int l, const cf* w25s, cf* lds) {
-    const int i = l / 5, n2 = l - 5 * i;
-    cf* p = lds + L::SA * (8 + (i >> 2)) + L::SJ * (16 + (i & 3));
-    cf a = p[L::SB * n2], b = p[L::SB * (5 + n2)], c = p[L::SB * (10 + n2)], d = p[L::SB * (15 + n2)], e = p[L::SB * (20 + n2)];
-    dft5<DIR>(a, b, c, d, e);
-    p[L::SB * n2] = a;
-    p[L::SB * (5 + n2)] = tw<DIR>(b, w25s[5 + n2]);
-    p[L::SB * (10 + n2)] = tw<DIR>(c, w25s[10 + n2]);
-    p[L::SB * (15 + n2)] = tw<DIR>(d, w25s[15 + n2]);
-    p[L::SB * (20 + n2)] = tw<DIR>(e, w25s[20 + n2]);
-}
-// round B, lane l < 40 = (butterfly i, k1 = l % 5): five-point transform over n2 of slots 5 k1 + n2 -> outputs beta = k1 + 5 k2, times
-// pass 2's output twiddle, stored to slot beta
-// (src == dst in the kernel: every lane of the wave has read its five slots before any lane's stores are issued -- one instruction
-// stream, in-order LDS; the CPU emulation, which runs the lanes one after the other, reads from a snapshot)
-template <int DIR, class L> ACQ_HD void pass2_light_b(int l, const cf* __restrict__ t2, const cf* src, cf* dst) {
-    const int i = l / 5, k1 = l - 5 * i, jpp = 16 + (i & 3);
-    const int off = L::SA * (8 + (i >> 2)) + L::SJ * jpp;
-    const cf* ps = src + off;
-    cf* p = dst + off;
-    cf v0 = ps[L::SB * (5 * k1)], v1 = ps[L::SB * (5 * k1 + 1)], v2 = ps[L::SB * (5 * k1 + 2)], v3 = ps[L::SB * (5 * k1 + 3)], v4 = ps[L::SB * (5 * k1 + 4)];
-    dft5<DIR>(v0, v1, v2, v3, v4);
-    p[L::SB * k1] = k1 == 0 ? v0 : tw<DIR>(v0, t2[k1 * RC + jpp]);
-    p[L::SB * (k1 + 5)] = tw<DIR>(v1, t2[(k1 + 5) * RC + jpp]);
-    p[L::SB * (k1 + 10)] = tw<DIR>(v2, t2[(k1 + 10) * RC + jpp]);
-    p[L::SB * (k1 + 15)] = tw<DIR>(v3, t2[(k1 + 15) * RC + jpp]);
-    p[L::SB * (k1 + 20)] = tw<DIR>(v4, t2[(k1 + 20) * RC + jpp]);
 }
 
 // pass 3 for the butterfly rho = 10 beta + alpha (0..249): y[n''] = F[250 n'' + rho].

@@ -123,20 +123,6 @@ template <class L = LayB>
 ACQ_HD void corr_phase2(int tid, const cf* t2, cf* lds) {
     if (tid < NBF2) pass2_inplace<+1, L>(tid, t2, lds);
 }
-// The same with roles (k_corr<..., ROT>, LayC's lane map): roles 0..2 are the first 192 butterflies on full waves, role 3 does the
-// last 8 as two rounds of five-point transforms on 40 lanes (acq_math.hpp pass2_light_*); the kernel hands role (wave + q) mod 4 to
-// each wave, so the light role visits every wave -- and every SIMD -- twice per cell.  Same bits as corr_phase2.
-template <class L = LayC>
-ACQ_HD void corr_phase2_role(int role, int lane, const cf* t2, const cf* w25s, cf* lds) {
-    if (role < 3) {
-        pass2_inplace<+1, L>(64 * role + lane, t2, lds);
-    } else if (lane < 40) {
-        pass2_light_a<+1, L>(lane, w25s, lds);
-        ACQ_SCHED_FENCE();
-        pass2_light_b<+1, L>(lane, t2, lds, lds);
-    }
-}
-
 // acc[m] accumulates y[n] for n = 250 (m0 + m) + rho over the 8 polyphase components (m0, the first
 // column of this pass, is a multiple of 20 so that column m0 + m reads radix-20 output m % 20):
 // W_N^{-q n} = conj(b) (per thread, b = bq[q][rho]) * conj(wqv[m]) (wave-uniform, wqv[m] = W_160^{q m}).
@@ -342,15 +328,9 @@ ACQ_HD uint64_t transpose8x8(uint64_t x) {
 
 // 1-bit input (Sample(), :143-153).  Once per workgroup the block is bit-transposed so that byte n'
 // holds the eight samples n' + 5000 nu (nu = bit number), with the quadrature-LO masks XOR-ed in
-// (transposing commutes with XOR, so the masks are transposed once on the host), and a 256-entry
-// table lut[b] = sum_nu (+-1 by bit nu of b) W_8^{nu kappa} is built.  The radix-8 partial sum of a
-// term is then two table look-ups: lut[I byte] + i lut[Q byte].
-struct BitsSrc {
-    const uint8_t* ib;   // [5000] transposed (capture ^ cos mask)   (workgroup-local)
-    const uint8_t* qb;   // [5000] transposed (capture ^ sin mask)
-    const cf* lut;       // [256]
-    ACQ_HD cf partial(int np, cf, cf, cf) const { return add_i(lut[ib[np]], lut[qb[np]]); }
-};
+// (transposing commutes with XOR, so the masks are transposed once on the host); a 256-entry
+// table lutc[b] = conj(sum_nu (+-1 by bit nu of b) W_8^{nu kappa}) (host-built, acq_tables.hpp) turns the
+// radix-8 partial sum of a term into two look-ups: lut[I byte] + i lut[Q byte] (fwd2_phase1).
 // real code replica, imag = 0 (SearchInit(), :101-102): init-time only, plain pruned radix-8
 struct RealSrc {
     const float* x;      // [40000]
@@ -374,14 +354,6 @@ struct CplxSrc {
     }
 };
 
-// rot[nu] = exp(-2 pi i nu (kappa + eps) / 8): the radix-8 step of row kappa, with the sub-bin Doppler offset eps of
-// this spectrum folded in (eps = 0: W_8^{nu kappa})
-ACQ_HD void fwd_build_lut(int tid, const cf* __restrict__ rot, cf* lut) {  // thread tid computes entry tid (WG = 256)
-    cf s = mk(0.f, 0.f);
-#pragma unroll
-    for (int nu = 0; nu < NPOLY; ++nu) s = s + pm1(((unsigned)tid >> nu) & 1u) * rot[nu];
-    lut[tid] = s;
-}
 ACQ_HD void fwd_stage_bits(int tid, const uint8_t* __restrict__ bytes, const uint64_t* __restrict__ cos_t,
                            const uint64_t* __restrict__ sin_t, uint64_t* ib, uint64_t* qb) {
     for (int B = tid; B < USED_BYTES / NPOLY; B += WG) {

@@ -64,37 +64,15 @@ struct TablesFold {
     std::vector<cf> fold;
 };
 
-// Tables of the 8-wave correlator (acq_corr8.hpp)
-struct Tables8 {
-    std::vector<cf> t1;  // [5][1000]   W_5000^{j' alpha}
-    std::vector<cf> t2;  // [9][100]    W_1000^{j'' beta}, beta = 1..9
-    std::vector<cf> t3;  // [9][10]     W_100^{d gamma}, gamma = 1..9
-    std::vector<cf> bq;  // [8][500]    W_40000^{q rho}
-    std::vector<cf> wq;  // [8][80]     W_80^{q m}
-    Tables8() : t1(5 * 1000), t2(9 * 100), t3(9 * 10), bq((size_t)NPOLY * 500), wq((size_t)NPOLY * 80) {
-        for (int al = 0; al < 5; ++al)
-            for (int jp = 0; jp < 1000; ++jp) t1[al * 1000 + jp] = unit_fwd((long long)jp * al, M_SUB);
-        for (int be = 1; be < 10; ++be)
-            for (int jpp = 0; jpp < 100; ++jpp) t2[(be - 1) * 100 + jpp] = unit_fwd((long long)jpp * be, 1000);
-        for (int ga = 1; ga < 10; ++ga)
-            for (int d = 0; d < 10; ++d) t3[(ga - 1) * 10 + d] = unit_fwd((long long)d * ga, 100);
-        for (int q = 0; q < NPOLY; ++q) {
-            for (int rho = 0; rho < 500; ++rho) bq[(size_t)q * 500 + rho] = unit_fwd((long long)q * rho, N_FFT);
-            for (int m = 0; m < 80; ++m) wq[(size_t)q * 80 + m] = unit_fwd((long long)q * m, 80);
-        }
-    }
-};
-
 // Forward-transform tables for `sub` sub-bin Doppler offsets r/sub (r < sub) of a bin (extension; the reference's grid is
 // sub = 1): spectrum r of a block is the transform of x[n] exp(-2 pi i (r/sub) n / N), i.e. the block's spectrum
 // evaluated r/sub of a bin higher, which the decimation-in-frequency split absorbs exactly into its twiddles:
-//   tn [r][kappa][n'] = exp(-2 pi i n' (kappa + r/sub) / N),   rot8[r][kappa][nu] = exp(-2 pi i nu (kappa + r/sub) / 8)
-//   lutc[r][kappa][b]  = conj( sum_nu (+1 / -1 by bit nu of b: Bipolar(), :68-70) rot8[r][kappa][nu] ): the pruned radix-8 sum of the
+//   tn [r][kappa][n'] = exp(-2 pi i n' (kappa + r/sub) / N)
+//   lutc[r][kappa][b]  = conj( sum_nu (+1 / -1 by bit nu of b: Bipolar(), :68-70) exp(-2 pi i nu (kappa + r/sub) / 8) ): the pruned radix-8 sum of the
 //                        eight 1-bit samples a transposed byte holds, conjugated (k_fwd2 runs the transform backwards on
 //                        conjugated inputs); summed in long double from the exact angles
-inline void forward_tables(int sub, std::vector<cf>& tn, std::vector<cf>& rot8, std::vector<cf>* lutc = nullptr) {
+inline void forward_tables(int sub, std::vector<cf>& tn, std::vector<cf>* lutc = nullptr) {
     tn.resize((size_t)sub * NPOLY * M_SUB);
-    rot8.resize((size_t)sub * NPOLY * NPOLY);
     if (lutc) {
         lutc->resize((size_t)sub * NPOLY * 256);
         const long double tp = 6.283185307179586476925286766559005768L;
@@ -122,7 +100,6 @@ inline void forward_tables(int sub, std::vector<cf>& tn, std::vector<cf>& rot8, 
         for (int ka = 0; ka < NPOLY; ++ka) {
             const long long m = (long long)ka * sub + r;  // (kappa + r/sub) * sub
             for (int n = 0; n < M_SUB; ++n) tn[((size_t)r * NPOLY + ka) * M_SUB + n] = unit_fwd((long long)n * m, (long long)N_FFT * sub);
-            for (int nu = 0; nu < NPOLY; ++nu) rot8[((size_t)r * NPOLY + ka) * NPOLY + nu] = unit_fwd((long long)nu * m, (long long)NPOLY * sub);
         }
 }
 

@@ -55,7 +55,6 @@ struct gpsacq_engine {
     int n_acc = 1, acc_step = 0;  // non-coherent accumulation (gpsacq_set_noncoherent)
     // Doppler grid (gpsacq_set_doppler_step): step = bin * dstride / sub, points -kmax..+kmax; sub = dstride = 1 is the reference's
     int sub = 1, dstride = 1, kmax = 0;
-    cf* d_rot8 = nullptr;
     cf* d_lutc = nullptr;  // [sub][8][256] look-up tables of k_fwd2
     bool creep_comp = false;      // re-align accumulated blocks by the code creep of each Doppler bin
     bool block_align = false;     // re-align accumulated blocks by the code phase between their starts (any stride)
@@ -73,10 +72,6 @@ struct gpsacq_engine {
     cf *d_t1 = nullptr, *d_t2 = nullptr, *d_bq = nullptr, *d_tn = nullptr;
     cf* d_fold = nullptr;  // the folded-rotation tables of k_corr<..., FOLD> (acq_tables.hpp TablesFold)
     unsigned char* d_rho = nullptr;
-    // variant build (-DACQ_EXPERIMENTS) only: tables of the 8-wave correlator; GPSACQ_CORR8=2|3 runs coherent single-pass searches
-    // on k_corr8 at that many workgroups per CU.  Always NULL / 0 in the product library.
-    cf *d_t1_8 = nullptr, *d_t2_8 = nullptr, *d_t3_8 = nullptr, *d_bq8 = nullptr;
-    int corr8 = 0;
     uint8_t *d_cos = nullptr, *d_sin = nullptr;
     uint64_t *d_cos_t = nullptr, *d_sin_t = nullptr;  // bit-transposed masks for k_fwd
     cf* d_code = nullptr;  // [32 + patch_cap][8][crow]
@@ -107,8 +102,6 @@ struct gpsacq_engine {
     size_t sats_cap = 0;
     uint8_t* d_gen = nullptr;
     size_t gen_cap = 0;
-    unsigned long long* d_prof = nullptr;  // GPSACQ_PROF=1: s_memtime phase profile of k_corr (diagnostic; 22-column coherent instance)
-    bool prof = false;                     // GPSACQ_PROF read once, at gpsacq_create
     // cached default schedule (task t = block t, PRN t % 32; with ref_quirks also its patch list: blocks 0, 32, 64, ...)
     size_t sched_tasks = 0;
     bool sched_valid = false;
@@ -198,7 +191,6 @@ static int run_forward(gpsacq_engine* e, FwdKind kind, const void* src, size_t s
             fa.iq_total = cap->iq_total;
         }
         fa.sub = sub;
-        fa.rot8 = e->d_rot8;
         fa.lutc = e->d_lutc;
         fa.cos_t = e->d_cos_t;
         fa.sin_t = e->d_sin_t;
@@ -225,7 +217,7 @@ extern "C" void gpsacq_destroy(gpsacq_engine* e) {
     if (!e) return;
     (void)hipSetDevice(e->p.device);
     if (e->stream) (void)hipStreamSynchronize(e->stream);
-    void* bufs[] = {e->d_t1, e->d_t2, e->d_bq, e->d_fold, e->d_tn, e->d_rho, e->d_t1_8, e->d_t2_8, e->d_t3_8, e->d_bq8, e->d_cos, e->d_sin, e->d_cos_t, e->d_sin_t, e->d_code, e->d_patch_blocks, e->d_bits, e->d_iq, e->d_iqbits, e->d_fsamp, e->d_pdump, e->d_sums, e->d_sats, e->d_gen, e->d_prof, e->d_rot8, e->d_lutc,
+    void* bufs[] = {e->d_t1, e->d_t2, e->d_bq, e->d_fold, e->d_tn, e->d_rho, e->d_cos, e->d_sin, e->d_cos_t, e->d_sin_t, e->d_code, e->d_patch_blocks, e->d_bits, e->d_iq, e->d_iqbits, e->d_fsamp, e->d_pdump, e->d_sums, e->d_sats, e->d_gen, e->d_lutc,
                     e->d_dpp, e->d_parts, e->d_tasks, e->d_cells, e->d_peaks};
     for (void* b : bufs)
         if (b) (void)hipFree(b);
@@ -268,10 +260,7 @@ extern "C" int gpsacq_create(const gpsacq_params* params, gpsacq_engine** out) {
     struct HostPrep {
         Tables T;
         TablesFold TF;
-#ifdef ACQ_EXPERIMENTS
-        Tables8 T8;
-#endif
-        std::vector<cf> tn, rot8, lutc;
+        std::vector<cf> tn, lutc;
         std::vector<uint8_t> cosm, sinm;
         std::vector<uint64_t> cos_t, sin_t;
         std::vector<float> rep;
@@ -280,7 +269,7 @@ extern "C" int gpsacq_create(const gpsacq_params* params, gpsacq_engine** out) {
     const gpsacq_params prm = *params;
     auto host_prep = [prm]() {
         std::unique_ptr<HostPrep> h(new HostPrep());
-        forward_tables(1, h->tn, h->rot8, &h->lutc);
+        forward_tables(1, h->tn, &h->lutc);
         h->cosm.resize(BLOCK_BYTES);
         h->sinm.resize(BLOCK_BYTES);
         lo_masks(prm.fc, prm.fs, BLOCK_BYTES, h->cosm.data(), h->sinm.data());
@@ -331,12 +320,6 @@ extern "C" int gpsacq_create(const gpsacq_params* params, gpsacq_engine** out) {
     e->crow = M_SUB + 2 * e->halo;
     e->cus = prop.multiProcessorCount;
     snprintf(e->name, sizeof e->name, "%s", prop.name);
-#ifdef ACQ_EXPERIMENTS
-    {
-        const char* pv = getenv("GPSACQ_PROF");  // diagnostic (k_corr phase profile); read once, here
-        e->prof = pv && *pv && atoi(pv) != 0;
-    }
-#endif
 #define HCK(expr)                                                                     \
     do {                                                                              \
         hipError_t e_ = (expr);                                                       \
@@ -366,8 +349,6 @@ extern "C" int gpsacq_create(const gpsacq_params* params, gpsacq_engine** out) {
     HCK(hipMalloc((void**)&e->d_t2, T.t2.size() * sizeof(cf)));
     HCK(hipMalloc((void**)&e->d_tn, hp->tn.size() * sizeof(cf)));
     HCK(hipMemcpy(e->d_tn, hp->tn.data(), hp->tn.size() * sizeof(cf), hipMemcpyHostToDevice));
-    HCK(hipMalloc((void**)&e->d_rot8, hp->rot8.size() * sizeof(cf)));
-    HCK(hipMemcpy(e->d_rot8, hp->rot8.data(), hp->rot8.size() * sizeof(cf), hipMemcpyHostToDevice));
     HCK(hipMalloc((void**)&e->d_lutc, hp->lutc.size() * sizeof(cf)));
     HCK(hipMemcpy(e->d_lutc, hp->lutc.data(), hp->lutc.size() * sizeof(cf), hipMemcpyHostToDevice));
     HCK(upload_wq(T.wq.data()));
@@ -378,22 +359,6 @@ extern "C" int gpsacq_create(const gpsacq_params* params, gpsacq_engine** out) {
         HCK(hipMalloc((void**)&e->d_rho, sizeof rho));
         HCK(hipMemcpy(e->d_rho, rho, sizeof rho, hipMemcpyHostToDevice));
     }
-#ifdef ACQ_EXPERIMENTS
-    {
-        const Tables8& T8 = hp->T8;
-        HCK(hipMalloc((void**)&e->d_t1_8, T8.t1.size() * sizeof(cf)));
-        HCK(hipMalloc((void**)&e->d_t2_8, T8.t2.size() * sizeof(cf)));
-        HCK(hipMalloc((void**)&e->d_t3_8, T8.t3.size() * sizeof(cf)));
-        HCK(hipMalloc((void**)&e->d_bq8, T8.bq.size() * sizeof(cf)));
-        HCK(hipMemcpy(e->d_t1_8, T8.t1.data(), T8.t1.size() * sizeof(cf), hipMemcpyHostToDevice));
-        HCK(hipMemcpy(e->d_t2_8, T8.t2.data(), T8.t2.size() * sizeof(cf), hipMemcpyHostToDevice));
-        HCK(hipMemcpy(e->d_t3_8, T8.t3.data(), T8.t3.size() * sizeof(cf), hipMemcpyHostToDevice));
-        HCK(hipMemcpy(e->d_bq8, T8.bq.data(), T8.bq.size() * sizeof(cf), hipMemcpyHostToDevice));
-        HCK(upload_wq8(T8.wq.data()));
-        const char* c8 = getenv("GPSACQ_CORR8");
-        e->corr8 = (c8 && *c8) ? atoi(c8) : 0;
-    }
-#endif
     HCK(hipMalloc((void**)&e->d_fold, hp->TF.fold.size() * sizeof(cf)));
     HCK(hipMemcpy(e->d_fold, hp->TF.fold.data(), hp->TF.fold.size() * sizeof(cf), hipMemcpyHostToDevice));
     HCK(hipMalloc((void**)&e->d_bq, T.bq.size() * sizeof(cf)));
@@ -639,12 +604,6 @@ static int search_core(gpsacq_engine* e, const Capture& cap_in, size_t n_blocks,
     ca.bq = e->d_bq;
     ca.fold = e->d_fold;
     ca.rho_map = e->d_rho;
-#ifdef ACQ_EXPERIMENTS
-    ca.t1_8 = e->d_t1_8;
-    ca.t2_8 = e->d_t2_8;
-    ca.t3_8 = e->d_t3_8;
-    ca.bq8 = e->d_bq8;
-#endif
     ca.cells = d_cells;
     ca.n_tasks = (int)n_tasks;
     ca.ndop = e->ndop;
@@ -659,11 +618,6 @@ static int search_core(gpsacq_engine* e, const Capture& cap_in, size_t n_blocks,
     ca.n_code = GPSACQ_NUM_SATS + (int)e->patch_cap;
     ca.sub = e->sub;
     ca.dstride = e->dstride;
-    if (e->prof && e->mc == 22 && e->n_acc == 1) {  // the profiled instance exists for the 22-column coherent kernel only
-        if (!e->d_prof) HIPCHK(hipMalloc((void**)&e->d_prof, 1024 * 16 * sizeof(unsigned long long)));
-        HIPCHK(hipMemsetAsync(e->d_prof, 0, 1024 * 16 * sizeof(unsigned long long), e->stream));
-        ca.prof = e->d_prof;
-    }
     if (e->block_align && e->n_acc > 1) {
         if ((double)e->nlags * 1000.0 != e->p.fs) return fail(GPSACQ_ERR_UNSUPPORTED, "block alignment needs a whole number of samples per code period (fs = %g Hz)", e->p.fs);
         const long long t = (long long)e->acc_step * (long long)block_samples;
@@ -677,12 +631,6 @@ static int search_core(gpsacq_engine* e, const Capture& cap_in, size_t n_blocks,
         // samples the code advances per accumulated block per Doppler bin: elapsed samples x (bin Hz / L1)
         if (e->creep_comp && e->n_acc > 1)
             ca.creep = (float)((double)e->acc_step * block_samples * (e->p.fs / N_FFT * e->dstride / e->sub) / 1575.42e6);
-#ifdef ACQ_EXPERIMENTS
-        const int mc8 = corr8_columns(e->nlags);
-        if (e->corr8 >= 2 && e->n_acc == 1 && mc8 > 0) {
-            if (launch_corr8(ca, mc8, e->corr8, e->stream) != 0) return fail(GPSACQ_ERR_UNSUPPORTED, "no 8-wave correlate kernel for %d columns", mc8);
-        } else
-#endif
         if (launch_corr(ca, e->mc, e->stream) != 0) return fail(GPSACQ_ERR_UNSUPPORTED, "no correlate kernel for %d columns", e->mc);
     } else if (realign) {
         // re-aligned lags cross the passes' column windows: the per-lag sums of every cell go to device memory (nlags floats per
@@ -723,21 +671,6 @@ static int search_core(gpsacq_engine* e, const Capture& cap_in, size_t n_blocks,
     }
     HIPCHK(hipGetLastError());
     HIPCHK(hipEventRecord(ev[2], e->stream));
-    if (ca.prof) {  // wave-role 0 and role 3 (lane 0): cycles summed over all workgroups, per segment
-        std::vector<unsigned long long> hb(1024 * 16);
-        HIPCHK(hipMemcpyAsync(hb.data(), e->d_prof, hb.size() * sizeof(unsigned long long), hipMemcpyDeviceToHost, e->stream));
-        HIPCHK(hipStreamSynchronize(e->stream));
-        unsigned long long h[16] = {0};
-        for (size_t i = 0; i < hb.size(); ++i) h[i & 15] += hb[i];
-        static const char* seg[8] = {"-", "load+mul+pass1", "barrier1", "pass2", "barrier2", "pass3", "barrier3", "scan"};
-        const double cells = (double)n_tasks * e->ndop;
-        for (int r = 0; r < 2; ++r) {
-            fprintf(stderr, "k_corr profile, wave %d, cycles per cell:", r ? 3 : 0);
-            double tot = 0;
-            for (int k = 0; k < 8; ++k) { fprintf(stderr, " %s %.0f", seg[k], h[8 * r + k] / cells); tot += h[8 * r + k] / cells; }
-            fprintf(stderr, " | total %.0f\n", tot);
-        }
-    }
     launch_peaks(d_cells, d_peaks, (int)n_tasks, e->ndop, e->dop_first, e->stream);
     HIPCHK(hipGetLastError());
     HIPCHK(hipEventRecord(ev[3], e->stream));
@@ -1013,20 +946,16 @@ extern "C" int gpsacq_set_doppler_step(gpsacq_engine* e, double step_hz) {
     if (2 * kmax + 1 > 0xFFFF) return fail(GPSACQ_ERR_UNSUPPORTED, "%d Doppler points exceed the 65535 the peak keys can carry", 2 * kmax + 1);
     if (sub != e->sub) {  // forward-transform tables of the sub-bin offsets
         HIPCHK(hipStreamSynchronize(e->stream));
-        std::vector<cf> tn, rot8, lutc;
-        forward_tables(sub, tn, rot8, &lutc);
-        cf *ntn = nullptr, *nrot = nullptr, *nlut = nullptr;
+        std::vector<cf> tn, lutc;
+        forward_tables(sub, tn, &lutc);
+        cf *ntn = nullptr, *nlut = nullptr;
         HIPCHK(hipMalloc((void**)&ntn, tn.size() * sizeof(cf)));
-        HIPCHK(hipMalloc((void**)&nrot, rot8.size() * sizeof(cf)));
         HIPCHK(hipMalloc((void**)&nlut, lutc.size() * sizeof(cf)));
         HIPCHK(hipMemcpy(ntn, tn.data(), tn.size() * sizeof(cf), hipMemcpyHostToDevice));
-        HIPCHK(hipMemcpy(nrot, rot8.data(), rot8.size() * sizeof(cf), hipMemcpyHostToDevice));
         HIPCHK(hipMemcpy(nlut, lutc.data(), lutc.size() * sizeof(cf), hipMemcpyHostToDevice));
         HIPCHK(hipFree(e->d_tn));
-        HIPCHK(hipFree(e->d_rot8));
         HIPCHK(hipFree(e->d_lutc));
         e->d_tn = ntn;
-        e->d_rot8 = nrot;
         e->d_lutc = nlut;
     }
     e->sub = sub;

@@ -8,7 +8,6 @@
 #include <vector>
 
 #include "../../gnss-gps-sdr_amd/csrc/acq_phases.hpp"
-#include "../../gnss-gps-sdr_amd/csrc/acq_corr8.hpp"
 #include "../../gnss-gps-sdr_amd/csrc/acq_tables.hpp"
 
 using namespace acq;
@@ -51,33 +50,16 @@ static void pp_to_natural(const cf* pp, long row, int off, bool conj, float* out
 extern "C" {
 
 // Sample(): spectrum of one 5120-byte block in natural order (un-conjugated); spectrum r of `sub` sub-bin Doppler
-// offsets (r = 0, sub = 1: the reference's Sample()).
+// offsets (r = 0, sub = 1: the reference's Sample()), through the phases of k_fwd2: bytes in registers, host-built conjugated
+// look-up table, the transform run backwards on conjugated inputs, derived pass-1 twiddles.
 void emul_forward_bits_sub(const uint8_t* bytes, const uint8_t* cosm, const uint8_t* sinm, int sub, int r, float* out) {
-    std::vector<uint64_t> ib(625), qb(625), cos_t(625), sin_t(625);
-    transpose_masks(cosm, cos_t.data());
-    transpose_masks(sinm, sin_t.data());
-    for (int tid = 0; tid < WG; ++tid) fwd_stage_bits(tid, bytes, cos_t.data(), sin_t.data(), ib.data(), qb.data());
-    std::vector<cf> tn, rot8;
-    forward_tables(sub, tn, rot8);
-    std::vector<cf> pp((size_t)NPOLY * M_SUB);
-    for (int kappa = 0; kappa < NPOLY; ++kappa) {  // the look-up table depends on the row
-        std::vector<cf> lut(256);
-        for (int tid = 0; tid < WG; ++tid) fwd_build_lut(tid, rot8.data() + ((size_t)r * NPOLY + kappa) * NPOLY, lut.data());
-        BitsSrc src{reinterpret_cast<const uint8_t*>(ib.data()), reinterpret_cast<const uint8_t*>(qb.data()), lut.data()};
-        emul_fwd_row(src, kappa, true, pp.data() + (size_t)kappa * M_SUB, tn.data() + ((size_t)r * NPOLY + kappa) * M_SUB);
-    }
-    pp_to_natural(pp.data(), M_SUB, 0, true, out);
-}
-// The same through the second form of the 1-bit path (k_fwd2: bytes in registers, host-built conjugated look-up table, the
-// transform run backwards on conjugated inputs, derived pass-1 twiddles): spectrum r of `sub` sub-bin offsets, natural order.
-void emul_forward_bits2_sub(const uint8_t* bytes, const uint8_t* cosm, const uint8_t* sinm, int sub, int r, float* out) {
     const Tables& T = tables();
     std::vector<uint64_t> ib(625), qb(625), cos_t(625), sin_t(625);
     transpose_masks(cosm, cos_t.data());
     transpose_masks(sinm, sin_t.data());
     for (int tid = 0; tid < WG; ++tid) fwd_stage_bits(tid, bytes, cos_t.data(), sin_t.data(), ib.data(), qb.data());
-    std::vector<cf> tn, rot8, lutc;
-    forward_tables(sub, tn, rot8, &lutc);
+    std::vector<cf> tn, lutc;
+    forward_tables(sub, tn, &lutc);
     std::vector<cf> pp((size_t)NPOLY * M_SUB), lds(Fwd2Lay::SIZE);
     std::vector<uint32_t> packed((size_t)WG * RA);
     std::vector<cf> w1((size_t)WG * 2 * (RA - 1));
@@ -116,11 +98,9 @@ void emul_forward_real(const float* x, float* out) {
 // lay: 1 = LayB (round 2's lane map), 2 = LayC (the product's: conflict-free lane assignment)
 template <class L>
 static int emul_cell_l(const float* dspec, const float* cspec, int halo, int dop, int S, int mc, int w1h, float* max_pwr,
-                       int* max_i, float* tot_pwr, bool fold = false, bool rot = false) {
+                       int* max_i, float* tot_pwr, bool fold = false) {
     const Tables& T = tables();
     static const TablesFold TF;
-    cf w25s[25];
-    for (int i = 0; i < 25; ++i) w25s[i] = w25_of(i / 5, i % 5);
     const int crow = M_SUB + 2 * halo;
     std::vector<cf> dpp((size_t)NPOLY * M_SUB), cpp((size_t)NPOLY * crow);
     for (int k = 0; k < N_FFT; ++k) {
@@ -147,20 +127,7 @@ static int emul_cell_l(const float* dspec, const float* cspec, int halo, int dop
             else corr_phase1<2, false, L>(tid, q, dop, dpp.data(), cpp.data(), crow, halo, w, lds.data());
         }
         const cf* t2_of_q = fold ? TF.t2q.data() + (size_t)q * NT2 : T.t2.data();
-        if (rot) {  // pass 2 by roles, the light role visiting wave (3 - q) mod 4 (k_corr<..., ROT>); its two rounds are wave-wide steps
-            for (int wave = 0; wave < WG / 64; ++wave) {
-                const int role = (wave + q) & 3;
-                if (role < 3) {
-                    for (int lane = 0; lane < 64; ++lane) pass2_inplace<+1, L>(64 * role + lane, t2_of_q, lds.data());
-                } else {
-                    for (int lane = 0; lane < 40; ++lane) pass2_light_a<+1, L>(lane, w25s, lds.data());
-                    const std::vector<cf> snap(lds);
-                    for (int lane = 0; lane < 40; ++lane) pass2_light_b<+1, L>(lane, t2_of_q, snap.data(), lds.data());
-                }
-            }
-        } else {
-            for (int tid = 0; tid < WG; ++tid) corr_phase2<L>(tid, t2_of_q, lds.data());
-        }
+        for (int tid = 0; tid < WG; ++tid) corr_phase2<L>(tid, t2_of_q, lds.data());
         if (fold) {  // the workgroup's LDS copy of this sub-transform's accumulate factors, as the kernel lays it out
             std::vector<cf> tqs((size_t)RA * 42, mk(0.f, 0.f));
             auto fill = [&](int tqs_stride) {
@@ -224,64 +191,11 @@ int emul_cell(const float* dspec, const float* cspec, int halo, int dop, int S, 
     if (lay == 1) return emul_cell_l<LayB>(dspec, cspec, halo, dop, S, mc, w1h, max_pwr, max_i, tot_pwr);
     if (lay == 2) return emul_cell_l<LayC>(dspec, cspec, halo, dop, S, mc, w1h, max_pwr, max_i, tot_pwr);
     if (lay == 3) return emul_cell_l<LayC>(dspec, cspec, halo, dop, S, mc, w1h, max_pwr, max_i, tot_pwr, true);  // folded rotation (k_corr<..., FOLD>)
-    if (lay == 4) return emul_cell_l<LayC>(dspec, cspec, halo, dop, S, mc, w1h, max_pwr, max_i, tot_pwr, true, true);  // ... + pass 2 by rotating roles (ROT)
-    if (lay == 5) return emul_cell_l<LayC>(dspec, cspec, halo, dop, S, mc, w1h, max_pwr, max_i, tot_pwr, false, true);  // roles without the fold
     return -1;
 }
 }  // extern "C"
 
-// One cell through the 8-wave correlator (acq_corr8.hpp): 5 x 10 x 10 x 10 on 500 threads.
-template <int MC>
-static int emul_cell8_mc(const cf* dpp, const cf* cpp, int crow, int halo, int dop, int S, float* max_pwr, int* max_i, float* tot_pwr) {
-    static Tables8 T;
-    std::vector<cf> lds(Lay8::SIZE);
-    std::vector<cf> acc((size_t)WG8 * MC8_MAX, mk(0.f, 0.f));
-    std::vector<cf> w1((size_t)WG8 * 2 * (R8A - 1));
-    for (int tid = 0; tid < WG8; ++tid) load_tw8(tid, T.t1.data(), *reinterpret_cast<cf(*)[2][R8A - 1]>(&w1[(size_t)tid * 2 * (R8A - 1)]));
-    for (int q = 0; q < NPOLY; ++q) {
-        for (int tid = 0; tid < WG8; ++tid)
-            corr8_phase1(tid, q, dop, dpp, cpp, crow, halo, *reinterpret_cast<cf(*)[2][R8A - 1]>(&w1[(size_t)tid * 2 * (R8A - 1)]), lds.data());
-        for (int tid = 0; tid < WG8; ++tid) corr8_phase2(tid, T.t2.data(), lds.data());
-        for (int tid = 0; tid < WG8; ++tid) corr8_phase3(tid, T.t3.data(), lds.data());
-        for (int tid = 0; tid < WG8; ++tid)
-            corr8_phase4<MC>(tid, T.bq[(size_t)q * 500 + (tid < NT8 ? tid : 0)], &T.wq[(size_t)q * WQ8_STRIDE], lds.data(), &acc[(size_t)tid * MC8_MAX]);
-    }
-    float mx = 0.f, sum = 0.f;
-    int mi = 0;
-    for (int tid = 0; tid < WG8; ++tid) {
-        float tmx, tsum;
-        int tmi;
-        corr8_scan<MC>(tid, S, &acc[(size_t)tid * MC8_MAX], tmx, tmi, tsum);
-        peak_merge(mx, mi, tmx, tmi);
-        sum += tsum;
-    }
-    *max_pwr = mx;
-    *max_i = mi;
-    *tot_pwr = sum;
-    return 0;
-}
-
 extern "C" {
-int emul_cell8(const float* dspec, const float* cspec, int halo, int dop, int S, float* max_pwr, int* max_i, float* tot_pwr) {
-    const int crow = M_SUB + 2 * halo;
-    std::vector<cf> dpp((size_t)NPOLY * M_SUB), cpp((size_t)NPOLY * crow);
-    for (int k = 0; k < N_FFT; ++k) {
-        dpp[(size_t)(k & 7) * M_SUB + (k >> 3)] = mk(dspec[2 * k], -dspec[2 * k + 1]);
-        cpp[(size_t)(k & 7) * crow + halo + (k >> 3)] = mk(cspec[2 * k], cspec[2 * k + 1]);
-    }
-    for (int q = 0; q < NPOLY; ++q)
-        for (int h = 0; h < halo; ++h) {
-            cpp[(size_t)q * crow + h] = cpp[(size_t)q * crow + M_SUB + h];
-            cpp[(size_t)q * crow + halo + M_SUB + h] = cpp[(size_t)q * crow + halo + h];
-        }
-    const int mc = (S + NT8 - 1) / NT8;
-    if (mc <= 6) return emul_cell8_mc<6>(dpp.data(), cpp.data(), crow, halo, dop, S, max_pwr, max_i, tot_pwr);
-    if (mc <= 11) return emul_cell8_mc<11>(dpp.data(), cpp.data(), crow, halo, dop, S, max_pwr, max_i, tot_pwr);
-    if (mc <= 17) return emul_cell8_mc<17>(dpp.data(), cpp.data(), crow, halo, dop, S, max_pwr, max_i, tot_pwr);
-    if (mc <= 20) return emul_cell8_mc<20>(dpp.data(), cpp.data(), crow, halo, dop, S, max_pwr, max_i, tot_pwr);
-    return -1;
-}
-
 // the product's lane maps, for the LDS conflict model (tools/lds_maps.py): lay 1 = LayB, 2 = LayC
 int emul_pass1_jp(int lay, int t) { return lay == 2 ? pass1_jp<LayC>(t) : pass1_jp<LayB>(t); }
 int emul_pass2_owner(int lay, int e) {

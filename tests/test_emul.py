@@ -22,10 +22,8 @@ def emul():
     vp, d, i = ctypes.c_void_p, ctypes.c_double, ctypes.c_int
     E.emul_forward_bits.argtypes = [vp] * 4
     E.emul_forward_bits_sub.argtypes = [vp, vp, vp, i, i, vp]
-    E.emul_forward_bits2_sub.argtypes = [vp, vp, vp, i, i, vp]
     E.emul_forward_real.argtypes = [vp] * 2
     E.emul_cell.argtypes = [vp, vp, i, i, i, i, i, i, vp, vp, vp]
-    E.emul_cell8.argtypes = [vp, vp, i, i, i, vp, vp, vp]
     E.emul_code_replica.argtypes = [d, i, vp]
     E.emul_lo_masks.argtypes = [d, d, vp, vp]
     E.emul_search_code.argtypes = [i, i]
@@ -80,7 +78,7 @@ def test_emulated_kernels_vs_oracle(emul, golden_dir, fc, fs, file, mc, w1h):
     assert emul.emul_lane_maps_are_permutations() == 0
     for dop in (-orc.dmax, -9, 0, 1, orc.dmax):
         got = {}
-        for lay in (1, 2, 3, 4, 5):  # LayB (round 2's lane map), LayC (conflict-free lanes), LayC + folded rotation, + roles in pass 2, roles alone
+        for lay in (1, 2, 3):  # LayB (round 2's lane map), LayC (conflict-free lanes), LayC + folded rotation
             mp, mi, tp = ctypes.c_float(), ctypes.c_int(), ctypes.c_float()
             assert emul.emul_cell(_p(d_in), _p(c_in), 24, dop, orc.num_lags, mc, w1h, lay, ctypes.byref(mp), ctypes.byref(mi), ctypes.byref(tp)) == 0
             ref = cells[dop + orc.dmax]
@@ -91,16 +89,6 @@ def test_emulated_kernels_vs_oracle(emul, golden_dir, fc, fs, file, mc, w1h):
         assert got[1][:2] == got[2][:2] and abs(got[1][2] / got[2][2] - 1) < 1e-6
         # the folded rotation multiplies by one table value where the other form multiplies by two: powers agree to float rounding
         assert got[3][1] == got[2][1] and abs(got[3][0] / got[2][0] - 1) < 2e-6 and abs(got[3][2] / got[2][2] - 1) < 2e-6
-        # pass 2 by roles (the last 8 radix-25 butterflies as 2 x 40 five-point transforms; a compiled-out experiment): the same
-        # transform -- bit-identical while both formed the inner twiddles as complex products (round 4, experiment G); the product's
-        # radix-25 now folds them into its second-stage butterflies (dft5_tw), the role path keeps the products: float rounding apart
-        for a_, b_ in ((4, 3), (5, 2)):
-            assert got[a_][1] == got[b_][1] and abs(got[a_][0] / got[b_][0] - 1) < 2e-6 and abs(got[a_][2] / got[b_][2] - 1) < 2e-6
-        # the 8-wave correlator (5 x 10 x 10 x 10 on 500 threads, acq_corr8.hpp): another factorisation of the same transform
-        mp, mi, tp = ctypes.c_float(), ctypes.c_int(), ctypes.c_float()
-        assert emul.emul_cell8(_p(d_in), _p(c_in), 24, dop, orc.num_lags, ctypes.byref(mp), ctypes.byref(mi), ctypes.byref(tp)) == 0
-        assert abs(mp.value / ref["max_pwr"] - 1) < 2e-5 and abs(tp.value / ref["tot_pwr"] - 1) < 2e-5 and mi.value == ref["max_i"]
-
 
 def test_emulated_subbin_forward_vs_oracle(emul, golden_dir):
     """Sub-bin Doppler offsets folded into the forward transform's twiddles (gpsacq_set_doppler_step) against the
@@ -119,21 +107,13 @@ def test_emulated_subbin_forward_vs_oracle(emul, golden_dir):
         orc.L.oracle_get_sample_spectrum(orc.h, _p(d_orc))
         a, b = d_emul.view(np.complex64), d_orc.view(np.complex64)
         assert np.abs(a - b).max() / np.abs(b).max() < 3e-6, (sub, r)
-        # the second form of the 1-bit path (k_fwd2): the same spectrum, its own rounding
-        d2 = np.zeros(80000, np.float32)
-        emul.emul_forward_bits2_sub(_p(blk), _p(cosm), _p(sinm), sub, r, _p(d2))
-        assert np.abs(d2.view(np.complex64) - b).max() / np.abs(b).max() < 3e-6, (sub, r)
     # r = 0 is the reference's Sample()
     d0, d1 = np.zeros(80000, np.float32), np.zeros(80000, np.float32)
     emul.emul_forward_bits_sub(_p(blk), _p(cosm), _p(sinm), 3, 0, _p(d0))
     emul.emul_forward_bits(_p(blk), _p(cosm), _p(sinm), _p(d1))
     assert np.array_equal(d0, d1)
-    d2 = np.zeros(80000, np.float32)
-    emul.emul_forward_bits2_sub(_p(blk), _p(cosm), _p(sinm), 1, 0, _p(d2))
     d_orc = orc.sample_spectrum(blk)
-    assert np.abs(d2.view(np.complex64) - d_orc).max() / np.abs(d_orc).max() < 2e-6
-    assert np.abs(d2.view(np.complex64) - d1.view(np.complex64)).max() / np.abs(d_orc).max() < 1e-6  # the two forms of the kernel
-
+    assert np.abs(d1.view(np.complex64) - d_orc).max() / np.abs(d_orc).max() < 2e-6
 
 def test_lane_maps_are_bank_conflict_free_in_the_lds_model(emul):
     """The lane maps the kernels really use (read out of acq_math.hpp through the emulation library) in the instruction-level

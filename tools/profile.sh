@@ -22,6 +22,5 @@ for set in "FETCH_SIZE" "WRITE_SIZE" \
   i=$((i+1))
   rocprofv3 --pmc $set --output-format csv -d $OUT/pmc$i -o p -- python $R/bench.py --steps 2 --warmup 1 --weak-blocks 0 --no-cpu-baseline --no-live-traffic --no-e2e --soak-seconds 0 --no-dist "$@" > $OUT/pmc$i.log 2>&1
 done
-GPSACQ_LIB=$R/build/var_exp/libgpsacq.so GPSACQ_PROF=1 python $R/bench.py --steps 1 --warmup 1 --weak-blocks 0 --no-cpu-baseline --no-live-traffic --no-e2e --soak-seconds 0 --no-dist "$@" > $OUT/phase_profile.log 2>&1
 find $OUT -name "*.db" -delete; find $OUT -type f | head -50 > $OUT/files.txt
 du -sh $OUT

@@ -53,12 +53,6 @@ for name, what in (("bench_traced.log", "traced"), ("bench_unprofiled.log", "un-
                                 cyc = avg_ms * 1e-3 * r["sclk_mhz"] * 1e6 * r.get("compute_units", 256) / r["cells_per_launch"]
                                 clock_lines.append(f"- rocprofv3 trace of that run: k_corr avg {avg_ms:.3f} ms x the same sclk = **{cyc:.0f} cycles per cell per CU**")
                                 break
-pp = os.path.join(src, "phase_profile.log")
-if os.path.exists(pp):
-    ph = [l.strip() for l in open(pp) if "k_corr profile" in l and not l.strip().endswith("total 0")]  # (only the 22-column instance carries the profiler)
-    if ph:
-        lines += ["## s_memtime phase profile (`GPSACQ_PROF=1`, k_corr<22,...,PROF>; cycles per cell per wave, summed over the launch / cells)", ""] + ["    " + l for l in ph[-2:]] + [""]
-
 agg = collections.defaultdict(list)
 for f in sorted(glob.glob(os.path.join(src, "pmc*", "p_counter_collection.csv"))):
     for r in csv.DictReader(open(f)):
