@@ -1016,10 +1016,13 @@ extern "C" int gpsacq_last_timing(const gpsacq_engine* e, gpsacq_timing* t) { re
 
 extern "C" void* gpsacq_stream(gpsacq_engine* e) { return e ? (void*)e->stream : nullptr; }
 
-// Synthetic capture on the device (gps_sig_gen.m's role; signal model of SURVEY.md section 8d)
-extern "C" int gpsacq_generate_device(gpsacq_engine* e, void* d_bits, size_t n_bytes, const gpsacq_sat* sats, int n_sats,
-                                      float noise_sigma, uint64_t seed, int sync) {
-    if (!e || !d_bits || n_bytes == 0 || n_sats < 0 || (n_sats > 0 && !sats)) return fail(GPSACQ_ERR_ARG, "gpsacq_generate_device: bad argument");
+// Synthetic capture on the device (gps_sig_gen.m's role; signal model of SURVEY.md section 8d).  The stream is a function of
+// (seed, satellites, absolute sample index) alone: any byte range of it can be generated anywhere -- a rank of a multi-GPU job
+// makes exactly its own blocks of the one capture every world size searches.
+extern "C" int gpsacq_generate_range_device(gpsacq_engine* e, void* d_bits, size_t n_bytes, uint64_t first_sample, const gpsacq_sat* sats,
+                                            int n_sats, float noise_sigma, uint64_t seed, int sync) {
+    if (!e || !d_bits || n_bytes == 0 || n_sats < 0 || (n_sats > 0 && !sats)) return fail(GPSACQ_ERR_ARG, "gpsacq_generate_range_device: bad argument");
+    if (first_sample & 7) return fail(GPSACQ_ERR_ARG, "gpsacq_generate_range_device: first_sample %llu is not a multiple of 8 (a byte boundary)", (unsigned long long)first_sample);
     HIPCHK(hipSetDevice(e->p.device));
     const double L1 = 1575.42e6, CPS = 1.023e6;
     std::vector<GenSat> gs((size_t)n_sats);
@@ -1040,7 +1043,7 @@ extern "C" int gpsacq_generate_device(gpsacq_engine* e, void* d_bits, size_t n_b
     GenArgs a{};
     a.bits = (uint8_t*)d_bits;
     a.n_bytes = n_bytes;
-    a.first_sample = 0;
+    a.first_sample = first_sample;
     a.seed = seed;
     a.sats = e->d_sats;
     a.n_sats = n_sats;
@@ -1050,16 +1053,24 @@ extern "C" int gpsacq_generate_device(gpsacq_engine* e, void* d_bits, size_t n_b
     if (sync) HIPCHK(hipStreamSynchronize(e->stream));
     return GPSACQ_OK;
 }
+extern "C" int gpsacq_generate_device(gpsacq_engine* e, void* d_bits, size_t n_bytes, const gpsacq_sat* sats, int n_sats,
+                                      float noise_sigma, uint64_t seed, int sync) {
+    return gpsacq_generate_range_device(e, d_bits, n_bytes, 0, sats, n_sats, noise_sigma, seed, sync);
+}
 
-extern "C" int gpsacq_generate(gpsacq_engine* e, uint8_t* bits_out, size_t n_bytes, const gpsacq_sat* sats, int n_sats,
-                               float noise_sigma, uint64_t seed) {
-    if (!e || !bits_out || n_bytes == 0) return fail(GPSACQ_ERR_ARG, "gpsacq_generate: bad argument");
+extern "C" int gpsacq_generate_range(gpsacq_engine* e, uint8_t* bits_out, size_t n_bytes, uint64_t first_sample, const gpsacq_sat* sats,
+                                     int n_sats, float noise_sigma, uint64_t seed) {
+    if (!e || !bits_out || n_bytes == 0) return fail(GPSACQ_ERR_ARG, "gpsacq_generate_range: bad argument");
     HIPCHK(hipSetDevice(e->p.device));
     if (int rc = grow(e->d_gen, e->gen_cap, n_bytes, e->stream)) return rc;
-    if (int rc = gpsacq_generate_device(e, e->d_gen, n_bytes, sats, n_sats, noise_sigma, seed, 0)) return rc;
+    if (int rc = gpsacq_generate_range_device(e, e->d_gen, n_bytes, first_sample, sats, n_sats, noise_sigma, seed, 0)) return rc;
     HIPCHK(hipMemcpyAsync(bits_out, e->d_gen, n_bytes, hipMemcpyDeviceToHost, e->stream));
     HIPCHK(hipStreamSynchronize(e->stream));
     return GPSACQ_OK;
+}
+extern "C" int gpsacq_generate(gpsacq_engine* e, uint8_t* bits_out, size_t n_bytes, const gpsacq_sat* sats, int n_sats,
+                               float noise_sigma, uint64_t seed) {
+    return gpsacq_generate_range(e, bits_out, n_bytes, 0, sats, n_sats, noise_sigma, seed);
 }
 
 // gps_sig_gen.m's signal for any PRN / navigation bits (k_siggen)

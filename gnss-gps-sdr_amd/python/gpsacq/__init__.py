@@ -62,7 +62,7 @@ class Sat(ctypes.Structure):
                 ("code_phase_samples", ctypes.c_double), ("carrier_phase_cycles", ctypes.c_double)]
 
 
-EXPORTS = ["gpsacq_generate", "gpsacq_generate_device", "gpsacq_generate_sig", "gpsacq_sig_bytes", "gpsacq_handoff", "gpsacq_iq8_to_bits", "gpsacq_iq8_to_bits_device", "gpsacq_create", "gpsacq_destroy", "gpsacq_last_error", "gpsacq_get_info", "gpsacq_search",
+EXPORTS = ["gpsacq_generate", "gpsacq_generate_device", "gpsacq_generate_range", "gpsacq_generate_range_device", "gpsacq_generate_sig", "gpsacq_sig_bytes", "gpsacq_handoff", "gpsacq_iq8_to_bits", "gpsacq_iq8_to_bits_device", "gpsacq_create", "gpsacq_destroy", "gpsacq_last_error", "gpsacq_get_info", "gpsacq_search",
            "gpsacq_search_device", "gpsacq_set_doppler_window", "gpsacq_set_doppler_step", "gpsacq_set_noncoherent", "gpsacq_set_creep_compensation", "gpsacq_set_block_alignment", "gpsacq_aligned_stride", "gpsacq_synchronize", "gpsacq_last_timing", "gpsacq_timing_ago", "gpsacq_stream", "gpsacq_search_code",
            "gpsacq_sample_spectrum", "gpsacq_code_spectrum", "gpsacq_multi_create", "gpsacq_multi_destroy",
            "gpsacq_multi_set_doppler_step", "gpsacq_multi_get_info", "gpsacq_multi_search_grid", "gpsacq_multi_search_blocks",
@@ -144,6 +144,10 @@ def load_library(path=None):
     lib.gpsacq_generate.restype = ctypes.c_int
     lib.gpsacq_generate_device.argtypes = [vp, vp, sz, ctypes.POINTER(Sat), ctypes.c_int, ctypes.c_float, ctypes.c_uint64, ctypes.c_int]
     lib.gpsacq_generate_device.restype = ctypes.c_int
+    lib.gpsacq_generate_range.argtypes = [vp, vp, sz, ctypes.c_uint64, ctypes.POINTER(Sat), ctypes.c_int, ctypes.c_float, ctypes.c_uint64]
+    lib.gpsacq_generate_range.restype = ctypes.c_int
+    lib.gpsacq_generate_range_device.argtypes = [vp, vp, sz, ctypes.c_uint64, ctypes.POINTER(Sat), ctypes.c_int, ctypes.c_float, ctypes.c_uint64, ctypes.c_int]
+    lib.gpsacq_generate_range_device.restype = ctypes.c_int
     lib.gpsacq_sig_bytes.argtypes = [ctypes.c_int]
     lib.gpsacq_sig_bytes.restype = ctypes.c_size_t
     lib.gpsacq_generate_sig.argtypes = [vp, ctypes.c_int, vp, ctypes.c_int, vp, sz]
@@ -434,12 +438,13 @@ class Engine:
             arr[i] = Sat(int(prn), float(amp), float(dop), float(ca), float(ph))
         return arr
 
-    def generate(self, n_bytes, sats=(), noise_sigma=1.0, seed=1):
+    def generate(self, n_bytes, sats=(), noise_sigma=1.0, seed=1, first_sample=0):
         """Synthetic 1-bit real-IF capture made on the device: sats = [(prn, amplitude, doppler_hz,
-        code_phase_samples, carrier_phase_cycles), ...] on top of white noise (gps_sig_gen.m's role)."""
+        code_phase_samples, carrier_phase_cycles), ...] on top of white noise (gps_sig_gen.m's role).  first_sample (a multiple
+        of 8): the n_bytes that start there in the stream -- any range of one capture, bit for bit."""
         out = np.zeros(int(n_bytes), dtype=np.uint8)
-        _check(self._lib, self._lib.gpsacq_generate(self._h, out.ctypes.data_as(ctypes.c_void_p), int(n_bytes), self._sats(sats),
-                                                    len(sats), float(noise_sigma), int(seed)))
+        _check(self._lib, self._lib.gpsacq_generate_range(self._h, out.ctypes.data_as(ctypes.c_void_p), int(n_bytes), int(first_sample),
+                                                          self._sats(sats), len(sats), float(noise_sigma), int(seed)))
         return out
 
     def generate_sig(self, prn, data_bits):
@@ -463,9 +468,9 @@ class Engine:
                                                            int(first_sample), n, out.ctypes.data_as(ctypes.c_void_p)))
         return out
 
-    def generate_device(self, d_bits_ptr, n_bytes, sats=(), noise_sigma=1.0, seed=1, sync=True):
-        _check(self._lib, self._lib.gpsacq_generate_device(self._h, d_bits_ptr, int(n_bytes), self._sats(sats), len(sats),
-                                                           float(noise_sigma), int(seed), 1 if sync else 0))
+    def generate_device(self, d_bits_ptr, n_bytes, sats=(), noise_sigma=1.0, seed=1, sync=True, first_sample=0):
+        _check(self._lib, self._lib.gpsacq_generate_range_device(self._h, d_bits_ptr, int(n_bytes), int(first_sample), self._sats(sats),
+                                                                 len(sats), float(noise_sigma), int(seed), 1 if sync else 0))
 
     # ---- 8-bit IQ ingestion --------------------------------------------------------------
     def iq8_to_bits(self, iq, signed=False, remove_dc=True, mix_hz=0.0, fs=0.0):

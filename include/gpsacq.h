@@ -335,6 +335,13 @@ GPSACQ_API int gpsacq_generate(gpsacq_engine* e, uint8_t* bits_out, size_t n_byt
                     float noise_sigma, uint64_t seed);
 GPSACQ_API int gpsacq_generate_device(gpsacq_engine* e, void* d_bits_out, size_t n_bytes, const gpsacq_sat* sats, int n_sats,
                            float noise_sigma, uint64_t seed, int sync);
+/* Any byte range of that stream: the n_bytes that start at sample first_sample (a multiple of 8) -- byte first_sample / 8 of what
+ * gpsacq_generate() writes for the same seed and satellites, bit for bit (noise and signals are functions of the absolute sample
+ * index).  One rank of a multi-GPU job generates exactly its own blocks of THE capture every world size searches. */
+GPSACQ_API int gpsacq_generate_range(gpsacq_engine* e, uint8_t* bits_out, size_t n_bytes, uint64_t first_sample, const gpsacq_sat* sats,
+                          int n_sats, float noise_sigma, uint64_t seed);
+GPSACQ_API int gpsacq_generate_range_device(gpsacq_engine* e, void* d_bits_out, size_t n_bytes, uint64_t first_sample,
+                                 const gpsacq_sat* sats, int n_sats, float noise_sigma, uint64_t seed, int sync);
 
 /*
  * The reference's own test signal (gps_sig_gen.m:8-41, the script that wrote gps_sig_tmp.bin), generated on the device:

@@ -234,6 +234,14 @@ int emul_lane_maps_are_permutations(void) {
 void emul_code_replica(double fs, int sv, float* out) { code_replica(fs, sv, out); }
 void emul_lo_masks(double fc, double fs, uint8_t* cosm, uint8_t* sinm) { lo_masks(fc, fs, BLOCK_BYTES, cosm, sinm); }
 int emul_search_code(int sv, int g1) { return search_code(sv, g1); }
+// the product's C/A generator (acq_tables.hpp CaCode + kTaps: what gpsacq_create feeds the replicas and the device chip table from)
+void emul_ca_chips(int sv, unsigned char* chips /*[1023]*/) {
+    CaCode ca(kTaps[sv][0], kTaps[sv][1]);
+    for (int i = 0; i < 1023; ++i) {
+        chips[i] = (unsigned char)ca.chip();
+        ca.clock();
+    }
+}
 int emul_dmax(double fs, double max_fo) { return doppler_half_range(fs, max_fo); }
 int emul_nlags(double fs) { return num_lags(fs); }
 }

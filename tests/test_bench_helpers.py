@@ -1,5 +1,6 @@
-"""bench.py's measurement helpers that need no GPU: the sysfs clock / power reader behind roofline.sclk_mhz and the sampler's
-statistics (CPU suite; the GPU box runs them for real in tests/test_gpu_round5.py)."""
+"""bench_extras.py's measurement helpers that need no GPU (bench.py re-exports what its own core uses): the sysfs clock / power
+reader behind roofline.sclk_mhz, the sampler's statistics, the host half of the parity verdict, the key digest
+(CPU suite; the GPU box runs them for real in tests/test_gpu_round5.py / test_gpu_round6.py)."""
 import importlib.util
 import os
 import time
@@ -8,7 +9,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
 def _bench():
-    spec = importlib.util.spec_from_file_location("bench_mod", os.path.join(ROOT, "bench.py"))
+    spec = importlib.util.spec_from_file_location("bench_extras_mod", os.path.join(ROOT, "bench_extras.py"))
     m = importlib.util.module_from_spec(spec)
     spec.loader.exec_module(m)
     return m
@@ -84,3 +85,40 @@ def test_compare_peaks_verdict_logic(monkeypatch):
     off_grid["lo_shift"][2] = 500
     r, _, _ = b.compare_peaks(cfg, off_grid, cpu, bits)
     assert r["unproven_mismatches"] == [2]
+
+
+def test_non_finite_gpu_values_are_never_within_tolerance():
+    """A GPU peak whose SNR is NaN but whose code phase and Doppler bin happen to match must fail the verdict (np.nanmax used to skip
+    it: ADVICE r5)."""
+    import numpy as np
+    from oracle_lib import Oracle
+    b = _bench()
+    cfg = b.CONFIGS[1]
+    bits = np.frombuffer(open(os.path.join(ROOT, "tests", "golden", "synth_nott_fs5456.bin"), "rb").read()[:4 * 5120], dtype=np.uint8)
+    _, cpu = Oracle(cfg["fc"], cfg["fs"], cfg["max_fo"], kind="f32").bench_blocks(bits, 4)
+    _, gpu = Oracle(cfg["fc"], cfg["fs"], cfg["max_fo"], kind="f64").search(bits.tobytes())
+    bad = gpu.copy()
+    bad["snr"][1] = np.nan
+    r, _, _ = b.compare_peaks(cfg, bad, cpu, bits)
+    assert r["ca_equal"] == 4 and r["non_finite_gpu_peaks"] == 1 and r["unproven_mismatches"] == [1]
+    assert not (r["snr_max_rel"] <= b.PARITY_SNR_REL)
+    bad["snr"][1] = np.inf
+    r, _, _ = b.compare_peaks(cfg, bad, cpu, bits)
+    assert r["n_unproven"] == 1 and not (r["snr_max_rel"] <= b.PARITY_SNR_REL)
+
+
+def test_keys_digest_and_host_packing():
+    """keys_digest: 16 hex digits of sha256 over the int64 keys; pack_keys_host: the packing of gpsacq_peak_keys_device /
+    gpsacq.dist.pack_keys on PEAK records (integer MAX = higher SNR, ties to the lower Doppler bin, c/search_offline.cpp:196-198)."""
+    import numpy as np
+    import torch
+    from gpsacq import dist as D
+    b = _bench()
+    pk = np.zeros(4, dtype=[("snr", "<f4"), ("lo_shift", "<i4"), ("ca_shift", "<i4"), ("max_pwr", "<f4")])
+    pk["snr"], pk["lo_shift"], pk["ca_shift"] = [30.5, 30.5, 12.0, 0.0], [-3, 4, 0, 0], [100, 5455, 7, 0]
+    keys = b.pack_keys_host(pk, 36)
+    t = torch.from_numpy(np.stack([pk["snr"].view("<i4"), pk["lo_shift"], pk["ca_shift"], pk["max_pwr"].view("<i4")], axis=1).astype(np.int32))
+    assert np.array_equal(keys, D.pack_keys(t, 36).numpy())
+    assert keys[0] > keys[1] > keys[2] > keys[3]  # equal SNR: the lower Doppler bin wins
+    d = b.keys_digest(keys)
+    assert len(d) == 16 and d == b.keys_digest(keys.copy()) and d != b.keys_digest(keys[::-1])

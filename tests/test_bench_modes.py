@@ -76,8 +76,9 @@ def test_eight_ranks_share_the_nottingham_sized_capture():
     """The driver's N = 8 launch line (`python -m torch.distributed.run --nnodes=1 --nproc-per-node 8 ... bench.py --gpus 8`) on the
     one-GPU box: gloo collectives, all eight ranks on device 0, the capture of the headline configuration (340 runs = 10 880
     blocks).  Pins what the first real SCALE run must not trip over: the split of 340 runs over 8 ranks (43 x 4 + 42 x 4 runs),
-    eight ranks seen by the collective, the satellites of EVERY rank's part of the capture in the merged keys, and a stdout that
-    carries the JSON line and nothing else (seven other ranks and torchrun write elsewhere)."""
+    eight ranks seen by the collective, the capture's satellites in the merged keys, the in-process multi-GPU leg (eight engines of the C
+    ABI on the one GPU) reproducing those keys, and a stdout that carries the JSON line and nothing else (seven other ranks, the child
+    process and torchrun write elsewhere)."""
     import socket
     with socket.socket() as sk:
         sk.bind(("127.0.0.1", 0))
@@ -95,7 +96,9 @@ def test_eight_ranks_share_the_nottingham_sized_capture():
     assert j["n_gpus"] == 8 and j["rccl_ranks_seen"] == 8 and j["dist_backend"] == "gloo" and j["steps"] == 3
     assert j["blocks_per_rank"] == [1376] * 4 + [1344] * 4 and sum(j["blocks_per_rank"]) == 10880
     assert j["config"]["cells_per_step_job"] == 10880 * 73 and j["config"]["blocks_rank0"] == 1376 and j["scaling"] == "strong"
-    assert len(j["injected_prns_all_ranks"]) > 8  # eight differently seeded parts
-    assert set(j["detected_prns"]) >= set(j["injected_prns_all_ranks"])
+    assert len(j["injected_prns_all_ranks"]) == 8  # ONE capture (seed 1000), every rank its own blocks of it
+    assert set(j["detected_prns"]) >= set(j["injected_prns_all_ranks"]) and len(j["keys_digest"]) == 16
+    im = j["extras"]["inproc_multi"]
+    assert "error" not in im and im["keys_equal_digest"] is True and im["runs"] == 340, im
     assert j["weak_scaling"]["blocks_per_gpu"] == 4096 and j["weak_scaling"]["value"] > 0
     assert j["value"] > 0 and 0 < j["roofline"]["frac"] < 1 and "cpu_baseline" not in j

@@ -27,6 +27,7 @@ def emul():
     E.emul_code_replica.argtypes = [d, i, vp]
     E.emul_lo_masks.argtypes = [d, d, vp, vp]
     E.emul_search_code.argtypes = [i, i]
+    E.emul_ca_chips.argtypes = [i, vp]
     E.emul_dmax.argtypes = [d, d]
     E.emul_nlags.argtypes = [d]
     return E
@@ -49,6 +50,23 @@ def test_host_tables_bit_exact(emul):
         assert np.array_equal(np.unpackbits(sinm, bitorder="little"), np.array([1, 1, 0, 0], np.uint8)[quad])
         assert emul.emul_dmax(fs, 5000.0) == L.oracle_dmax(fs, 5000.0)
         assert emul.emul_nlags(fs) == L.oracle_nlags(fs)
+
+
+def test_product_ca_generator_against_is_gps_200_table_3_I(emul, golden_dir):
+    """The PRODUCT's C/A generator (acq_tables.hpp: CaCode, an integer shift-register pair, + kTaps) for all 32 PRNs against
+    the reference-held IS-GPS-200G Table 3-I: first ten chips (octal column) and the whole period = G1 xor G2 delayed by the
+    table's chip delay (c/cacode.h:9-35, c/search_offline.cpp:20-53), and against the oracle chip for chip."""
+    from test_oracle import _table_3_I, _g1_g2
+    first10, delays = _table_3_I(golden_dir)
+    g1, g2 = _g1_g2()
+    L = lib("f64")
+    for sv in range(32):
+        chips, o = np.zeros(1023, np.uint8), np.zeros(1023, np.uint8)
+        emul.emul_ca_chips(sv, _p(chips))
+        L.oracle_ca_chips(sv, _p(o))
+        assert list(chips[:10]) == first10[sv], f"PRN {sv + 1}"
+        assert np.array_equal(chips, g1 ^ np.roll(g2, delays[sv])), f"PRN {sv + 1}"
+        assert np.array_equal(chips, o)
 
 
 @pytest.mark.parametrize("fc,fs,file,mc,w1h", [(4.092e6, 5.456e6, "synth_nott_fs5456.bin", 22, 0), (2.046e6, 8.184e6, "gps_sig_tmp.bin", 33, 1),

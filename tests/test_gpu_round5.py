@@ -85,9 +85,10 @@ def test_peak_keys_device_equals_the_torch_packing(golden_dir):
     with gpsacq.Engine(4.092e6, 5.456e6, 5000.0) as eng:
         d_bits = torch.from_numpy(buf[:nblk * 5120].copy()).to(dev)
         d_peaks = torch.zeros((nblk, 4), dtype=torch.int32, device=dev)
-        eng.search_device(d_bits.data_ptr(), nblk, d_peaks.data_ptr(), sync=False)
         k32 = torch.full((32,), -1, dtype=torch.int64, device=dev)
         kall = torch.full((nblk,), -1, dtype=torch.int64, device=dev)
+        torch.cuda.synchronize()  # the fills run on torch's stream, the search on the engine's own (non-blocking) stream: order them
+        eng.search_device(d_bits.data_ptr(), nblk, d_peaks.data_ptr(), sync=False)
         eng.peak_keys_device(d_peaks.data_ptr(), nblk, k32.data_ptr(), per_prn=True)
         eng.peak_keys_device(d_peaks.data_ptr(), nblk, kall.data_ptr(), per_prn=False, sync=True)
         want_all = D.pack_keys(d_peaks, eng.kmax)

@@ -50,6 +50,39 @@ def test_ca_code_properties():
     assert L.oracle_search_code(3, 0x3FF) == 0
 
 
+def _table_3_I(golden_dir):
+    t = json.load(open(os.path.join(golden_dir, "ref_known_answers.json")))["is_gps_200_table_3_I"]
+    first10 = [[(int(o, 8) >> (9 - i)) & 1 for i in range(10)] for o in t["first_10_chips_octal"]]
+    return first10, t["g2_delay_chips"]
+
+
+def _g1_g2():
+    """G1 = 1 + x^3 + x^10, G2 = 1 + x^2 + x^3 + x^6 + x^8 + x^9 + x^10, all-ones start (IS-GPS-200 3.3.2.3): the two
+    maximal-length sequences by themselves, written here independently of the oracle and of the product."""
+    g1, g2, o1, o2 = [1] * 10, [1] * 10, [], []
+    for _ in range(1023):
+        o1.append(g1[9])
+        o2.append(g2[9])
+        g1 = [g1[2] ^ g1[9]] + g1[:9]
+        g2 = [g2[1] ^ g2[2] ^ g2[5] ^ g2[7] ^ g2[8] ^ g2[9]] + g2[:9]
+    return np.array(o1, np.uint8), np.array(o2, np.uint8)
+
+
+def test_all_32_prns_against_is_gps_200_table_3_I(golden_dir):
+    """The reference-held definition of the codes (IS-GPS-200G.pdf, Table 3-I, in the reference repository): the first ten chips
+    of every PRN in octal, and the G2 delay of every PRN -- all 1023 chips = G1 xor G2 delayed by that many chips.  Pins the tap
+    table of c/search_offline.cpp:20-53 and the generator of c/cacode.h:9-35 as the oracle restates them, for every PRN."""
+    first10, delays = _table_3_I(golden_dir)
+    assert len(first10) == 32 and len(delays) == 32
+    L = lib("f64")
+    g1, g2 = _g1_g2()
+    for sv in range(32):
+        chips = np.zeros(1023, np.uint8)
+        L.oracle_ca_chips(sv, _p(chips))
+        assert list(chips[:10]) == first10[sv], f"PRN {sv + 1}"
+        assert np.array_equal(chips, g1 ^ np.roll(g2, delays[sv])), f"PRN {sv + 1}"
+
+
 def test_grid_sizes():
     L = lib("f64")
     L.oracle_dmax.restype = int

@@ -9,7 +9,7 @@ R=${GRAFT_REPO_ROOT:-/root/repo}
 OUT=$R/gpurun_out/prof_$TAG
 mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
-ARGS="--steps 20 --warmup 5 --weak-blocks 0 --no-cpu-baseline --no-live-traffic --no-e2e --soak-seconds 0 --no-dist $@"
+ARGS="--steps 20 --warmup 5 --bare --no-dist $@"
 (cd $R && python -c "import bench; print(bench.kernel_source_sha())") > $OUT/kernel_source_sha.txt  # what the counters belong to
 echo "bench.py $ARGS" > $OUT/command.txt
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace -o t -- python $R/bench.py $ARGS > $OUT/bench_traced.log 2>&1
@@ -18,9 +18,9 @@ i=0
 for set in "FETCH_SIZE" "WRITE_SIZE" \
   "SQ_WAVES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_INSTS_VALU SQ_INSTS_LDS SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_WAIT_INST_LDS" \
   "SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_INSTS_SALU SQ_INSTS_SMEM SQ_INSTS_VMEM_RD" \
-  "TCC_HIT_sum TCC_MISS_sum" "GRBM_GUI_ACTIVE TCP_TCC_READ_REQ_sum"; do
+  "TCC_HIT_sum TCC_MISS_sum" "GRBM_GUI_ACTIVE TCP_TCC_READ_REQ_sum" "TCP_TOTAL_CACHE_ACCESSES_sum"; do
   i=$((i+1))
-  rocprofv3 --pmc $set --output-format csv -d $OUT/pmc$i -o p -- python $R/bench.py --steps 2 --warmup 1 --weak-blocks 0 --no-cpu-baseline --no-live-traffic --no-e2e --soak-seconds 0 --no-dist "$@" > $OUT/pmc$i.log 2>&1
+  rocprofv3 --pmc $set --output-format csv -d $OUT/pmc$i -o p -- python $R/bench.py --steps 2 --warmup 1 --bare --no-dist "$@" > $OUT/pmc$i.log 2>&1
 done
 find $OUT -name "*.db" -delete; find $OUT -type f | head -50 > $OUT/files.txt
 du -sh $OUT

@@ -97,8 +97,18 @@ try:
                               ("SQ_WAIT_INST_LDS", "lds_issue_stall_share_of_wave_cycles"), ("SQ_WAIT_ANY", "waitcnt_barrier_share_of_wave_cycles")):
                 if key in d:
                     onchip[name] = d[key] / d["SQ_WAVE_CYCLES"]
-        if "GRBM_GUI_ACTIVE" in d and "TCP_TCC_READ_REQ_sum" in d:
-            onchip["l2_to_l1_bytes_per_cell"] = d["TCP_TCC_READ_REQ_sum"] * 64.0 / cells
+        if "TCP_TCC_READ_REQ_sum" in d:
+            # one TCP -> TCC read request moves a 128-byte line on gfx950 (the same accounting MI355X_MICROARCH.md documents for FETCH_SIZE:
+            # 128-byte requests tallied at 64).  Cross-check inside this profile: a cell's vector-memory read instructions are 16 bytes per
+            # lane = 1 KiB = 8 lines per wave-instruction, and with ~0 % L1 reuse every one of them becomes requests
+            onchip["l2_to_l1_read_requests_per_cell"] = d["TCP_TCC_READ_REQ_sum"] / cells
+            onchip["l2_to_l1_bytes_per_cell"] = d["TCP_TCC_READ_REQ_sum"] * 128.0 / cells
+            if "SQ_INSTS_VMEM_RD" in d:
+                onchip["l2_to_l1_bytes_per_cell_from_vmem_instr"] = d["SQ_INSTS_VMEM_RD"] * 1024.0 / cells
+                onchip["l1_lines_requested_over_lines_loaded"] = d["TCP_TCC_READ_REQ_sum"] / (d["SQ_INSTS_VMEM_RD"] * 8.0)  # ~1: no L1 reuse
+            for k_tot, k_hit in (("TCP_TOTAL_CACHE_ACCESSES_sum", "TCP_TCC_READ_REQ_sum"),):
+                if k_tot in d and d[k_tot] > 0:
+                    onchip["l1_miss_share_of_accesses"] = d[k_hit] / d[k_tot]
         if "GRBM_GUI_ACTIVE" in d:
             # GRBM_GUI_ACTIVE: shader-clock cycles the kernel kept the GPU busy, summed over the 8 XCDs -- a duration in CYCLES, no clock reading needed
             cyc = d["GRBM_GUI_ACTIVE"] / 8.0 * 256.0 / cells

@@ -4,7 +4,7 @@
 // the rate as roofline.pk_fma_stream_TF next to the 157.3 TFLOP/s of the datasheet (2.4 GHz x 4 cycles per packed
 // instruction): the ceiling a kernel made of nothing but packed FMAs would reach here (measurement aid, not product code).
 // The loop is written on hard-coded registers (256 v_pk_fma_f32 on 8 independent accumulator chains + 3 scalar instructions per
-// trip), so what is timed is the instruction stream below and nothing a compiler added.  tools/ubench/gen_pk_bank.py measured
+// trip), so what is timed is the instruction stream below and nothing a compiler added.  A generator of such streams (round 5, profiles/r05_experiments/a_pk_issue_cost.log) measured
 // that the rate does not depend on where the operands live (VGPR bank pairs, SGPR operand, two or three distinct sources).
 // The operands ROTATE (below), so that the datapath toggles as it does on real data and the clock is the one a transform kernel gets.
 // usage: pk_fma_stream [seconds]   ->  one JSON line on stdout
@@ -24,6 +24,7 @@
 
 template <int LDS_FLOATS> __global__ __launch_bounds__(256) void k_stream(float* out, int iters, float seed) {
     __shared__ float pad[LDS_FLOATS];  // 44 KB: three workgroups per CU, like k_corr (36 KB: four)
+    pad[threadIdx.x] = 0.f;             // (only its own entry is read back below)
     // a different point near the unit circle in every lane (80 000 turns of 2^-10 rad per launch move the radius by 4 %)
     const float ang = 0.001f * (float)(threadIdx.x + 1) + seed, zx = __cosf(ang), zy = __sinf(ang);
     float res;
@@ -35,12 +36,19 @@ template <int LDS_FLOATS> __global__ __launch_bounds__(256) void k_stream(float*
         "1:\n\t" FMA32 FMA32 FMA32 FMA32 FMA32 FMA32 FMA32 FMA32
         "s_sub_u32 s22, s22, 1\n\ts_cmp_lg_u32 s22, 0\n\ts_cbranch_scc1 1b\n\t"
         "v_add_f32 %0, v0, v4\n\tv_add_f32 %0, %0, v9\n\tv_add_f32 %0, %0, v29"
-        : "=v"(res)
+        : "=&v"(res)  // early clobber: never the register of an input
         : "v"(zx), "s"(iters), "v"(zy)
         : "v0", "v1", "v4", "v5", "v8", "v9", "v12", "v13", "v16", "v17", "v20", "v21", "v24", "v25", "v28", "v29", "v32", "v33", "s22", "scc");
     out[blockIdx.x * blockDim.x + threadIdx.x] = res + pad[threadIdx.x];
 }
 
+// workgroups of k_stream<LDS_FLOATS> one CU holds at once = waves per SIMD (256 threads = one wave on each of the 4 SIMDs): asked of
+// the runtime, so the figure printed is the occupancy found on this device, not the one the 160 KB LDS of gfx950 is assumed to give
+template <int LDS_FLOATS> static int resident_workgroups() {
+    int n = 0;
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, k_stream<LDS_FLOATS>, 256, 0) != hipSuccess) return -1;
+    return n;
+}
 template <int LDS_FLOATS> static double run(float* d, int cus, int wps, double seconds, double* ns_per_instr) {
     const int iters = 2500, grid = cus * wps;  // ~10 ms per launch
     hipLaunchKernelGGL(k_stream<LDS_FLOATS>, dim3(grid), dim3(256), 0, 0, d, 100, 1e-6f);
@@ -78,12 +86,14 @@ int main(int argc, char** argv) {
     float* d = nullptr;
     if (hipMalloc((void**)&d, (size_t)cus * 4 * 256 * sizeof(float)) != hipSuccess) return 2;
     double ns3 = 0, ns4 = 0;
-    const double tf3 = run<11000>(d, cus, 3, seconds * 0.75, &ns3);
-    const double tf4 = run<9000>(d, cus, 4, seconds * 0.25, &ns4);
-    printf("{\"pk_fma_stream_TF\": %.3f, \"ns_per_wave_instr_per_simd\": %.4f, \"waves_per_simd\": 3, \"pk_fma_stream_TF_4_waves\": %.3f, "
+    const int occ3 = resident_workgroups<11000>(), occ4 = resident_workgroups<9000>();
+    if (occ3 != 3 || occ4 != 4) fprintf(stderr, "pk_fma_stream: occupancy %d / %d workgroups per CU where 3 / 4 were intended (LDS per CU: %zu bytes)\n", occ3, occ4, (size_t)prop.maxSharedMemoryPerMultiProcessor);
+    const double tf3 = run<11000>(d, cus, occ3 > 0 ? occ3 : 3, seconds * 0.75, &ns3);
+    const double tf4 = run<9000>(d, cus, occ4 > 0 ? occ4 : 4, seconds * 0.25, &ns4);
+    printf("{\"pk_fma_stream_TF\": %.3f, \"ns_per_wave_instr_per_simd\": %.4f, \"waves_per_simd\": %d, \"waves_per_simd_second_leg\": %d, \"pk_fma_stream_TF_4_waves\": %.3f, "
            "\"ns_per_wave_instr_per_simd_4_waves\": %.4f, \"compute_units\": %d, \"seconds\": %.2f, "
            "\"form\": \"256 x v_pk_fma_f32 z, z, s, z (z += s i z: 8 independent chains of rotating operands on hard-coded registers) + 3 scalar instructions per trip\"}\n",
-           tf3, ns3, tf4, ns4, cus, seconds);
+           tf3, ns3, occ3, occ4, tf4, ns4, cus, seconds);
     (void)hipFree(d);
     return 0;
 }
