@@ -327,7 +327,7 @@ def main():
         parallelism = f"Doppler slabs over {world} GPU(s), per-(position, PRN) peak all-reduce(MAX)"
         weak_blocks = 0
     else:
-        total_runs = os.path.getsize(args.capture) // (32 * 5120) if args.capture else max(world, args.blocks_total // 32)  # (SearchTask stops at the first short read, :241-244)
+        total_runs = os.path.getsize(args.capture) // (32 * 5120) if args.capture else max(1, args.blocks_total // 32)  # (SearchTask stops at the first short read, :241-244)
         first_run, n_runs = gdist.shard_runs(total_runs, rank, world)
         nblk = n_runs * 32
         data_seed = CAPTURE_SEED + rank if iq8 else CAPTURE_SEED  # (the IQ stand-in comes from a sequential torch generator: one stream per rank)

@@ -585,7 +585,7 @@ def gpu_library_baseline(torch, eng, dev, d_bits, stride, nblk, gpu_peaks=None, 
     D = torch.from_numpy(np.stack([eng.sample_spectrum(host[b * stride:b * stride + 5120]) for b in range(nb)])).to(dev)
     C = torch.from_numpy(np.stack([eng.code_spectrum(b % 32) for b in range(nb)])).to(dev)
     Dc = torch.conj(D).resolve_conj().contiguous()
-    C2 = torch.cat([C, C], dim=1)  # roll(C, d)[i] = C[(i - d) mod N] = C2[N - d + i]
+    C2 = torch.cat([C, C], dim=1)  # roll(C, d)[i] = C[(i - d) mod N] = C2[(N - d) mod N + i]
     ev = [torch.cuda.Event(enable_timing=True) for _ in range(4)]
     times = []
     res = None
@@ -593,7 +593,8 @@ def gpu_library_baseline(torch, eng, dev, d_bits, stride, nblk, gpu_peaks=None, 
         ev[0].record()
         prod = torch.empty((nb, ndop, N), dtype=torch.complex64, device=dev)
         for k, d in enumerate(range(-dmax, dmax + 1)):
-            torch.mul(Dc, C2[:, N - d:2 * N - d], out=prod[:, k, :])
+            o = (N - d) % N
+            torch.mul(Dc, C2[:, o:o + N], out=prod[:, k, :])
         ev[1].record()
         y = torch.fft.ifft(prod, dim=-1, norm="forward")  # backward transform without the 1/N
         ev[2].record()
