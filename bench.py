@@ -207,7 +207,14 @@ def init_dist(args, torch, backend, world, dev_index):
         import torch.distributed as dist
         if backend == "nccl":
             dist.init_process_group(backend="nccl", device_id=torch.device("cuda", dev_index))
-            return dist, None, dist.new_group(backend="gloo")
+            host_group = None
+            try:
+                host_group = dist.new_group(backend="gloo")
+            except Exception as ex:  # (no usable interface for gloo: the final wait then uses the RCCL barrier)
+                print(f"bench.py: no gloo group for the final wait ({str(ex)[:120]})", file=sys.stderr)
+            ok = torch.tensor([1 if host_group is not None else 0], dtype=torch.int32, device=torch.device("cuda", dev_index))
+            dist.all_reduce(ok, op=dist.ReduceOp.MIN)  # every rank takes the same branch
+            return dist, None, (host_group if int(ok.item()) == 1 else None)
         dist.init_process_group(backend=backend)
         return dist, None, None
     if args.no_dist or backend != "nccl":

@@ -658,7 +658,7 @@ def inproc_multi_child(argv):
                       "cells_per_s": a.runs * 32 * (2 * m.kmax + 1) / (ms * 1e-3)}))
 
 
-def inproc_multi(cfg, total_runs, seed, devices, want_digest, timeout_s=240):
+def inproc_multi(cfg, total_runs, seed, devices, want_digest, timeout_s=120):
     """After the timed region at N > 1, from rank 0: ONE process drives all N devices through gpsacq_multi_search_blocks -- the C
     ABI's own decomposition (one engine per device, ncclCommInitAll, ONE ncclAllReduce(MAX) of 32 keys) -- over the capture the ranks
     just searched.  Runs as a child process with a time limit (a hang there must not take the bench line with it); the other ranks'
