@@ -32,9 +32,10 @@ hipError_t upload_wq(const cf* host) { return hipMemcpyToSymbol(HIP_SYMBOL(c_wq)
 // ---------------------------------------------------------------------------------------
 // Forward transform (Sample() :141-161 / SearchInit() :101-106): grid (n_items), one workgroup per item computes the
 // eight rows of its polyphase spectrum one after the other and writes each once, coalesced.
-// SRC_REAL: float code replicas (SearchInit).  SRC_BITS: the 1-bit capture gps_test reads.  SRC_IQ8: an 8-bit IQ capture
-// (rtl-sdr / HackRF) -- mean removal, mixer, sign and the bit transpose happen while the block is staged, so the 1-bit
-// stream the reference's MATLAB scripts write to disk (proc_rtl_bin_for_gps.m:22-26,43-47) is never materialised.
+// k_fwd:  SRC_REAL: float code replicas (SearchInit); SRC_REALMIX: multi-bit samples.
+// k_fwd2: SRC_BITS: the 1-bit capture gps_test reads; SRC_IQ8: an 8-bit IQ capture (rtl-sdr / HackRF) -- mean removal, mixer, sign and
+// the bit transpose happen while the block is staged, so the 1-bit stream the reference's MATLAB scripts write to disk
+// (proc_rtl_bin_for_gps.m:22-26,43-47) is never materialised.
 enum { SRC_REAL = 0, SRC_BITS = 1, SRC_IQ8 = 2, SRC_REALMIX = 3 };  // SRC_REALMIX: multi-bit samples, complex floats with the LO applied
 
 // iq8 staging, step 1: the block's first 5000 bytes of the 1-bit stream, made from the IQ bytes (one aligned 16-byte group
@@ -84,8 +85,8 @@ __global__ __launch_bounds__(WG) void k_fwd(FwdArgs a) {
     }
 }
 
-// The 1-bit / 8-bit IQ capture, second form (acq_phases.hpp fwd2_*): same spectra (conjugated, polyphase rows) as k_fwd<SRC_BITS>
-// to float rounding; three workgroups per CU (46 KB of LDS, <= 168 VGPRs).
+// The 1-bit / 8-bit IQ capture (acq_phases.hpp fwd2_*): the block's eight polyphase rows, conjugated; three workgroups per CU
+// (46 KB of LDS, <= 168 VGPRs).
 template <int SRC>
 __global__ __launch_bounds__(WG, 3) void k_fwd2(FwdArgs a) {
     static_assert(SRC == SRC_BITS || SRC == SRC_IQ8, "k_fwd2 is the 1-bit path");
