@@ -166,3 +166,38 @@ def test_bench_gpus_n_without_the_devices_fails_loudly():
     r = _bench_cli("--gpus", "1", "--spawn-check", env={"WORLD_SIZE": "2", "RANK": "0"})
     assert r.returncode != 0 and "WORLD_SIZE=2" in r.stderr
 
+
+
+def test_merged_keys_do_not_depend_on_the_world_size():
+    """What bench.py's `keys_digest` rests on (north_star: "identical acquisition results ... at 1/2/4/8"): the per-PRN best keys of the
+    whole capture are the same 32 numbers however the 340 runs are dealt to 1, 2, 3, 4, 8 or 400 ranks (shard_runs: contiguous, balanced,
+    ranks without work contribute zeros) -- integer MAX is associative, and ties (equal SNR) go to the lower Doppler bin whatever the
+    order of the merges (c/search_offline.cpp:196-198)."""
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    sys.path.insert(0, os.path.join(root, "gnss-gps-sdr_amd", "python"))
+    sys.path.insert(0, root)
+    from gpsacq import dist as D
+    import bench_extras as X
+    n_runs = 340
+    allpk = _fake_peaks(n_runs * 32, 321)
+    digests = {}
+    for world in (1, 2, 3, 4, 8, 400):
+        merged = torch.zeros(32, dtype=torch.int64)
+        covered = 0
+        for rank in range(world):
+            first, n = D.shard_runs(n_runs, rank, world)
+            assert first == covered  # contiguous, in rank order
+            covered += n
+            mine = torch.from_numpy(allpk[first * 32:(first + n) * 32].copy().view(np.int32).reshape(-1, 4))
+            best = D.per_prn_best(D.pack_keys(mine, 36)) if n > 0 else torch.zeros(32, dtype=torch.int64)
+            merged = torch.maximum(merged, best)
+        assert covered == n_runs
+        digests[world] = X.keys_digest(merged.numpy())
+    assert len(set(digests.values())) == 1, digests
+    # the digest sees a single changed code phase
+    other = allpk.copy()
+    win = int(np.argmax(other["snr"]))
+    other["ca"][win] = (other["ca"][win] + 1) % 5456
+    k = D.per_prn_best(D.pack_keys(torch.from_numpy(other.view(np.int32).reshape(-1, 4)), 36))
+    assert X.keys_digest(k.numpy()) != digests[1]
