@@ -28,6 +28,8 @@
  *   gpsacq_iq8_to_bits       the MATLAB pre-processing that produces gps_test's input from an 8-bit IQ
  *                            capture: proc_rtl_bin_for_gps.m:12-26,31-47, proc_hackrf_bin_for_gps.m:7-19
  *   gpsacq_generate          the role of gps_sig_gen.m (synthetic 1-bit capture; here noise + any PRN set with Doppler)
+ *   gpsacq_generate_range    any byte window of that stream (a function of the absolute sample index): what lets every rank of a
+ *                            multi-GPU job make its own blocks of the ONE capture all world sizes search
  *   gpsacq_generate_sig      gps_sig_gen.m:8-41 itself (one PRN, navigation bits, raised-cosine BPSK at fs/4), bit-exact
  *   gpsacq_generate_sig_tx   gps_sig_gen.m:21-30, the script's int8 complex-baseband file for HackRF replay
  *   gpsacq_handoff           CHANNEL::Start()'s NCO set-up from a search hit, c/channel.cpp:134-163
