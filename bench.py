@@ -45,7 +45,7 @@ from bench_extras import (ALG_BYTES_PER_CELL, CAPTURE_SEED, CONFIGS, FP32_PEAK_C
 class Leg:
     """One timed workload: `n_tasks` tasks over `nblk` resident blocks on this rank."""
 
-    def __init__(self, torch, eng, dev, dist, backend, nblk, n_tasks, d_bits, d_tasks, stride, grid, n_keys=32, iq=None):
+    def __init__(self, torch, eng, dev, dist, backend, nblk, n_tasks, d_bits, d_tasks, stride, grid, n_keys=32, iq=None, keep_cells=False):
         self.torch, self.eng, self.dev, self.dist, self.backend = torch, eng, dev, dist, backend
         self.iq = iq  # gpsacq.Iq8Input: d_bits then holds interleaved 8-bit I,Q bytes, `stride` bytes per block
         self.nblk, self.n_tasks, self.d_bits, self.d_tasks, self.stride, self.grid, self.n_keys = nblk, n_tasks, d_bits, d_tasks, stride, grid, n_keys
@@ -53,6 +53,9 @@ class Leg:
         # i's all-reduce overlaps step i+1's search (two peak / key buffers; the engine stream waits for a buffer's previous reader).
         self.d_peaks = [torch.zeros((max(n_tasks, 1), 4), dtype=torch.int32, device=dev) for _ in range(2)]
         self.d_keys = [torch.zeros(n_keys, dtype=torch.int64, device=dev) for _ in range(2)]
+        # keep_cells: every step writes its cells (16 bytes per cell, the kernel's only per-cell output) into this buffer instead of the
+        # engine's own scratch -- the same kernels, the same launches -- so that the LAST TIMED STEP's cells can be checked afterwards
+        self.d_cells = torch.empty((n_tasks, eng.num_doppler, 4), dtype=torch.int32, device=dev) if (keep_cells and n_tasks > 0 and iq is None) else None
         self.sampler = None  # bench_extras.ClockSampler: sclk / power readings + cycle stamps during the timed steps of run()
         self.eng_stream = torch.cuda.ExternalStream(eng.stream_ptr, device=dev)
         self.reader_done = [None, None]
@@ -70,7 +73,8 @@ class Leg:
                 eng.search_iq8_device(self.d_bits.data_ptr(), self.iq, self.nblk, buf.data_ptr(), stride=self.stride, sync=False)
             else:
                 eng.search_device(self.d_bits.data_ptr(), self.nblk, buf.data_ptr(), stride=self.stride,
-                                  d_tasks_ptr=self.d_tasks.data_ptr() if self.d_tasks is not None else None, n_tasks=self.n_tasks, sync=False)
+                                  d_tasks_ptr=self.d_tasks.data_ptr() if self.d_tasks is not None else None, n_tasks=self.n_tasks,
+                                  d_cells_ptr=self.d_cells.data_ptr() if self.d_cells is not None else None, sync=False)
             # best peak per PRN (block schedule) / per (block, PRN) (grid) as keys whose integer MAX is the reference's ordering (higher SNR;
             # ties -> lower Doppler bin, :198): made by the library, one launch on the engine's stream.  Every key of the buffer is rewritten
             eng.peak_keys_device(buf.data_ptr(), self.n_tasks, best.data_ptr(), per_prn=not self.grid, sync=False)
@@ -188,7 +192,8 @@ def parse_args():
     ap.add_argument("--no-library-baseline", action="store_true", help="skip extras.gpu_library_baseline (the same cells through rocFFT)")
     ap.add_argument("--no-inproc-multi", action="store_true", help="N > 1: skip the in-process gpsacq_multi_search_blocks leg")
     ap.add_argument("--parity-selftest", action="store_true", help="corrupt one GPU peak (ca_shift + 1) before the parity verdict: the run must then exit 3 (tests)")
-    ap.add_argument("--parity-blocks", type=int, default=96, help="N > 1: blocks of rank 0's share pushed through the oracle for the parity verdict")
+    ap.add_argument("--parity-blocks", type=int, default=0, help="N > 1: blocks of rank 0's share pushed through the oracle for the parity verdict (0: the whole share)")
+    ap.add_argument("--parity-seconds", type=float, default=60.0, help="time limit of the oracle's all-cores pass over rank 0's share (blocks it does not reach are not part of the verdict)")
     ap.add_argument("--pk-fma-seconds", type=float, default=3.0, help="N = 1: seconds of the pure v_pk_fma_f32 stream behind roofline.pk_fma_stream_TF (0: skip)")
     ap.add_argument("--no-e2e", action="store_true", help="skip the gps_test end-to-end leg")
     ap.add_argument("--spawn-check", action="store_true", help="launcher check without a GPU: every rank joins a gloo group, rank 0 prints the ranks it saw")
@@ -384,7 +389,9 @@ def main():
         blocks_per_rank, devices = [int(v) for v in t[:, 0].tolist()], [int(v) for v in t[:, 1].tolist()]
 
     n_keys = tasks.shape[0] if grid else 32
-    leg = Leg(torch, eng, dev, dist, backend, nblk, n_tasks, d_bits, d_tasks, stride, grid, n_keys=n_keys, iq=iq_in)
+    # rank 0's share of the LAST TIMED STEP is checked against the oracle afterwards (peaks and cells): its cells are kept
+    check_parity = rank == 0 and not grid and not iq8 and n_tasks > 0 and not args.no_cpu_baseline and args.config in (1, 2)
+    leg = Leg(torch, eng, dev, dist, backend, nblk, n_tasks, d_bits, d_tasks, stride, grid, n_keys=n_keys, iq=iq_in, keep_cells=check_parity)
     if rank == 0:
         leg.sampler = ClockSampler(torch, dev_index)  # sclk / power during the K timed steps (roofline.sclk_mhz, .power_w)
     elapsed, kern_ms, best = leg.run(args.steps, args.warmup)
@@ -392,12 +399,12 @@ def main():
     clock = X.clock_of_leg(leg) if leg.sampler is not None else None
     leg.sampler = None
     ms_step = 1e3 * elapsed / args.steps
-    # the peaks of the LAST TIMED STEP (this rank's share), kept for the parity verdict before any other leg runs
-    check_parity = rank == 0 and not grid and not iq8 and n_tasks > 0 and not args.no_cpu_baseline and args.config in (1, 2)
-    gpu_peaks = None
+    # the peaks and cells of the LAST TIMED STEP (this rank's whole share), copied out for the parity verdict before any other leg runs
+    gpu_peaks = gpu_cells = None
     if check_parity:
-        from oracle_lib import PEAK_DTYPE as _PK
-        gpu_peaks = leg.d_peaks[(leg.step_no - 1) & 1][:min(n_tasks, 1024)].cpu().numpy().view(_PK).reshape(-1)
+        from oracle_lib import CELL_DTYPE as _CL, PEAK_DTYPE as _PK
+        gpu_peaks = leg.d_peaks[(leg.step_no - 1) & 1][:n_tasks].cpu().numpy().view(_PK).reshape(-1)
+        gpu_cells = leg.d_cells.cpu().numpy().view(_CL).reshape(n_tasks, eng.num_doppler)
 
     side = world == 1 and n_tasks > 0 and args.soak_seconds > 0  # the N = 1 side legs
     soak_leg = X.soak(leg, cells_job, args.soak_seconds) if side else None

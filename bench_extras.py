@@ -99,6 +99,7 @@ def make_iq_capture(torch, dev, fs, n_blocks, seed):
 
 PARITY_SNR_REL = 1e-4   # BASELINE.json north_star: correlator magnitudes within 1e-4 relative
 PARITY_PWR_REL = 2e-5   # what the GPU suite asserts per cell (tests/test_gpu_parity.py REL)
+PARITY_SCREEN_REL = 1e-5  # cells: within this of the oracle's FLOAT build passes; further off, the double build judges at PARITY_PWR_REL
 PARITY_TIE_REL = 1e-5   # two candidates closer than this in the double-precision oracle are a float-rounding tie
 
 
@@ -442,14 +443,17 @@ def cpu_baseline_reference(cfg, bits, ndop, target_s=15.0):
                       f"same capture, {dt:.1f} s incl. process start, on {os.cpu_count()} core host ({cpu_model()}), 1 thread"}
 
 
-def cpu_baseline_all_cores(cfg, bits, ndop, one_thread_rate, target_s=8.0):
-    """The same port on every core the process may use: an OpenMP loop inside liboracle_f32.so (oracle_bench_omp)."""
+def cpu_baseline_all_cores(cfg, bits, ndop, one_thread_rate, cap_s=60.0, first_block=0):
+    """The same port on every core the process may use -- ONE pass over the whole share of the capture this rank searched, inside
+    liboracle_f32.so (oracle_search_omp: blocks handed out in ascending order, reference schedule block -> PRN) -- which KEEPS what it
+    computes: the all-cores figure and the checker's side of parity_vs_gpu are the same work.  cap_s bounds the leg on a slow host
+    (blocks not reached by then are simply not part of the verdict).  Returns (dict, peaks, cells[block][bin], blocks done)."""
     import ctypes
-    from oracle_lib import lib
+    from oracle_lib import CELL_DTYPE, PEAK_DTYPE, lib
     L = lib("f32")
-    L.oracle_bench_omp.restype = ctypes.c_long
-    L.oracle_bench_omp.argtypes = [ctypes.c_double] * 3 + [ctypes.c_void_p, ctypes.c_long, ctypes.c_long, ctypes.c_int, ctypes.c_double,
-                                                            ctypes.POINTER(ctypes.c_double), ctypes.POINTER(ctypes.c_int)]
+    L.oracle_search_omp.restype = ctypes.c_long
+    L.oracle_search_omp.argtypes = [ctypes.c_double] * 3 + [ctypes.c_void_p, ctypes.c_long, ctypes.c_long, ctypes.c_long, ctypes.c_int, ctypes.c_double,
+                                                             ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.POINTER(ctypes.c_double), ctypes.POINTER(ctypes.c_int)]
     try:
         ncpu = len(os.sched_getaffinity(0))
     except (AttributeError, OSError):
@@ -462,15 +466,21 @@ def cpu_baseline_all_cores(cfg, bits, ndop, one_thread_rate, target_s=8.0):
         pass
     buf = np.ascontiguousarray(bits)
     nblk = buf.size // 5120
+    peaks, cells, done = np.zeros(nblk, PEAK_DTYPE), np.zeros((nblk, ndop), CELL_DTYPE), np.zeros(nblk, np.uint8)
     el, used = ctypes.c_double(), ctypes.c_int()
     nthreads = ncpu if quota is None else max(1, min(ncpu, int(math.ceil(quota))))
-    cells = L.oracle_bench_omp(cfg["fc"], cfg["fs"], cfg["max_fo"], buf.ctypes.data, nblk, 5120, nthreads, target_s, ctypes.byref(el), ctypes.byref(used))
-    rate = cells / el.value
-    return {"value": rate, "unit": "cells/s", "cores": used.value, "kind": "port",
-            "sched_getaffinity_cores": ncpu, "os_cpu_count": os.cpu_count(), "cgroup_cpu_quota_cores": quota,
-            "speedup_over_1_thread": rate / one_thread_rate if one_thread_rate else None,
-            "sample": f"OpenMP, {used.value} threads (sched_getaffinity: {ncpu} cores, cgroup cpu.max quota: {quota} cores), blocks of the same {nblk}-block sample dealt "
-                      f"round-robin x {ndop} bins for {el.value:.1f} s = {cells} cells"}
+    n_cells = L.oracle_search_omp(cfg["fc"], cfg["fs"], cfg["max_fo"], buf.ctypes.data, nblk, 5120, int(first_block), nthreads, float(cap_s),
+                                  peaks.ctypes.data, cells.ctypes.data, done.ctypes.data, ctypes.byref(el), ctypes.byref(used))
+    n_done = int(done.sum())
+    if not done[:n_done].all():  # (ascending hand-out and every block taken is finished: the blocks done are a prefix)
+        raise RuntimeError("oracle_search_omp: the blocks done are not a prefix of the share")
+    rate = n_cells / el.value if el.value > 0 else 0.0
+    return ({"value": rate, "unit": "cells/s", "cores": used.value, "kind": "port",
+             "sched_getaffinity_cores": ncpu, "os_cpu_count": os.cpu_count(), "cgroup_cpu_quota_cores": quota,
+             "speedup_over_1_thread": rate / one_thread_rate if one_thread_rate else None, "blocks": n_done, "blocks_of_the_share": nblk, "seconds": el.value,
+             "sample": f"OpenMP, {used.value} threads (sched_getaffinity: {ncpu} cores, cgroup cpu.max quota: {quota} cores), one pass over {n_done} of the {nblk} blocks "
+                       f"this rank searched x {ndop} bins = {n_cells} cells in {el.value:.1f} s; its peaks and cells are what parity_vs_gpu compares the timed step's with"},
+            peaks[:n_done], cells[:n_done], n_done)
 
 
 def compare_peaks(cfg, gpu_peaks, cpu_peaks, host_bits, first_block=0):
@@ -516,60 +526,79 @@ def compare_peaks(cfg, gpu_peaks, cpu_peaks, host_bits, first_block=0):
              "n_unproven": len(unproven), "snr_max_rel": snr_max_rel, "non_finite_gpu_peaks": int((~finite).sum())}, orc, lag_powers)
 
 
-def parity_vs_gpu(cfg, leg, nblk, gpu_peaks, cpu_peaks, host_bits, first_block=0, seed=5):
+def compare_cells(gpu_cells, cpu_cells, host_bits, first_block, orc, lag_powers, max_recheck=20000):
+    """Part (2) of parity_vs_gpu, host only: EVERY cell of the blocks the oracle searched (c/search_offline.cpp:190-196: max_pwr, its lag,
+    tot_pwr).  Two tiers: the oracle's float build is the screen -- a power within PARITY_SCREEN_REL of it passes --, its double build
+    the judge: a power further off, and every cell whose lag differs, is recomputed in double; the power must then be within
+    PARITY_PWR_REL, the lag's power within PARITY_TIE_REL of the largest (a float-rounding tie).  Non-finite or non-positive GPU powers
+    and lags outside the scan fail outright."""
+    n = min(len(gpu_cells), len(cpu_cells))
+    g, o = gpu_cells[:n], cpu_cells[:n]
+    dmax, S = orc.dmax, orc.num_lags
+    bad_values, worst_screen, judge = 0, 0.0, {}
+    for f in ("max_pwr", "tot_pwr"):
+        gv, ov = g[f].astype(np.float64), o[f].astype(np.float64)
+        ok = np.isfinite(gv) & (gv > 0)
+        bad_values += int((~ok).sum())
+        with np.errstate(divide="ignore", invalid="ignore"):
+            rel = np.where(ok & (ov > 0), np.abs(gv / ov - 1.0), np.inf)
+        over = rel > PARITY_SCREEN_REL
+        if (~over).any():
+            worst_screen = max(worst_screen, float(rel[~over].max()))
+        for b, d in zip(*np.nonzero(over & ok)):
+            judge.setdefault((int(b), int(d)), set()).add(f)
+    lag_in = (g["max_i"] >= 0) & (g["max_i"] < S)
+    lag_bad = [[first_block + int(b), int(d) - dmax] for b, d in zip(*np.nonzero(~lag_in))]
+    for b, d in zip(*np.nonzero((g["max_i"] != o["max_i"]) & lag_in)):
+        judge.setdefault((int(b), int(d)), set()).add("lag")
+    worst_judged, lag_ties, too_many = 0.0, 0, len(judge) > max_recheck
+    pwr_bad = []
+    if not too_many:
+        bits = np.frombuffer(host_bits, dtype=np.uint8)
+        for (b, d), what in sorted(judge.items()):
+            pw = lag_powers(bits[b * 5120:(b + 1) * 5120], (first_block + b) % 32, d - dmax).astype(np.float64)
+            truth = {"max_pwr": float(pw.max()), "tot_pwr": float(pw.sum())}
+            for f in what - {"lag"}:
+                rel = abs(float(g[f][b, d]) / truth[f] - 1.0) if truth[f] > 0 else float("inf")
+                worst_judged = max(worst_judged, rel)
+                if not rel <= PARITY_PWR_REL:
+                    pwr_bad.append([first_block + b, d - dmax, f, rel])
+            if "lag" in what:
+                if truth["max_pwr"] - float(pw[int(g["max_i"][b, d])]) <= PARITY_TIE_REL * truth["max_pwr"]:
+                    lag_ties += 1
+                else:
+                    lag_bad.append([first_block + b, d - dmax])
+    ok = bad_values == 0 and not lag_bad and not pwr_bad and not too_many
+    return {"ok": bool(ok), "cells": int(g.size), "pwr_max_rel": max(worst_screen, worst_judged), "pwr_max_rel_vs_float_oracle_where_screened": worst_screen,
+            "cells_judged_in_double": len(judge), "pwr_max_rel_judged_in_double": worst_judged, "too_many_cells_off_the_screen": bool(too_many),
+            "non_finite_or_non_positive_cell_powers": bad_values, "cell_lag_ties": lag_ties, "cell_lag_mismatches": lag_bad[:8], "n_cell_lag_mismatches": len(lag_bad),
+            "cell_power_mismatches": pwr_bad[:8], "n_cell_power_mismatches": len(pwr_bad)}
+
+
+def parity_vs_gpu(cfg, gpu_peaks, gpu_cells, cpu_peaks, cpu_cells, host_bits, first_block=0, share_blocks=None):
     """The timed step's own results against the oracle (test infrastructure; c/search_offline.cpp:190-198,248), AFTER the timed
-    region: (1) the GPU's peak of every block the oracle's float build searched -- same capture, same blocks, reference schedule block
-    -> PRN block % 32 -- must carry the same ca_shift and lo_shift and an SNR within 1e-4; a different (lo, ca) is accepted only as a
-    PROVEN tie: in the double-precision oracle the two candidates' SNRs agree to 1e-5.  (2) three seeded random (block, PRN) rows of
-    this rank's WHOLE share, all Doppler bins, cell by cell against liboracle_f64: max_pwr / tot_pwr to 2e-5 (finite, positive), the
-    lag identical or a proven tie."""
-    from oracle_lib import CELL_DTYPE
-    torch, eng, d_bits, stride = leg.torch, leg.eng, leg.d_bits, leg.stride
+    region, host only -- the GPU's peaks and cells are the copies taken right behind the last timed step: (1) the peak of every block
+    the oracle searched -- same capture, same blocks, reference schedule block -> PRN block % 32 -- must carry the same ca_shift and
+    lo_shift and an SNR within 1e-4; a different (lo, ca) is accepted only as a PROVEN tie: in the double-precision oracle the two
+    candidates' SNRs agree to 1e-5.  (2) every cell of those blocks, all Doppler bins (compare_cells): powers within 1e-5 of the oracle's
+    float build or within 2e-5 of its double build (finite, positive), the lag identical or a tie proven in double."""
     part1, orc, lag_powers = compare_peaks(cfg, gpu_peaks, cpu_peaks, host_bits, first_block)
-    dmax = orc.dmax
-    rng = np.random.default_rng(seed)
-    rows = sorted(int(b) for b in rng.choice(nblk, size=min(3, nblk), replace=False))
-    dev = d_bits.device
-    with torch.cuda.stream(leg.eng_stream):  # allocations, fills and the H2D copy on the engine's own stream: ordered before the search
-        tasks = torch.tensor([[b, (first_block + b) % 32] for b in rows], dtype=torch.int32).to(dev)
-        d_cells = torch.zeros((len(rows), eng.num_doppler, 4), dtype=torch.int32, device=dev)
-        d_pk = torch.zeros((len(rows), 4), dtype=torch.int32, device=dev)
-    eng.search_device(d_bits.data_ptr(), nblk, d_pk.data_ptr(), stride=stride, d_tasks_ptr=tasks.data_ptr(), n_tasks=len(rows),
-                      d_cells_ptr=d_cells.data_ptr(), sync=True)
-    gc = d_cells.cpu().numpy().view(CELL_DTYPE).reshape(len(rows), eng.num_doppler)
-    pwr_max_rel, lag_ties, lag_bad, cells, bad_values = 0.0, 0, [], 0, 0
-    for r, b in enumerate(rows):
-        blk = d_bits[b * stride:b * stride + 5120].cpu().numpy()
-        sv = (first_block + b) % 32
-        oc, _ = orc.search_block(blk, sv)
-        cells += oc.size
-        for f in ("max_pwr", "tot_pwr"):
-            gv = gc[r][f].astype(np.float64)
-            ok = np.isfinite(gv) & (gv > 0)
-            bad_values += int((~ok).sum())
-            with np.errstate(divide="ignore", invalid="ignore"):
-                rel = np.where(ok, np.abs(gv / oc[f].astype(np.float64) - 1.0), np.inf)
-            pwr_max_rel = max(pwr_max_rel, float(np.max(rel)))
-        for d in np.nonzero(gc[r]["max_i"] != oc["max_i"])[0]:
-            gi = int(gc[r]["max_i"][d])
-            if not 0 <= gi < orc.num_lags:
-                lag_bad.append([int(b), int(d) - dmax])
-                continue
-            pw = lag_powers(blk, sv, int(d) - dmax)
-            a, c = float(pw[gi]), float(pw[oc["max_i"][d]])
-            if abs(a - c) <= PARITY_TIE_REL * c:
-                lag_ties += 1
-            else:
-                lag_bad.append([int(b), int(d) - dmax])
-    ok = (part1["n_unproven"] == 0 and part1["snr_max_rel"] <= PARITY_SNR_REL and pwr_max_rel <= PARITY_PWR_REL and not lag_bad and bad_values == 0)
-    return {"ok": bool(ok), "blocks": part1["blocks"], "ca_equal": part1["ca_equal"], "lo_equal": part1["lo_equal"], "proven_ties": part1["proven_ties"],
-            "unproven_mismatches": part1["unproven_mismatches"], "snr_max_rel": part1["snr_max_rel"], "non_finite_gpu_peaks": part1["non_finite_gpu_peaks"],
-            "cells": int(cells), "cell_rows_block_prn": [[first_block + b, (first_block + b) % 32] for b in rows],
-            "pwr_max_rel": pwr_max_rel, "non_finite_or_non_positive_cell_powers": bad_values, "cell_lag_ties": lag_ties, "cell_lag_mismatches": lag_bad[:8],
-            "first_block_of_this_rank": first_block,
-            "tolerances": {"snr_rel": PARITY_SNR_REL, "pwr_rel": PARITY_PWR_REL, "tie_rel": PARITY_TIE_REL},
-            "what": "GPU peaks of the LAST TIMED STEP (rank 0's share) vs the oracle's float build on the same blocks (ca_shift / lo_shift equal "
-                    "or a tie proven in the double-precision oracle, SNR to 1e-4) + 3 random full rows of cells vs liboracle_f64 (2e-5)"}
+    n = part1["blocks"]
+    if gpu_cells is not None and cpu_cells is not None:
+        part2 = compare_cells(gpu_cells[:n], cpu_cells[:n], host_bits, first_block, orc, lag_powers)
+    else:
+        part2 = {"ok": True, "cells": 0, "pwr_max_rel": 0.0, "note": "no cells compared"}
+    ok = part1["n_unproven"] == 0 and part1["snr_max_rel"] <= PARITY_SNR_REL and part2["ok"] and part2["pwr_max_rel"] <= PARITY_PWR_REL
+    out = {"ok": bool(ok), "blocks": n, "ca_equal": part1["ca_equal"], "lo_equal": part1["lo_equal"], "proven_ties": part1["proven_ties"],
+           "unproven_mismatches": part1["unproven_mismatches"], "snr_max_rel": part1["snr_max_rel"], "non_finite_gpu_peaks": part1["non_finite_gpu_peaks"]}
+    out.update({k: v for k, v in part2.items() if k != "ok"})
+    out.update({"first_block_of_this_rank": first_block, "blocks_of_this_ranks_share": share_blocks,
+                "whole_share": (share_blocks is not None and n == share_blocks),
+                "tolerances": {"snr_rel": PARITY_SNR_REL, "pwr_rel": PARITY_PWR_REL, "pwr_screen_rel": PARITY_SCREEN_REL, "tie_rel": PARITY_TIE_REL},
+                "what": "peaks AND cells of the LAST TIMED STEP (rank 0's share) vs the oracle on the same blocks: ca_shift / lo_shift equal or a tie "
+                        "proven in the double-precision oracle, SNR to 1e-4; every cell's max_pwr / tot_pwr within 1e-5 of the oracle's float build or "
+                        "2e-5 of its double build, its lag identical or a tie proven in double"})
+    return out
 
 
 # ---- the same cells through the vendor FFT on the same GPU --------------------------------------------------------------------
@@ -875,37 +904,52 @@ def build_line(c):
                          "note": "8-bit IQ read (80 000 B per block) + polyphase spectrum written (320 KB per block) over the stage's HIP-event time"}
     # ---- the oracle: baseline (N = 1) and checker (any N) -- test infrastructure, outside the timed region ----
     if c.check_parity:
-        host_bits = c.d_bits[:min(c.nblk, 1024) * 5120].cpu().numpy()
+        n_share = c.nblk if (c.world == 1 or c.args.parity_blocks <= 0) else min(c.nblk, c.args.parity_blocks)
+        host_bits = c.d_bits[:n_share * 5120].cpu().numpy()  # (the bits path: blocks 5120 bytes apart)
+        ndop, first_block = c.eng.num_doppler, c.first_run * 32
+        port = port_peaks = None
         if c.world == 1:
             out["roofline"]["hbm_secondary"]["hbm_copy_measured_GBs"] = hbm_copy_gbs(c.torch, c.dev)
-            port, cpu_peaks = cpu_baseline(c.cfg, host_bits, c.eng.num_doppler)
-            ref = cpu_baseline_reference(c.cfg, host_bits, c.eng.num_doppler)
+            port, port_peaks = cpu_baseline(c.cfg, host_bits[:min(n_share, 1024) * 5120], ndop)
+            ref = cpu_baseline_reference(c.cfg, host_bits[:min(n_share, 1024) * 5120], ndop)
             out["cpu_baseline"] = ref or port
             if ref:
                 out["cpu_baseline_port"] = port
             verdict_home = out["cpu_baseline"]
         else:  # the CPU baseline is an N = 1 figure; the verdict on rank 0's share is not
-            _, cpu_peaks = cpu_baseline(c.cfg, host_bits, c.eng.num_doppler, target_s=4.0, max_blocks=c.args.parity_blocks)
             verdict_home = out
+        # the checker's side: the oracle's float build over rank 0's WHOLE share on every core the process may use (= the all-cores figure)
+        cpu_cells = None
+        try:
+            allc, cpu_peaks, cpu_cells, _ = cpu_baseline_all_cores(c.cfg, host_bits, ndop, port["value"] if port else None,
+                                                                    cap_s=c.args.parity_seconds, first_block=first_block)
+            if port_peaks is not None:  # the same code on one thread and on many: the same peaks, bit for bit
+                m = min(len(port_peaks), len(cpu_peaks))
+                allc["equals_the_one_thread_run"] = bool(all(np.array_equal(port_peaks[f][:m], cpu_peaks[f][:m]) for f in ("snr", "lo_shift", "ca_shift")))
+        except Exception as ex:  # (no OpenMP build, ...): the verdict falls back to the blocks one thread searched, peaks only
+            allc = {"error": str(ex)[:300]}
+            if port_peaks is None:
+                _, port_peaks = cpu_baseline(c.cfg, host_bits, ndop, target_s=4.0, max_blocks=96)
+            cpu_peaks = port_peaks
+        if c.world == 1:
+            out["cpu_baseline_all_cores"] = allc
+        else:
+            out["parity_oracle_run"] = allc
         if c.args.parity_selftest:
             c.gpu_peaks = c.gpu_peaks.copy()
             i_bad = min(7, len(c.gpu_peaks) - 1)
             c.gpu_peaks["ca_shift"][i_bad] = (c.gpu_peaks["ca_shift"][i_bad] + 1) % c.eng.num_lags
         try:
-            par = parity_vs_gpu(c.cfg, c.leg, c.nblk, c.gpu_peaks, cpu_peaks, host_bits, first_block=c.first_run * 32)
+            par = parity_vs_gpu(c.cfg, c.gpu_peaks, c.gpu_cells, cpu_peaks, cpu_cells, host_bits, first_block=first_block, share_blocks=c.nblk)
         except Exception as ex:
             par = {"ok": False, "error": str(ex)[:300]}
         verdict_home["parity_vs_gpu"] = par
         # (flat copies: a consumer that keeps scalars only still sees the verdict)
         verdict_home.update({"parity_ok": par.get("ok"), "parity_blocks": par.get("blocks"), "parity_cells": par.get("cells"),
+                             "parity_whole_share": par.get("whole_share"),
                              "parity_ca_equal": par.get("ca_equal"), "parity_lo_equal": par.get("lo_equal"), "parity_proven_ties": par.get("proven_ties"),
                              "parity_snr_max_rel": par.get("snr_max_rel"), "parity_pwr_max_rel": par.get("pwr_max_rel")})
         parity_failed = not par.get("ok")
-        if c.world == 1:
-            try:
-                out["cpu_baseline_all_cores"] = cpu_baseline_all_cores(c.cfg, host_bits, c.eng.num_doppler, port["value"])
-            except Exception as ex:  # the 1-thread figure is the contract; this one is informative
-                out["cpu_baseline_all_cores"] = {"error": str(ex)}
     if c.world == 1 and not c.args.no_library_baseline and not c.grid and not c.iq8 and c.n_tasks >= 32:
         try:  # the same cells through the vendor FFT on this GPU
             from gpsacq import PEAK_DTYPE as _PK2

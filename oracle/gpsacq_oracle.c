@@ -523,5 +523,53 @@ long oracle_bench_omp(double fc, double fs, double max_fo, const unsigned char *
     if (threads_used) *threads_used = used;
     return cells;
 }
+
+/* ONE pass over a capture on several cores that KEEPS what it computed (bench.py: the all-cores figure and, with the same work, the
+ * checker of every block of the timed step): block b (capture index first_block + b) against PRN (first_block + b) % 32, the
+ * reference schedule (SearchTask :239-246); blocks are handed out in ascending order, a thread takes no new block after `seconds`.
+ * peaks[b] / cells[b * ndop ..] (cells may be NULL) / done[b] = 1 are written for every block searched; blocks never reached keep
+ * done[b] = 0.  Returns the cells searched; *elapsed the timed span (SearchInit of every instance untimed, like oracle_bench_omp). */
+long oracle_search_omp(double fc, double fs, double max_fo, const unsigned char *bits, long n_blocks, long stride, long first_block,
+                       int nthreads, double seconds, oracle_peak *peaks, oracle_cell *cells, unsigned char *done, double *elapsed,
+                       int *threads_used) {
+    long total = 0, next = 0;
+    double t_begin = 0, t_end = 0;
+    int used = 0;
+    if (nthreads < 1) nthreads = 1;
+    if (done) memset(done, 0, (size_t)n_blocks);
+#pragma omp parallel num_threads(nthreads) reduction(+ : total)
+    {
+        oracle_t *o = oracle_create(fc, fs, max_fo, 0);
+#pragma omp barrier
+#pragma omp master
+        {
+            t_begin = omp_get_wtime();
+            used = omp_get_num_threads();
+        }
+#pragma omp barrier
+        const double deadline = omp_get_wtime() + seconds;
+        const int ndop = o ? 2 * o->dmax + 1 : 0;
+        while (o && omp_get_wtime() < deadline) {
+            long b;
+#pragma omp atomic capture
+            b = next++;
+            if (b >= n_blocks) break;
+            oracle_peak pk;
+            oracle_cell *row = cells ? cells + (size_t)b * ndop : NULL;
+            oracle_search_block(o, bits + b * stride, (int)((first_block + b) % NUM_SATS), row, &pk);
+            if (!row) pk.max_pwr = 0;
+            if (peaks) peaks[b] = pk;
+            if (done) done[b] = 1;
+            total += ndop;
+        }
+#pragma omp barrier
+#pragma omp master
+        t_end = omp_get_wtime();
+        if (o) oracle_destroy(o);
+    }
+    if (elapsed) *elapsed = t_end - t_begin;
+    if (threads_used) *threads_used = used;
+    return total;
+}
 #endif
 

@@ -107,6 +107,92 @@ def test_non_finite_gpu_values_are_never_within_tolerance():
     assert r["n_unproven"] == 1 and not (r["snr_max_rel"] <= b.PARITY_SNR_REL)
 
 
+def test_all_cores_oracle_pass_keeps_the_results_of_the_one_thread_port():
+    """cpu_baseline_all_cores (oracle_search_omp): one OpenMP pass over a share of the capture -- block b of the share against PRN
+    (first_block + b) % 32, the reference schedule -- returns the SAME peaks and cells as the oracle's plain per-block search (bit for
+    bit: the same code, only dealt to threads), the blocks done are a prefix, and a pass whose time is up does nothing."""
+    import numpy as np
+    from oracle_lib import Oracle
+    b = _bench()
+    cfg = b.CONFIGS[1]
+    bits = np.frombuffer(open(os.path.join(ROOT, "tests", "golden", "synth_nott_fs5456.bin"), "rb").read()[:10 * 5120], dtype=np.uint8)
+    d, pk, cl, n = b.cpu_baseline_all_cores(cfg, bits, 73, 1000.0, cap_s=120.0, first_block=32 * 3)
+    assert n == 10 and d["blocks"] == 10 and d["blocks_of_the_share"] == 10 and d["value"] > 0 and d["cores"] >= 1 and d["speedup_over_1_thread"] > 0
+    oc, op = Oracle(cfg["fc"], cfg["fs"], cfg["max_fo"], kind="f32").search(bits.tobytes(), [(i, (96 + i) % 32) for i in range(10)])
+    for f in ("snr", "lo_shift", "ca_shift", "max_pwr"):
+        assert np.array_equal(pk[f], op[f]), f
+    for f in ("max_pwr", "max_i", "tot_pwr", "snr"):
+        assert np.array_equal(cl[f], oc[f]), f
+    d0, pk0, cl0, n0 = b.cpu_baseline_all_cores(cfg, bits, 73, None, cap_s=0.0)
+    assert n0 == 0 and len(pk0) == 0 and cl0.shape == (0, 73) and d0["blocks"] == 0 and d0["speedup_over_1_thread"] is None
+
+
+def test_compare_cells_verdict_logic():
+    """Part (2) of parity_vs_gpu on the oracle alone (no GPU): the double-precision oracle's cells stand in for the GPU's, the float
+    build's (the all-cores pass) are the checker's.  Equal results pass; a power 1.5e-5 off the float build goes to the double build
+    and passes there; 6e-5 off fails; a lag moved to a weaker sample fails, moved to an exact tie passes as a proven tie; NaN, a
+    non-positive power and a lag outside the scan fail outright; too many cells off the screen fail without being judged."""
+    import numpy as np
+    from oracle_lib import Oracle
+    b = _bench()
+    cfg = b.CONFIGS[1]
+    nb = 3
+    bits = np.frombuffer(open(os.path.join(ROOT, "tests", "golden", "synth_nott_fs5456.bin"), "rb").read()[:nb * 5120], dtype=np.uint8)
+    _, cpu_pk, cpu_cl, _ = b.cpu_baseline_all_cores(cfg, bits, 73, None, cap_s=120.0)
+    gcl, gpk = Oracle(cfg["fc"], cfg["fs"], cfg["max_fo"], kind="f64").search(bits.tobytes())
+    r = b.parity_vs_gpu(cfg, gpk, gcl, cpu_pk, cpu_cl, bits, first_block=0, share_blocks=nb)
+    assert r["ok"] and r["whole_share"] and r["blocks"] == nb and r["cells"] == nb * 73 and r["cells_judged_in_double"] == 0 and r["pwr_max_rel"] < 5e-6, r
+    assert b.parity_vs_gpu(cfg, gpk, gcl, cpu_pk, cpu_cl, bits, share_blocks=nb + 32)["whole_share"] is False
+
+    def verdict(mutate):
+        g = gcl.copy()
+        mutate(g)
+        return b.parity_vs_gpu(cfg, gpk, g, cpu_pk, cpu_cl, bits, share_blocks=nb)
+
+    def scale(f, k):
+        def m(g):
+            g[f][1, 40] *= np.float32(1.0 + k)
+        return m
+    r = verdict(scale("tot_pwr", 1.5e-5))  # off the screen, inside the judge's tolerance
+    assert r["ok"] and r["cells_judged_in_double"] == 1 and 1e-5 < r["pwr_max_rel_judged_in_double"] <= 2e-5, r
+    r = verdict(scale("max_pwr", 6e-5))
+    assert not r["ok"] and r["n_cell_power_mismatches"] == 1 and r["cell_power_mismatches"][0][:3] == [1, 40 - 36, "max_pwr"], r
+
+    def move_lag(g):
+        g["max_i"][2, 5] = (g["max_i"][2, 5] + 11) % 5456
+    r = verdict(move_lag)
+    assert not r["ok"] and r["cell_lag_mismatches"] == [[2, 5 - 36]] and r["cell_lag_ties"] == 0, r
+    for bad in (np.nan, np.inf, 0.0, -1.0):
+        def poison(g, bad=bad):
+            g["tot_pwr"][0, 0] = bad
+        r = verdict(poison)
+        assert not r["ok"] and r["non_finite_or_non_positive_cell_powers"] == 1, (bad, r)
+
+    def off_scan(g):
+        g["max_i"][0, 72] = 5456
+    r = verdict(off_scan)
+    assert not r["ok"] and r["cell_lag_mismatches"] == [[0, 36]], r
+    # an exact tie in the double-precision powers: the GPU may report either lag
+    orc = Oracle(cfg["fc"], cfg["fs"], cfg["max_fo"], kind="f64")
+    _, _, lag_powers = b.compare_peaks(cfg, gpk, cpu_pk, bits)
+    calls = []
+
+    def tied(block, sv, lo):
+        pw = lag_powers(block, sv, lo).copy()
+        pw[(int(np.argmax(pw)) + 11) % 5456] = pw.max()
+        calls.append((sv, lo))
+        return pw
+    g = gcl.copy()
+    move_lag(g)
+    r = b.compare_cells(g, cpu_cl, bits, 0, orc, tied)
+    assert r["ok"] and r["cell_lag_ties"] == 1 and calls == [(2, 5 - 36)], r
+    # every cell 1e-4 off: nothing is judged one by one, the verdict is a failure
+    g = gcl.copy()
+    g["max_pwr"] *= np.float32(1.0001)
+    r = b.compare_cells(g, cpu_cl, bits, 0, orc, lag_powers, max_recheck=50)
+    assert not r["ok"] and r["too_many_cells_off_the_screen"] and r["cells_judged_in_double"] == nb * 73, r
+
+
 def test_keys_digest_and_host_packing():
     """keys_digest: 16 hex digits of sha256 over the int64 keys; pack_keys_host: the packing of gpsacq_peak_keys_device /
     gpsacq.dist.pack_keys on PEAK records (integer MAX = higher SNR, ties to the lower Doppler bin, c/search_offline.cpp:196-198)."""

@@ -26,9 +26,9 @@ def _line(r):
 
 
 def test_default_line_carries_its_own_parity_verdict_and_clock():
-    """cpu_baseline.parity_vs_gpu: the peaks of the last timed step against the oracle's float build on the blocks the cpu_baseline
-    leg searches anyway (c/search_offline.cpp:190-198: same code phase, same Doppler bin, SNR to 1e-4, ties proven in double),
-    plus three full rows of cells against liboracle_f64; roofline.sclk_mhz / cycles_per_cell_per_cu / frac_at_clock from readings
+    """cpu_baseline.parity_vs_gpu: the peaks of the last timed step against the oracle's float build on EVERY block of the step (the
+    all-cores pass of the oracle; c/search_offline.cpp:190-198: same code phase, same Doppler bin, SNR to 1e-4, ties proven in double),
+    and every cell of those blocks (powers to 1e-5 of the float build or 2e-5 of liboracle_f64, lags equal or proven ties); roofline.sclk_mhz / cycles_per_cell_per_cu / frac_at_clock from readings
     taken DURING the timed steps; roofline.pk_fma_stream_TF from the micro-benchmark run in the untimed part."""
     r = _run_bench("--steps", "8", "--warmup", "2", "--blocks-total", "640", "--weak-blocks", "0", "--no-e2e", "--no-live-traffic",
                    "--soak-seconds", "0.5", "--pk-fma-seconds", "1.0")
@@ -37,9 +37,12 @@ def test_default_line_carries_its_own_parity_verdict_and_clock():
     cb = j["cpu_baseline"]
     par = cb["parity_vs_gpu"]
     assert par["ok"] is True and cb["parity_ok"] is True, par
-    assert par["blocks"] >= 200 and par["ca_equal"] + par["proven_ties"] >= par["blocks"] and not par["unproven_mismatches"]
+    assert par["blocks"] == 640 and par["whole_share"] is True and par["ca_equal"] + par["proven_ties"] >= par["blocks"] and not par["unproven_mismatches"]
     assert par["lo_equal"] + par["proven_ties"] >= par["blocks"]
-    assert par["snr_max_rel"] <= 1e-4 and par["pwr_max_rel"] <= 2e-5 and par["cells"] == 3 * 73 and not par["cell_lag_mismatches"]
+    assert par["snr_max_rel"] <= 1e-4 and par["pwr_max_rel"] <= 2e-5 and par["cells"] == 640 * 73 and not par["cell_lag_mismatches"]
+    assert par["non_finite_or_non_positive_cell_powers"] == 0 and not par["cell_power_mismatches"] and not par["too_many_cells_off_the_screen"]
+    ac = j["cpu_baseline_all_cores"]
+    assert "error" not in ac and ac["blocks"] == 640 and ac["equals_the_one_thread_run"] is True and ac["value"] > 0, ac
     assert cb["parity_blocks"] == par["blocks"] and cb["parity_snr_max_rel"] == par["snr_max_rel"] and cb["parity_pwr_max_rel"] == par["pwr_max_rel"]
     rf = j["roofline"]
     cs = rf["clock_sampling"]
@@ -155,13 +158,13 @@ def test_headline_size_properties_on_the_device_path():
 def test_parity_verdict_on_the_references_own_capture(golden_dir):
     """`bench.py --config 2 --capture gps_sig_tmp.bin` with the CPU baseline on: the verdict covers every one of the 384 blocks of the
     reference-held file (12 runs x 32 PRN x 49 bins at fs 8.184 MHz, 8184 lags; the k_corr<33> instance) -- same code phase and Doppler
-    bin as the oracle in all of them, three rows of cells to 2e-5 -- and PRN 8 is the file's satellite (README.md:45,57)."""
+    bin as the oracle in all of them, every one of their 18 816 cells within tolerance -- and PRN 8 is the file's satellite (README.md:45,57)."""
     r = _run_bench("--config", "2", "--capture", os.path.join(golden_dir, "gps_sig_tmp.bin"), "--steps", "2", "--warmup", "1", "--no-e2e",
                    "--no-live-traffic", "--soak-seconds", "0", "--weak-blocks", "0")
     assert r.returncode == 0, r.stderr[-3000:]
     j = _line(r)
     par = j["cpu_baseline"]["parity_vs_gpu"]
-    assert par["ok"] is True and par["blocks"] == 384 and par["ca_equal"] + par["proven_ties"] == 384 and par["cells"] == 3 * 49
+    assert par["ok"] is True and par["blocks"] == 384 and par["ca_equal"] + par["proven_ties"] == 384 and par["cells"] == 384 * 49 and par["whole_share"] is True
     assert par["snr_max_rel"] <= 1e-4 and par["pwr_max_rel"] <= 2e-5
     best = {d["prn"]: d for d in j["detected"]}
     assert 8 in best and best[8]["lo_shift"] == 0 and best[8]["snr"] > 500

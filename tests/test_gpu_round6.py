@@ -93,6 +93,7 @@ def test_keys_digest_is_identical_at_1_2_and_8_ranks_and_rank0_is_checked_agains
     j1 = _bench(*SMALL)
     assert j1["n_gpus"] == 1 and j1["keys_digest_comparable_across_n"] is True and len(j1["keys_digest"]) == 16
     assert j1["cpu_baseline"]["parity_ok"] is True and j1["cpu_baseline"]["parity_vs_gpu"]["first_block_of_this_rank"] == 0
+    assert j1["cpu_baseline"]["parity_blocks"] == 1280 and j1["cpu_baseline"]["parity_cells"] == 1280 * 73 and j1["cpu_baseline"]["parity_whole_share"] is True
     assert set(j1["detected_prns"]) >= set(j1["injected_prns_all_ranks"]) and len(j1["injected_prns_all_ranks"]) == 8
     for n in (2, 8):
         j = _torchrun(n, *SMALL)
@@ -101,8 +102,11 @@ def test_keys_digest_is_identical_at_1_2_and_8_ranks_and_rank0_is_checked_agains
         assert j["detected"] == j1["detected"] and j["injected_prns_all_ranks"] == j1["injected_prns_all_ranks"]
         assert "cpu_baseline" not in j  # an N = 1 figure
         par = j["parity_vs_gpu"]
-        assert j["parity_ok"] is True and par["ok"] is True and par["blocks"] >= min(96, j["blocks_per_rank"][0]) and par["cells"] == 3 * 73, par
-        assert par["snr_max_rel"] <= 1e-4 and par["pwr_max_rel"] <= 2e-5
+        # rank 0's WHOLE share: every block's peak and every cell of the last timed step against the oracle
+        assert j["parity_ok"] is True and par["ok"] is True and par["whole_share"] is True and j["parity_whole_share"] is True, par
+        assert par["blocks"] == j["blocks_per_rank"][0] and par["cells"] == par["blocks"] * 73 and par["first_block_of_this_rank"] == 0, par
+        assert par["snr_max_rel"] <= 1e-4 and par["pwr_max_rel"] <= 2e-5 and not par["cell_lag_mismatches"] and not par["cell_power_mismatches"]
+        assert "error" not in j["parity_oracle_run"], j["parity_oracle_run"]
         im = j["extras"]["inproc_multi"]
         assert "error" not in im, im
         assert im["keys_equal_digest"] is True and im["keys_digest"] == j1["keys_digest"] and im["devices"] == [0] * n and im["runs"] == 40
