@@ -15,7 +15,8 @@ Scaling: STRONG, and every world size searches THE SAME capture.  The capture is
 (gpsacq_generate_range_device): rank r of N generates exactly blocks [first_run * 32, ...) of the stream the N = 1 job searches
 (gpsacq.dist.shard_runs).  `keys_digest` -- sha256 of the 32 merged per-PRN keys of the last timed step (snr, Doppler bin, code phase
 of the best peak of every PRN over the whole capture; c/search_offline.cpp:196-198) -- and `detected` are therefore IDENTICAL at N = 1,
-2, 4, 8 by construction; rank 0's share is checked against the oracle at any N (cpu_baseline.parity_vs_gpu / parity_vs_gpu); at N > 1
+2, 4, 8 by construction; rank 0's WHOLE share of the last timed step -- every block's peak, every cell -- is checked against the oracle at
+any N (cpu_baseline.parity_vs_gpu / parity_vs_gpu: the oracle's all-cores pass, which is also the cpu_baseline_all_cores figure); at N > 1
 rank 0 also drives all N devices once through the C ABI's own gpsacq_multi_search_blocks (extras.inproc_multi) and compares its keys.
 
 Other lines (the default stays the one the driver records): --config 2|3|4 (BASELINE configs[2..4]), --input iq8 (8-bit IQ capture
