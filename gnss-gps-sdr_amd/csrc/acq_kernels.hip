@@ -243,8 +243,19 @@ template <class L> __device__ __forceinline__ int corr_rho(const CorrArgs& a, in
 // tables of the sub-transform in flight are one LDS image refreshed by LDS-DMA (buffer_load ... lds: 1 KB = 64 lanes x 16 bytes per
 // wave-instruction, no VGPRs, no ds_write; six of them per sub-transform, spread over the four waves): -1.4 % kernel time on
 // configs[1] and [4] (profiles/r04_experiments/a_fold_bq.log; with per-thread copies instead of the DMA it was -0.6 %).
-template <int MC, int WPS, int NB, bool NC, bool W1H = false, class L = LayC, bool NCREG = false, bool FOLD = false>
+// PERSIST (round 6; every instance that runs three workgroups per CU): the grid is a.persist_wgs workgroups -- as many as are resident
+// at once -- and a workgroup walks cells handed out at run time: it draws a ticket from the counter of the XCD it really runs on
+// (XCC_ID), and the ticket stands for one Doppler point of one unit of work (a task, or a chunk of a fine grid's task) that the XCD
+// took from ONE global counter when it reached it (draw_ticket / task_of_ticket below).  The cells of a unit stay on one XCD and the
+// cells in flight on an XCD are consecutive points of one or two units -- the L2 working set of the one-cell-per-workgroup launch (a
+// static stride loses it: 24 % slower, profiles/r05_experiments/f_persistent_workgroups.log).  What changes: an XCD takes work at its
+// own pace -- under the power cap the XCDs of a package run 3-5 % apart and the fixed deal block g -> XCD g % 8
+// moves at the slowest one's, through an in-order dispatcher that leaves slots of the others empty meanwhile -- and a CU never waits
+// for a workgroup to be dispatched.  -1.7 ... -4.4 % kernel time by box on configs[1] (profiles/r06_experiments/a_persistent_stealing.log).
+// The ticket is drawn before the peak scan and travels to the other threads through the reduction's LDS slots and barrier.
+template <int MC, int WPS, int NB, bool NC, bool W1H = false, class L = LayC, bool NCREG = false, bool FOLD = false, bool PERSIST = false>
 __global__ __launch_bounds__(WG, WPS) void k_corr(CorrArgs a) {
+    static_assert(!PERSIST || !NC || NCREG, "persistent workgroups: the coherent instances and the one with its non-coherent sums in registers");
     __shared__ __attribute__((aligned(16))) cf lds[L::SIZE];  // transform buffer
     // pass 2's 500 twiddles; with FOLD followed by the accumulate factors [alpha][column], in whole 1 KB chunks (the DMA's unit)
     constexpr int TQS = TqStride<MC>::value;
@@ -255,33 +266,107 @@ __global__ __launch_bounds__(WG, WPS) void k_corr(CorrArgs a) {
     __shared__ float red[4 * (WG / 64)];
     __shared__ float pws[NC && !NCREG ? MC * NBF3 : 1];  // non-coherent power per lag of this pass
     const int tid = threadIdx.x;
-    const int g = blockIdx.x, xcd = g & 7, slot = g >> 3;
-    const int grp = slot / a.ndop, di = slot - grp * a.ndop;
-    const int task = grp * 8 + xcd;
-    if (task >= a.n_tasks) return;
-    const Task tk = a.tasks[task];
+    // PERSIST: what a cell needs only at its start and end (task list, grid, output, hand-out state) is re-read from the kernel-argument
+    // segment where it is used -- scalar loads through a pointer the compiler cannot see through -- instead of living in SGPRs across
+    // the sub-transforms, whose radix-25 constants fill the scalar file (it would park them in VGPR lanes: v_readlane in the hot loop)
+    typedef const __attribute__((address_space(4))) CorrArgs* KArgs;
+    auto K = [&]() __attribute__((always_inline)) {
+        KArgs p = (KArgs)__builtin_amdgcn_kernarg_segment_ptr();
+        asm volatile("" : "+s"(p));
+        return p;
+    };
+#define KA(field) (PERSIST ? K()->field : a.field)
+    // PERSIST: the XCD this workgroup runs on, from the hardware (HW_REG_XCC_ID through __smid(): XCC_ID << 6 | SE_ID << 4 | CU_ID)
+    const int my_xcd = PERSIST ? (int)((__smid() >> 6) & 7u) : 0;
+    // The next cell of this workgroup's XCD (thread 0 only).  The unit handed to an XCD is a CHUNK of a task: a.persist_chunk
+    // consecutive Doppler points (all of them when a task has few -- the reference's 73 bins are one chunk --, ~128 of a fine grid's
+    // thousands, so that a few long tasks still spread evenly and no XCD is left with a whole task at the end; an XCD re-reads the
+    // task's 650 KB of spectra per chunk: nothing next to the chunk's work).  Ticket t of an XCD is point t % chunk of its
+    // (t / chunk)-th unit slot; which unit that is is decided by whoever draws the slot's first ticket -- at once, so that the holders
+    // of the slot's other tickets find it published: unit u = the next of ONE global counter = chunk u % units of task u / units.
+    auto draw_ticket = [&]() __attribute__((always_inline)) {
+        const int t = __hip_atomic_fetch_add(KA(persist_queue) + 16 * my_xcd, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        const int s = t / KA(persist_chunk);
+        if (t == s * KA(persist_chunk) && s < KA(persist_slots)) {
+            const int u = __hip_atomic_fetch_add(KA(persist_queue) + 16 * 8, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            __hip_atomic_store(KA(persist_tasks) + (size_t)my_xcd * KA(persist_slots) + s, u + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+        return t;
+    };
+    // the (task, Doppler point) a ticket stands for; a ticket past the last point of a task's last chunk is void: draw again
+    auto task_of_ticket = [&](int ticket, int& di_out) __attribute__((always_inline)) {
+        for (;;) {
+            const int s = ticket / KA(persist_chunk), j = ticket - s * KA(persist_chunk);
+            if (s >= KA(persist_slots)) return KA(n_tasks);  // (cannot happen: an XCD draws at most every unit + one ticket per workgroup)
+            int* const slot = KA(persist_tasks) + (size_t)my_xcd * KA(persist_slots) + s;
+            int u1;  // (the slot's first ticket was drawn before this one, by a workgroup that published the unit in the same breath)
+            while ((u1 = __hip_atomic_load(slot, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) == 0) __builtin_amdgcn_s_sleep(1);
+            const int u = u1 - 1, t = u / KA(persist_units), c = u - t * KA(persist_units);
+            if (t >= KA(n_tasks)) return KA(n_tasks);
+            di_out = c * KA(persist_chunk) + j;
+            if (di_out < KA(ndop)) return t;
+            ticket = draw_ticket();
+        }
+    };
+    int task, di;
+    cf w1[2][RA - 1];
+    if constexpr (PERSIST) {
+        if (tid == 0) {
+            int d0;
+            const int t0 = task_of_ticket(draw_ticket(), d0);
+            red[3] = __int_as_float(t0);   // (slots 4 w + 3 of the reduction's array are free)
+            red[7] = __int_as_float(d0);
+        }
+        load_tw1<W1H, L>(tid, a.t1, w1);  // once per workgroup
+        if constexpr (!FOLD)
+            for (int i = tid; i < NT2; i += WG) t2s[i] = a.t2[i];
+        __syncthreads();
+        task = __builtin_amdgcn_readfirstlane(__float_as_int(red[3]));  // (uniform: kept in SGPRs)
+        di = __builtin_amdgcn_readfirstlane(__float_as_int(red[7]));
+    } else {
+        const int g = blockIdx.x, xcd = g & 7, slot = g >> 3;
+        const int grp = slot / KA(ndop);
+        di = slot - grp * KA(ndop);
+        task = grp * 8 + xcd;
+    }
+    for (;;) {  // one trip unless PERSIST (every way out of the body returns)
+    if (task >= KA(n_tasks)) return;
+    const Task tk = KA(tasks)[task];
     // task lists handed over in device memory are not seen by the host: bound them here (uniform branch)
-    if (tk.spec < 0 || (long)tk.spec + (long)(a.n_acc - 1) * a.acc_step >= a.n_spec || tk.code < 0 || tk.code >= a.n_code) {
+    if (tk.spec < 0 || (long)tk.spec + (long)(KA(n_acc) - 1) * KA(acc_step) >= KA(n_spec) || tk.code < 0 || tk.code >= KA(n_code)) {
         if (tid == 0) {
             Cell c;
             c.max_pwr = 0.f;
             c.max_i = -1;
             c.tot_pwr = 0.f;
             c.snr = 0.f;
-            a.cells[(size_t)task * a.ndop + di] = c;
+            KA(cells)[(size_t)task * KA(ndop) + di] = c;
         }
-        return;
+        if constexpr (PERSIST) {  // (uniform: every thread takes the same next cell through LDS)
+            __syncthreads();  // red[3], red[7] of this cell are read
+            if (tid == 0) {
+                int d0;
+                const int t0 = task_of_ticket(draw_ticket(), d0);
+                red[3] = __int_as_float(t0);   // (slots 4 w + 3 of the reduction's array are free)
+                red[7] = __int_as_float(d0);
+            }
+            __syncthreads();
+            task = __builtin_amdgcn_readfirstlane(__float_as_int(red[3]));  // (uniform: kept in SGPRs)
+            di = __builtin_amdgcn_readfirstlane(__float_as_int(red[7]));
+            continue;
+        } else return;
     }
     int dop, rsub;
-    grid_point(di + a.dop_first, a.sub, a.dstride, dop, rsub);
-    const cf* dpp = a.dpp + ((size_t)tk.spec * a.sub + rsub) * NPOLY * M_SUB;
-    const cf* cpp = a.cpp + (size_t)tk.code * NPOLY * a.crow;
+    grid_point(di + KA(dop_first), KA(sub), KA(dstride), dop, rsub);
+    const cf* dpp = KA(dpp) + ((size_t)tk.spec * KA(sub) + rsub) * NPOLY * M_SUB;
+    const cf* cpp = KA(cpp) + (size_t)tk.code * NPOLY * a.crow;
 
     // q-independent twiddles: pass 2's table into LDS (16-byte copies), pass 1's into registers
-    if constexpr (!FOLD)
-        for (int i = tid; i < NT2; i += WG) t2s[i] = a.t2[i];
-    cf w1[2][RA - 1];
-    load_tw1<W1H, L>(tid, a.t1, w1);
+    if constexpr (!PERSIST) {
+        if constexpr (!FOLD)
+            for (int i = tid; i < NT2; i += WG) t2s[i] = a.t2[i];
+        load_tw1<W1H, L>(tid, a.t1, w1);
+    }
 
     cf acc[MC];
 #pragma unroll
@@ -298,7 +383,7 @@ __global__ __launch_bounds__(WG, WPS) void k_corr(CorrArgs a) {
     }
     const int t3 = tid < NBF3 ? tid : 0;
     const int rho = corr_rho<L>(a, t3);  // the radix-20 butterfly (output residue) this thread owns
-    const int n_acc = NC ? a.n_acc : 1;
+    const int n_acc = NC ? KA(n_acc) : 1;
     // FOLD: which 16 bytes of the global table fold[q] (acq_tables.hpp TablesFold: [t2q (500)][tq (10 x 160)] per q) each lane copies
     // into its slot of the LDS image, for the one or two chunks this wave is responsible for (lanes past the image copy entry 0
     // into the image's padding)
@@ -318,7 +403,7 @@ __global__ __launch_bounds__(WG, WPS) void k_corr(CorrArgs a) {
         }
     }
     for (int k = 0; k < n_acc; ++k) {
-        const cf* dk = dpp + (size_t)k * a.acc_step * a.sub * NPOLY * M_SUB;
+        const cf* dk = dpp + (size_t)k * KA(acc_step) * KA(sub) * NPOLY * M_SUB;
         // one sub-transform; `first` (a std::bool_constant): its outputs are the accumulators' first values
         auto subtransform = [&](const int q, auto first) __attribute__((always_inline)) {
             cf b = mk(0.f, 0.f);
@@ -375,21 +460,24 @@ __global__ __launch_bounds__(WG, WPS) void k_corr(CorrArgs a) {
             // every lag has one owner per block, so the scatter needs no atomics; successive blocks'
             // updates are separated by the barriers of the next 8 sub-transforms
             // block k's peak sits later by what the code has crept at this cell's Doppler, and by the code phase its start is ahead of block 0's
-            const int shift = __float2int_rn((float)k * a.creep * (float)(di + a.dop_first)) + k * a.lag_step;
-            if (a.pdump) corr_dump_power<MC>(tid, rho, a.nlags, a.m0, shift, acc, a.pdump + ((size_t)task * a.ndop + di) * a.nlags);
-            else corr_accumulate_power<MC>(tid, rho, a.nlags, a.m0, shift, acc, pws);
+            const int shift = __float2int_rn((float)k * a.creep * (float)(di + KA(dop_first))) + k * a.lag_step;
+            if (a.pdump) corr_dump_power<MC>(tid, rho, KA(nlags), a.m0, shift, acc, a.pdump + ((size_t)task * KA(ndop) + di) * KA(nlags));
+            else corr_accumulate_power<MC>(tid, rho, KA(nlags), a.m0, shift, acc, pws);
         }
     }
     if (NC && !NCREG && a.pdump) return;  // this pass's powers are in a.pdump; launch_scan_power makes the cells
 
+    int next_ticket = 0;  // PERSIST: drawn now, needed after the scan
+    if constexpr (PERSIST)
+        if (tid == 0) next_ticket = draw_ticket();
     float mx, sum;
     int mi;
-    if (NC && NCREG) corr_scan_power_reg<MC>(tid, rho, a.nlags, a.m0, pw, mx, mi, sum);
+    if (NC && NCREG) corr_scan_power_reg<MC>(tid, rho, KA(nlags), a.m0, pw, mx, mi, sum);
     else if (NC) {
         __syncthreads();  // the last block's scatter
-        corr_scan_power<MC>(tid, rho, a.nlags, a.m0, pws, mx, mi, sum);
+        corr_scan_power<MC>(tid, rho, KA(nlags), a.m0, pws, mx, mi, sum);
     }
-    else corr_scan<MC>(tid, rho, a.nlags, a.m0, acc, mx, mi, sum);
+    else corr_scan<MC>(tid, rho, KA(nlags), a.m0, acc, mx, mi, sum);
     // wave reduction (64 lanes), then across the 4 waves through LDS
     wave_reduce_peak(mx, mi, sum);
     const int wave = tid >> 6;
@@ -397,6 +485,12 @@ __global__ __launch_bounds__(WG, WPS) void k_corr(CorrArgs a) {
         red[wave * 4 + 0] = mx;
         red[wave * 4 + 1] = __int_as_float(mi);
         red[wave * 4 + 2] = sum;
+        if (PERSIST && tid == 0) {
+            int d0;
+            const int t0 = task_of_ticket(next_ticket, d0);
+            red[3] = __int_as_float(t0);   // (slots 4 w + 3 of the reduction's array are free)
+            red[7] = __int_as_float(d0);
+        }
     }
     __syncthreads();
     if (tid == 0) {
@@ -408,11 +502,18 @@ __global__ __launch_bounds__(WG, WPS) void k_corr(CorrArgs a) {
         c.max_pwr = mx;
         c.max_i = mi;
         c.tot_pwr = sum;
-        const float ave = sum / (float)a.nlags;  // :195 tot_pwr / i
+        const float ave = sum / (float)KA(nlags);  // :195 tot_pwr / i
         c.snr = (sum > 0.f) ? mx / ave : 0.f;    // :196; 0/0 of the reference defined as 0
-        a.cells[(size_t)task * a.ndop + di] = c;
+        KA(cells)[(size_t)task * KA(ndop) + di] = c;
+    }
+    // PERSIST: on to this workgroup's next cell.  No barrier needed here: the next cell's first LDS writes (pass-1 stores, the table DMA)
+    // touch buffers last read before the final sub-transform's third barrier; `red` is rewritten two dozen barriers from now
+    if constexpr (!PERSIST) return;
+    task = __builtin_amdgcn_readfirstlane(__float_as_int(red[3]));  // (uniform: kept in SGPRs)
+    di = __builtin_amdgcn_readfirstlane(__float_as_int(red[7]));
     }
 }
+#undef KA
 
 // More than 10000 lags (fs > 10 MHz) take several k_corr passes of 40 columns each; this folds the
 // partial cells (ascending lag ranges, so strict '>' keeps the first maximum) and sets the SNR.
@@ -537,6 +638,7 @@ int corr_columns(int nlags) {  // accumulator columns of the smallest instance t
         if (need <= m) return m;
     return MC_MAX;  // several passes of 40 columns
 }
+bool corr_has_persistent_form(int mc) { return mc == 12 || mc == 22 || mc == 28 || mc == 33; }
 int launch_corr(const CorrArgs& a, int mc, hipStream_t s) {
     const int groups = (a.n_tasks + 7) / 8;
     const dim3 grid((unsigned)groups * 8u * (unsigned)a.ndop), block(WG);
@@ -544,29 +646,38 @@ int launch_corr(const CorrArgs& a, int mc, hipStream_t s) {
     // non-coherent, W1H>.  LDS (49 KB per workgroup) admits 3 workgroups per CU; 12, 22 and 28 columns fit 168 VGPRs,
     // 28 and 33 columns do with half the pass-1 twiddles derived (W1H); 40 columns then spill 40 bytes per lane and are still
     // faster at 3 per CU (14.4 vs 13.5 M cells/s; without W1H 116 bytes and slower: profiles/r02_experiments/i, r02j).
+    // a.persist_wgs > 0 (the engine armed the hand-out state): the three-per-CU instances run as persistent workgroups
+    const bool persist = a.persist_wgs > 0 && a.persist_queue && a.persist_tasks && corr_has_persistent_form(mc);
+    const dim3 pgrid((unsigned)(persist ? a.persist_wgs : 1));
     switch (mc) {
         case 12:
             // non-coherent: without creep re-alignment the per-lag sums stay in registers and three workgroups fit a CU (BASELINE
             // configs[3]); with it they go through a per-lag LDS array (61 KB: two per CU)
-            if (a.n_acc > 1 && a.creep == 0.f && a.lag_step == 0) hipLaunchKernelGGL((k_corr<12, 3, 2, true, false, LayC, true>), grid, block, 0, s, a);
-            else if (a.n_acc > 1) hipLaunchKernelGGL((k_corr<12, 2, 2, true>), grid, block, 0, s, a);
+            if (a.n_acc > 1 && a.creep == 0.f && a.lag_step == 0) {
+                if (persist) hipLaunchKernelGGL((k_corr<12, 3, 2, true, false, LayC, true, false, true>), pgrid, block, 0, s, a);
+                else hipLaunchKernelGGL((k_corr<12, 3, 2, true, false, LayC, true>), grid, block, 0, s, a);
+            } else if (a.n_acc > 1) hipLaunchKernelGGL((k_corr<12, 2, 2, true>), grid, block, 0, s, a);
+            else if (persist) hipLaunchKernelGGL((k_corr<12, 3, 2, false, false, LayC, false, false, true>), pgrid, block, 0, s, a);
             else hipLaunchKernelGGL((k_corr<12, 3, 2, false>), grid, block, 0, s, a);
             break;
         case 22:
             if (a.n_acc > 1) hipLaunchKernelGGL((k_corr<22, 2, 2, true>), grid, block, 0, s, a);
+            else if (persist) hipLaunchKernelGGL((k_corr<22, 3, 2, false, false, LayC, false, true, true>), pgrid, block, 0, s, a);
             else hipLaunchKernelGGL((k_corr<22, 3, 2, false, false, LayC, false, true>), grid, block, 0, s, a);  // FOLD
             break;
         case 28:
             if (a.n_acc > 1) hipLaunchKernelGGL((k_corr<28, 2, 2, true>), grid, block, 0, s, a);
+            else if (persist) hipLaunchKernelGGL((k_corr<28, 3, 2, false, true, LayC, false, false, true>), pgrid, block, 0, s, a);
             else hipLaunchKernelGGL((k_corr<28, 3, 2, false, true>), grid, block, 0, s, a);
             break;
         case 33:
             if (a.n_acc > 1) hipLaunchKernelGGL((k_corr<33, 2, 2, true, false, LayA>), grid, block, 0, s, a);
+            else if (persist) hipLaunchKernelGGL((k_corr<33, 3, 2, false, true, LayC, false, false, true>), pgrid, block, 0, s, a);
             else hipLaunchKernelGGL((k_corr<33, 3, 2, false, true>), grid, block, 0, s, a);
             break;
         case 40:
             if (a.n_acc > 1) hipLaunchKernelGGL((k_corr<40, 1, 2, true, false, LayA>), grid, block, 0, s, a);  // 84 KB of LDS: one workgroup per CU
-            else hipLaunchKernelGGL((k_corr<40, 3, 2, false, true>), grid, block, 0, s, a);  // 40 bytes of spills: still 7 % faster than 2 per CU
+            else hipLaunchKernelGGL((k_corr<40, 3, 2, false, true>), grid, block, 0, s, a);  // 28 bytes of spills: still 7 % faster than 2 per CU; no persistent form (it would spill 84)
             break;
         default: return -1;
     }

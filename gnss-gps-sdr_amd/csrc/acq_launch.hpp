@@ -57,6 +57,12 @@ struct CorrArgs {
                           // block samples) mod S, when the blocks are not whole code periods apart and re-alignment is asked for (0 = off)
     int n_spec, n_code;   // rows of dpp / cpp: tasks pointing outside get an empty cell (max_i = -1)
     int sub, dstride;     // Doppler grid (acq_phases.hpp grid_point): dop_first/ndop count grid points; spectrum of (block, r) at row block*sub + r
+    int* persist_queue;   // k_corr<..., PERSIST>: 8 per-XCD ticket counters + the global task counter, 64 bytes apart (9 x 16 ints, zeroed before the launch); NULL: off
+    int* persist_tasks;   // k_corr<..., PERSIST>: [8][persist_slots] unit (task, chunk) of an XCD's s-th unit slot + 1 (0: not decided yet; zeroed before the launch)
+    int persist_slots;    // >= units + workgroups (an XCD's tickets run past the last unit by at most one per workgroup)
+    int persist_wgs;      // workgroups of the persistent launch (3 per CU); 0: one workgroup per cell
+    int persist_chunk;    // Doppler points per hand-out unit (a chunk of one task): ceil(ndop / persist_units)
+    int persist_units;    // units per task: ceil(ndop / ~128)
     float* pdump;      // non-coherent mode with creep re-alignment over several column passes (fs > 10 MHz): per-lag power sums in
                        // device memory, [n_tasks * ndop][nlags], zeroed by the caller; the cells then come from launch_scan_power.  Else NULL
 };
@@ -71,6 +77,7 @@ void launch_fwd_realmix(const FwdArgs& a, int n_items, hipStream_t s);
 void launch_code_halo(cf* cpp, int n_rows, int crow, int halo, hipStream_t s);
 void launch_quirk_patch(const QuirkArgs& a, int n_patch, hipStream_t s);
 int corr_columns(int nlags);
+bool corr_has_persistent_form(int mc);  // instances launch_corr can run as persistent workgroups (CorrArgs::persist_*)
 hipError_t upload_wq(const cf* host);  // fills the __constant__ copy of wq on the current device
 int launch_corr(const CorrArgs& a, int mc, hipStream_t s);
 void launch_scan_power(const float* pdump, Cell* cells, size_t n_cells, int nlags, hipStream_t s);

@@ -102,6 +102,10 @@ struct gpsacq_engine {
     size_t sats_cap = 0;
     uint8_t* d_gen = nullptr;
     size_t gen_cap = 0;
+    // k_corr<..., PERSIST>: the hand-out state of a launch (9 counters 64 bytes apart, then [8][slots] task slots), zeroed before it
+    int* d_persist = nullptr;
+    size_t persist_cap = 0;
+    bool persist = false;
     // cached default schedule (task t = block t, PRN t % 32; with ref_quirks also its patch list: blocks 0, 32, 64, ...)
     size_t sched_tasks = 0;
     bool sched_valid = false;
@@ -217,7 +221,7 @@ extern "C" void gpsacq_destroy(gpsacq_engine* e) {
     if (!e) return;
     (void)hipSetDevice(e->p.device);
     if (e->stream) (void)hipStreamSynchronize(e->stream);
-    void* bufs[] = {e->d_t1, e->d_t2, e->d_bq, e->d_fold, e->d_tn, e->d_rho, e->d_cos, e->d_sin, e->d_cos_t, e->d_sin_t, e->d_code, e->d_patch_blocks, e->d_bits, e->d_iq, e->d_iqbits, e->d_fsamp, e->d_pdump, e->d_sums, e->d_sats, e->d_gen, e->d_lutc,
+    void* bufs[] = {e->d_t1, e->d_t2, e->d_bq, e->d_fold, e->d_tn, e->d_rho, e->d_cos, e->d_sin, e->d_cos_t, e->d_sin_t, e->d_code, e->d_patch_blocks, e->d_bits, e->d_iq, e->d_iqbits, e->d_fsamp, e->d_pdump, e->d_sums, e->d_sats, e->d_gen, e->d_persist, e->d_lutc,
                     e->d_dpp, e->d_parts, e->d_tasks, e->d_cells, e->d_peaks};
     for (void* b : bufs)
         if (b) (void)hipFree(b);
@@ -319,6 +323,10 @@ extern "C" int gpsacq_create(const gpsacq_params* params, gpsacq_engine** out) {
     e->halo = ((dmax + 1 + 7) / 8 + 2 + 7) & ~7;  // |floor((q - dop)/8)| <= (dmax + 1)/8 + 1 (a sub-bin grid reaches bin -(dmax + 1))
     e->crow = M_SUB + 2 * e->halo;
     e->cus = prop.multiProcessorCount;
+    {
+        const char* pe = getenv("GPSACQ_CORR_PERSIST");  // 0: one workgroup per cell (A/B runs)
+        e->persist = !(pe && atoi(pe) == 0);
+    }
     snprintf(e->name, sizeof e->name, "%s", prop.name);
 #define HCK(expr)                                                                     \
     do {                                                                              \
@@ -528,6 +536,34 @@ static int pass_columns(int n_cols, int p) {
     return left >= MC_MAX ? MC_MAX : corr_columns(left * NBF3);
 }
 
+// Arms the run-time hand-out of cells for the next launch_corr (k_corr<..., PERSIST>, acq_kernels.hip): the launch then is three
+// resident workgroups per CU that draw (task, Doppler point) tickets instead of one workgroup per cell.  Every instance that runs
+// three workgroups per CU has a persistent form: the coherent ones and the 12-column one with its non-coherent sums in registers
+// (launch_corr picks by the same conditions; for any other instance the fields are ignored).  The state is zeroed on the stream in
+// front of the launch it belongs to.  GPSACQ_CORR_PERSIST=0 (read at gpsacq_create): one workgroup per cell, as up to round 5.
+static int arm_persist(gpsacq_engine* e, CorrArgs& ca, int mc) {
+    ca.persist_wgs = 0;
+    ca.persist_queue = ca.persist_tasks = nullptr;
+    const bool three_per_cu = ca.n_acc == 1 || (mc == 12 && ca.creep == 0.f && ca.lag_step == 0);
+    if (!e->persist || !three_per_cu || ca.pdump || !corr_has_persistent_form(mc)) return GPSACQ_OK;
+    const int wgs = 3 * e->cus;
+    // the hand-out unit: a chunk of one task's Doppler points -- the whole task up to 146 points (the reference's grids), else ~128
+    const int units = ca.ndop <= 146 ? 1 : (ca.ndop + 127) / 128;
+    const int chunk = (ca.ndop + units - 1) / units;
+    const size_t slots = (size_t)ca.n_tasks * (size_t)units + (size_t)wgs + 2;  // an XCD's tickets run past the last unit by at most one per workgroup
+    if (slots > 0x7fffffffu / 8) return GPSACQ_OK;  // (a batch too large for the slot table: one workgroup per cell)
+    const size_t ints = 9 * 16 + 8 * slots;
+    if (int rc = grow(e->d_persist, e->persist_cap, ints, e->stream)) return rc;
+    HIPCHK(hipMemsetAsync(e->d_persist, 0, ints * sizeof(int), e->stream));
+    ca.persist_queue = e->d_persist;
+    ca.persist_tasks = e->d_persist + 9 * 16;
+    ca.persist_slots = (int)slots;
+    ca.persist_wgs = wgs;
+    ca.persist_units = units;
+    ca.persist_chunk = chunk;
+    return GPSACQ_OK;
+}
+
 static int search_core(gpsacq_engine* e, const Capture& cap_in, size_t n_blocks, const gpsacq_task* h_tasks,
                        const void* d_user_tasks, size_t n_tasks, Cell* d_cells, Peak* d_peaks) {
     Capture cap = cap_in;
@@ -631,6 +667,7 @@ static int search_core(gpsacq_engine* e, const Capture& cap_in, size_t n_blocks,
         // samples the code advances per accumulated block per Doppler bin: elapsed samples x (bin Hz / L1)
         if (e->creep_comp && e->n_acc > 1)
             ca.creep = (float)((double)e->acc_step * block_samples * (e->p.fs / N_FFT * e->dstride / e->sub) / 1575.42e6);
+        if (int rc = arm_persist(e, ca, e->mc)) return rc;
         if (launch_corr(ca, e->mc, e->stream) != 0) return fail(GPSACQ_ERR_UNSUPPORTED, "no correlate kernel for %d columns", e->mc);
     } else if (realign) {
         // re-aligned lags cross the passes' column windows: the per-lag sums of every cell go to device memory (nlags floats per
@@ -665,6 +702,7 @@ static int search_core(gpsacq_engine* e, const Capture& cap_in, size_t n_blocks,
             ca.m0 = p * MC_MAX;
             ca.cells = e->d_parts + (size_t)p * n_cells;
             const int mc = pass_columns(n_cols, p);
+            if (int rc = arm_persist(e, ca, mc)) return rc;
             if (launch_corr(ca, mc, e->stream) != 0) return fail(GPSACQ_ERR_UNSUPPORTED, "no correlate kernel for %d columns", mc);
         }
         launch_merge_cells(e->d_parts, d_cells, n_cells, n_pass, e->nlags, e->stream);
@@ -927,6 +965,12 @@ extern "C" int gpsacq_set_doppler_window(gpsacq_engine* e, int first_bin, int n_
         return fail(GPSACQ_ERR_ARG, "Doppler window [%d, %d] outside [-%d, %d]", first_bin, first_bin + n_bins - 1, e->kmax, e->kmax);
     e->dop_first = first_bin;
     e->ndop = n_bins;
+    return GPSACQ_OK;
+}
+
+extern "C" int gpsacq_set_cell_handout(gpsacq_engine* e, int on) {
+    if (!e) return fail(GPSACQ_ERR_ARG, "gpsacq_set_cell_handout: null engine");
+    e->persist = on != 0;
     return GPSACQ_OK;
 }
 

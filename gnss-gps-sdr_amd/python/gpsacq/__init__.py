@@ -63,7 +63,7 @@ class Sat(ctypes.Structure):
 
 
 EXPORTS = ["gpsacq_generate", "gpsacq_generate_device", "gpsacq_generate_range", "gpsacq_generate_range_device", "gpsacq_generate_sig", "gpsacq_sig_bytes", "gpsacq_handoff", "gpsacq_iq8_to_bits", "gpsacq_iq8_to_bits_device", "gpsacq_create", "gpsacq_destroy", "gpsacq_last_error", "gpsacq_get_info", "gpsacq_search",
-           "gpsacq_search_device", "gpsacq_set_doppler_window", "gpsacq_set_doppler_step", "gpsacq_set_noncoherent", "gpsacq_set_creep_compensation", "gpsacq_set_block_alignment", "gpsacq_aligned_stride", "gpsacq_synchronize", "gpsacq_last_timing", "gpsacq_timing_ago", "gpsacq_stream", "gpsacq_search_code",
+           "gpsacq_search_device", "gpsacq_set_doppler_window", "gpsacq_set_cell_handout", "gpsacq_set_doppler_step", "gpsacq_set_noncoherent", "gpsacq_set_creep_compensation", "gpsacq_set_block_alignment", "gpsacq_aligned_stride", "gpsacq_synchronize", "gpsacq_last_timing", "gpsacq_timing_ago", "gpsacq_stream", "gpsacq_search_code",
            "gpsacq_sample_spectrum", "gpsacq_code_spectrum", "gpsacq_multi_create", "gpsacq_multi_destroy",
            "gpsacq_multi_set_doppler_step", "gpsacq_multi_get_info", "gpsacq_multi_search_grid", "gpsacq_multi_search_blocks",
            "gpsacq_pipe_buffer", "gpsacq_pipe_submit", "gpsacq_pipe_collect", "gpsacq_search_iq8", "gpsacq_search_iq8_device",
@@ -118,6 +118,8 @@ def load_library(path=None):
     lib.gpsacq_search_device.restype = ctypes.c_int
     lib.gpsacq_set_doppler_window.argtypes = [vp, ctypes.c_int, ctypes.c_int]
     lib.gpsacq_set_doppler_window.restype = ctypes.c_int
+    lib.gpsacq_set_cell_handout.argtypes = [vp, ctypes.c_int]
+    lib.gpsacq_set_cell_handout.restype = ctypes.c_int
     lib.gpsacq_set_doppler_step.argtypes = [vp, ctypes.c_double]
     lib.gpsacq_set_doppler_step.restype = ctypes.c_int
     lib.gpsacq_set_noncoherent.argtypes = [vp, ctypes.c_int, ctypes.c_int]
@@ -267,6 +269,11 @@ class Engine:
         """Search only bins first_bin .. first_bin+n_bins-1 (multi-GPU Doppler-slab sharding)."""
         _check(self._lib, self._lib.gpsacq_set_doppler_window(self._h, int(first_bin), int(n_bins)))
         self._refresh_info()
+
+    def set_cell_handout(self, on):
+        """Run-time hand-out of the correlate kernel's cells to persistent workgroups (default on) or one workgroup per cell
+        (gpsacq_set_cell_handout): the same cells bit for bit, a different time."""
+        _check(self._lib, self._lib.gpsacq_set_cell_handout(self._h, 1 if on else 0))
 
     def set_doppler_step(self, step_hz):
         """Doppler grid step in Hz: finer than fs/40000 through sub-bin spectra, coarser through a bin stride

@@ -184,6 +184,16 @@ GPSACQ_API int gpsacq_pipe_collect(gpsacq_engine* e, int slot, const gpsacq_peak
  */
 GPSACQ_API int gpsacq_set_doppler_window(gpsacq_engine* e, int first_bin, int n_bins);
 /*
+ * How the correlate kernel's cells reach the compute units (no reference equivalent: Correlate(), c/search_offline.cpp:169-201, is a
+ * serial loop).  on != 0 (the default; GPSACQ_CORR_PERSIST=0 in the environment at gpsacq_create turns it off): three resident
+ * workgroups per CU draw (task, Doppler point) tickets at run time -- every XCD of the package takes work at its own pace, a task's
+ * points (or a ~128-point chunk of a fine grid's task) stay on one XCD.  on == 0: one workgroup per cell, block g on XCD g % 8, as up
+ * to round 5.  The cells are the same bit for bit either way (the same arithmetic per cell); only the time differs (3-5 % by box).
+ * Applies to the instances that run three workgroups per CU (every coherent search up to fs = 8.25 MHz, and the 12-column
+ * non-coherent one without re-alignment); the others ignore it.
+ */
+GPSACQ_API int gpsacq_set_cell_handout(gpsacq_engine* e, int on);
+/*
  * Doppler grid step (extension; the reference's grid is whole FFT bins of fs/40000 Hz, c/search_offline.cpp:176,182,
  * and its front end ignores argv[4]).  step_hz <= 0 or within (bin, 2 bin): the reference grid.  step_hz < bin: the
  * grid is refined to bin / R, R = ceil(bin / step_hz) (the finest grid not coarser than asked): each block is
