@@ -51,20 +51,24 @@ class Leg:
         self.iq = iq  # gpsacq.Iq8Input: d_bits then holds interleaved 8-bit I,Q bytes, `stride` bytes per block
         self.nblk, self.n_tasks, self.d_bits, self.d_tasks, self.stride, self.grid, self.n_keys = nblk, n_tasks, d_bits, d_tasks, stride, grid, n_keys
         # The search and the key packing run on the engine's own HIP stream, the collective on torch's stream behind an event, so step
-        # i's all-reduce overlaps step i+1's search (two peak / key buffers; the engine stream waits for a buffer's previous reader).
-        self.d_peaks = [torch.zeros((max(n_tasks, 1), 4), dtype=torch.int32, device=dev) for _ in range(2)]
-        self.d_keys = [torch.zeros(n_keys, dtype=torch.int64, device=dev) for _ in range(2)]
+        # i's all-reduce overlaps the searches behind it.  THREE peak / key buffers (the engine stream waits for a buffer's previous
+        # reader): the correlate kernel's workgroups are persistent and fill every CU until the kernel ends, so the all-reduce kernel of
+        # step i gets its CU at the boundary between the correlators of steps i+1 and i+2 -- with two buffers step i+2's search would
+        # wait for it there (a rendezvous of all ranks in every step), with three it has until step i+3.
+        self.NBUF = 3
+        self.d_peaks = [torch.zeros((max(n_tasks, 1), 4), dtype=torch.int32, device=dev) for _ in range(self.NBUF)]
+        self.d_keys = [torch.zeros(n_keys, dtype=torch.int64, device=dev) for _ in range(self.NBUF)]
         # keep_cells: every step writes its cells (16 bytes per cell, the kernel's only per-cell output) into this buffer instead of the
         # engine's own scratch -- the same kernels, the same launches -- so that the LAST TIMED STEP's cells can be checked afterwards
         self.d_cells = torch.empty((n_tasks, eng.num_doppler, 4), dtype=torch.int32, device=dev) if (keep_cells and n_tasks > 0 and iq is None) else None
         self.sampler = None  # bench_extras.ClockSampler: sclk / power readings + cycle stamps during the timed steps of run()
         self.eng_stream = torch.cuda.ExternalStream(eng.stream_ptr, device=dev)
-        self.reader_done = [None, None]
+        self.reader_done = [None] * self.NBUF
         self.step_no = 0
 
     def step(self):
         torch, eng = self.torch, self.eng
-        slot = self.step_no & 1
+        slot = self.step_no % self.NBUF
         self.step_no += 1
         buf, best = self.d_peaks[slot], self.d_keys[slot]
         if self.n_tasks > 0:
@@ -404,7 +408,7 @@ def main():
     gpu_peaks = gpu_cells = None
     if check_parity:
         from oracle_lib import CELL_DTYPE as _CL, PEAK_DTYPE as _PK
-        gpu_peaks = leg.d_peaks[(leg.step_no - 1) & 1][:n_tasks].cpu().numpy().view(_PK).reshape(-1)
+        gpu_peaks = leg.d_peaks[(leg.step_no - 1) % leg.NBUF][:n_tasks].cpu().numpy().view(_PK).reshape(-1)
         gpu_cells = leg.d_cells.cpu().numpy().view(_CL).reshape(n_tasks, eng.num_doppler)
 
     side = world == 1 and n_tasks > 0 and args.soak_seconds > 0  # the N = 1 side legs

@@ -854,7 +854,10 @@ def build_line(c):
         ("tasks_per_rank" if c.grid else "blocks_per_rank"): c.blocks_per_rank, "devices_per_rank": c.devices,
         # What binds k_corr is the fp32 vector pipe, not HBM: the fused kernel keeps the IFFT intermediate in LDS and reads both spectra
         # from L2, so the algorithmic bytes of SURVEY 8(d) never reach HBM; VALU, LDS and L2 -> L1 are busy AT ONCE (co-limiters below).
-        "roofline": {"bound": "valu_fp32", "kernel": f"k_corr<{c.eng.acc_columns}>", "achieved": achieved_tf, "peak": FP32_VALU_PEAK_TF, "unit": "TFLOP/s",
+        "roofline": {"bound": "valu_fp32", "kernel": f"k_corr<{c.eng.acc_columns}>",
+                     "cell_handout": ("persistent workgroups draw (task, Doppler point) tickets at run time (gpsacq_set_cell_handout)"
+                                      if c.eng.cell_handout and not (c.eng.acc_columns == 40) else "one workgroup per cell"),
+                     "achieved": achieved_tf, "peak": FP32_VALU_PEAK_TF, "unit": "TFLOP/s",
                      "frac": achieved_tf / FP32_VALU_PEAK_TF, "flops_per_cell": fl, "flops_definition": "SURVEY.md 8(d): 6N + 5N log2 N + 5S",
                      "kernel_ms": c.kern_ms, "cells_per_launch": c.cells_rank, "kernel_cells_per_s": c.cells_rank / (c.kern_ms * 1e-3) if c.kern_ms else None,
                      "sclk_mhz": sclk, "sclk_mhz_xcd_min": (c.clock.get("sclk_mhz_xcd_min_max") or [None])[0] if c.clock else None,
@@ -953,7 +956,7 @@ def build_line(c):
     if c.world == 1 and not c.args.no_library_baseline and not c.grid and not c.iq8 and c.n_tasks >= 32:
         try:  # the same cells through the vendor FFT on this GPU
             from gpsacq import PEAK_DTYPE as _PK2
-            pk = c.leg.d_peaks[(c.leg.step_no - 1) & 1][:32].cpu().numpy().view(_PK2).reshape(-1)
+            pk = c.leg.d_peaks[(c.leg.step_no - 1) % c.leg.NBUF][:32].cpu().numpy().view(_PK2).reshape(-1)
             out["extras"]["gpu_library_baseline"] = gpu_library_baseline(c.torch, c.eng, c.dev, c.d_bits, c.stride, c.nblk, gpu_peaks=pk)
         except Exception as ex:
             out["extras"]["gpu_library_baseline"] = {"error": str(ex)[:300]}

@@ -246,6 +246,9 @@ class Engine:
         self._refresh_info()
         self.fc, self.fs, self.max_fo = float(fc), float(fs), float(max_fo)
         self._quirks = bool(ref_quirks)
+        # run-time hand-out of the correlate kernel's cells (gpsacq_set_cell_handout): on unless the environment said 0 at gpsacq_create
+        env = os.environ.get("GPSACQ_CORR_PERSIST", "")
+        self.cell_handout = not (env.lstrip("-+").isdigit() and int(env) == 0)
 
     def _refresh_info(self):
         info = Info()
@@ -274,6 +277,7 @@ class Engine:
         """Run-time hand-out of the correlate kernel's cells to persistent workgroups (default on) or one workgroup per cell
         (gpsacq_set_cell_handout): the same cells bit for bit, a different time."""
         _check(self._lib, self._lib.gpsacq_set_cell_handout(self._h, 1 if on else 0))
+        self.cell_handout = bool(on)
 
     def set_doppler_step(self, step_hz):
         """Doppler grid step in Hz: finer than fs/40000 through sub-bin spectra, coarser through a bin stride

@@ -21,6 +21,8 @@
  *   gpsacq_search_iq8        same on an 8-bit IQ capture: what proc_rtl_bin_for_gps.m / proc_hackrf_bin_for_gps.m + gps_test
  *                            do in two steps through a 1-bit file, fused into the forward transform
  *   gpsacq_set_doppler_step  the Doppler grid of Correlate()'s loop, :176,182 (finer or coarser than fs/40000)
+ *   gpsacq_set_cell_handout  how the iterations of Correlate()'s `for dop` loop (:176) and of SearchTask()'s `for sv` loop (:239) reach the
+ *                            compute units: drawn at run time by persistent workgroups (default) or one workgroup per cell; same results
  *   gpsacq_multi_search_grid the same Correlate() grid cut over several GPUs, peaks merged by one RCCL all-reduce
  *   gpsacq_multi_search_blocks  the SearchTask() run loop (:237-262) cut over several GPUs by whole runs, per-PRN best
  *                            peak merged by one RCCL all-reduce
