@@ -137,3 +137,26 @@ def test_environment_switch_and_repeated_launches(gpsacq_mod, golden_dir, monkey
             assert np.array_equal(d_pk[k].cpu().numpy().view(gpsacq_mod.PEAK_DTYPE).reshape(-1)[:n], ref_peaks[:n]), k
         cells, peaks = eng.search(buf)
         assert np.array_equal(cells, ref_cells) and np.array_equal(peaks, ref_peaks)
+
+
+@pytest.mark.parametrize("name,fc,fs,max_fo", [("gps_sig_tmp.bin", 2.046e6, 8.184e6, 5000.0), ("synth_nott_fs5456.bin", 4.092e6, 5.456e6, 5000.0),
+                                             ("synth_rtl_fs2800.bin", 0.62e6, 2.8e6, 100000.0)])
+def test_every_cell_is_written_exactly_where_it_belongs(gpsacq_mod, golden_dir, name, fc, fs, max_fo):
+    """The hand-out must give every (task, Doppler point) to exactly one workgroup: the cell buffer is poisoned (all bits set: NaN
+    powers, lag -1) in front of every search, so a cell nobody drew would stay poisoned and a cell computed for the wrong slot would
+    differ from the one-workgroup-per-cell result.  19 551 / 4672 / 94 281 cells for 768 workgroups; three searches each."""
+    import torch
+    buf = np.frombuffer(open(os.path.join(golden_dir, name), "rb").read(), dtype=np.uint8)
+    n = buf.size // 5120
+    dev = torch.device("cuda", 0)
+    d_bits = torch.from_numpy(buf[:n * 5120].copy()).to(dev)
+    with gpsacq_mod.Engine(fc, fs, max_fo) as eng:
+        def run(e):
+            d_cells = torch.full((n, e.num_doppler, 4), -1, dtype=torch.int32, device=dev)
+            d_pk = torch.full((n, 4), -1, dtype=torch.int32, device=dev)
+            torch.cuda.synchronize()
+            e.search_device(d_bits.data_ptr(), n, d_pk.data_ptr(), d_cells_ptr=d_cells.data_ptr(), sync=True)
+            c = d_cells.cpu().numpy().view(gpsacq_mod.CELL_DTYPE).reshape(n, e.num_doppler)
+            assert (c["max_i"] >= 0).all() and np.isfinite(c["max_pwr"]).all() and np.isfinite(c["tot_pwr"]).all() and (c["tot_pwr"] > 0).all()
+            return c, d_pk.cpu().numpy().view(gpsacq_mod.PEAK_DTYPE).reshape(-1)
+        _both(eng, run)
