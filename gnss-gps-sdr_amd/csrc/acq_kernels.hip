@@ -251,7 +251,7 @@ template <class L> __device__ __forceinline__ int corr_rho(const CorrArgs& a, in
 // static stride loses it: 24 % slower, profiles/r05_experiments/f_persistent_workgroups.log).  What changes: an XCD takes work at its
 // own pace -- under the power cap the XCDs of a package run 3-5 % apart and the fixed deal block g -> XCD g % 8
 // moves at the slowest one's, through an in-order dispatcher that leaves slots of the others empty meanwhile -- and a CU never waits
-// for a workgroup to be dispatched.  -1.3 ... -4.4 % kernel time by box on configs[1], -4 ... -5 % on configs[2-4] (profiles/r06_experiments/a_persistent_stealing.log).
+// for a workgroup to be dispatched.  -1.7 ... -4.4 % kernel time by box on configs[1] (profiles/r06_experiments/a_persistent_stealing.log).
 // The ticket is drawn before the peak scan and travels to the other threads through the reduction's LDS slots and barrier.
 template <int MC, int WPS, int NB, bool NC, bool W1H = false, class L = LayC, bool NCREG = false, bool FOLD = false, bool PERSIST = false>
 __global__ __launch_bounds__(WG, WPS) void k_corr(CorrArgs a) {
