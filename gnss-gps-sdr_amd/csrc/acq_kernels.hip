@@ -286,8 +286,9 @@ __global__ __launch_bounds__(WG, WPS) void k_corr(CorrArgs a) {
     // of the slot's other tickets find it published: unit u = the next of ONE global counter = chunk u % units of task u / units.
     auto draw_ticket = [&]() __attribute__((always_inline)) {
         const int t = __hip_atomic_fetch_add(KA(persist_queue) + 16 * my_xcd, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        const int s = t / KA(persist_chunk);
-        if (t == s * KA(persist_chunk) && s < KA(persist_slots)) {
+        int s, j;
+        handout_ticket(t, KA(persist_chunk), s, j);
+        if (j == 0 && s < KA(persist_slots)) {
             const int u = __hip_atomic_fetch_add(KA(persist_queue) + 16 * 8, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             __hip_atomic_store(KA(persist_tasks) + (size_t)my_xcd * KA(persist_slots) + s, u + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         }
@@ -296,15 +297,15 @@ __global__ __launch_bounds__(WG, WPS) void k_corr(CorrArgs a) {
     // the (task, Doppler point) a ticket stands for; a ticket past the last point of a task's last chunk is void: draw again
     auto task_of_ticket = [&](int ticket, int& di_out) __attribute__((always_inline)) {
         for (;;) {
-            const int s = ticket / KA(persist_chunk), j = ticket - s * KA(persist_chunk);
-            if (s >= KA(persist_slots)) return KA(n_tasks);  // (cannot happen: an XCD draws at most every unit + one ticket per workgroup)
+            int s, j, t;
+            handout_ticket(ticket, KA(persist_chunk), s, j);
+            if (s >= KA(persist_slots)) return KA(n_tasks);  // (cannot happen: handout_slots)
             int* const slot = KA(persist_tasks) + (size_t)my_xcd * KA(persist_slots) + s;
             int u1;  // (the slot's first ticket was drawn before this one, by a workgroup that published the unit in the same breath)
             while ((u1 = __hip_atomic_load(slot, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) == 0) __builtin_amdgcn_s_sleep(1);
-            const int u = u1 - 1, t = u / KA(persist_units), c = u - t * KA(persist_units);
-            if (t >= KA(n_tasks)) return KA(n_tasks);
-            di_out = c * KA(persist_chunk) + j;
-            if (di_out < KA(ndop)) return t;
+            const int kind = handout_cell(u1 - 1, j, KA(persist_units), KA(persist_chunk), KA(ndop), KA(n_tasks), t, di_out);
+            if (kind < 0) return KA(n_tasks);
+            if (kind > 0) return t;
             ticket = draw_ticket();
         }
     };

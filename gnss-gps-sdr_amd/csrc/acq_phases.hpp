@@ -203,6 +203,35 @@ ACQ_HD void grid_point(int k, int sub, int dstride, int& dop, int& r) {
     }
 }
 
+// ---- run-time hand-out of cells to persistent workgroups (k_corr<..., PERSIST>): the index arithmetic, shared by the kernel, the
+// engine that sizes the hand-out state and the CPU emulation that walks the protocol (tests/emul) ----
+// The unit of work an XCD takes from the global counter is a chunk of one task's Doppler points: the whole task up to 146 points (the
+// reference's grids: 73 / 49 / 143 bins), else chunks of ~128, so that a few tasks of thousands of points still spread evenly.
+struct Handout {
+    int units;  // units per task
+    int chunk;  // Doppler points per unit (the task's last unit may hold fewer: tickets past its end are void)
+};
+ACQ_HD Handout handout_plan(int ndop) {
+    Handout h;
+    h.units = ndop <= 146 ? 1 : (ndop + 127) / 128;
+    h.chunk = (ndop + h.units - 1) / h.units;
+    return h;
+}
+// unit slots per XCD: an XCD draws at most every unit, and its tickets run past the last one by at most one per workgroup
+ACQ_HD long handout_slots(long n_tasks, int units, int wgs) { return n_tasks * units + wgs + 2; }
+// ticket t of an XCD's counter: point j of the XCD's slot-th unit
+ACQ_HD void handout_ticket(int ticket, int chunk, int& slot, int& j) {
+    slot = ticket / chunk;
+    j = ticket - slot * chunk;
+}
+// point j of global unit u: the cell (task, di).  1: a cell; 0: void (past the task's last point); -1: past the last task
+ACQ_HD int handout_cell(int u, int j, int units, int chunk, int ndop, int n_tasks, int& task, int& di) {
+    task = u / units;
+    if (task >= n_tasks) return -1;
+    di = (u - task * units) * chunk + j;
+    return di < ndop ? 1 : 0;
+}
+
 // Peak scan over the first S lags (:190-194), this thread's share, ascending n.
 template <int MC>
 ACQ_HD void corr_scan(int tid, int rho, int S, int m0, const cf* acc, float& mx, int& mi, float& sum) {

@@ -547,10 +547,9 @@ static int arm_persist(gpsacq_engine* e, CorrArgs& ca, int mc) {
     const bool three_per_cu = ca.n_acc == 1 || (mc == 12 && ca.creep == 0.f && ca.lag_step == 0);
     if (!e->persist || !three_per_cu || ca.pdump || !corr_has_persistent_form(mc)) return GPSACQ_OK;
     const int wgs = 3 * e->cus;
-    // the hand-out unit: a chunk of one task's Doppler points -- the whole task up to 146 points (the reference's grids), else ~128
-    const int units = ca.ndop <= 146 ? 1 : (ca.ndop + 127) / 128;
-    const int chunk = (ca.ndop + units - 1) / units;
-    const size_t slots = (size_t)ca.n_tasks * (size_t)units + (size_t)wgs + 2;  // an XCD's tickets run past the last unit by at most one per workgroup
+    const Handout plan = handout_plan(ca.ndop);  // the unit of the hand-out: a task, or a ~128-point chunk of one (acq_phases.hpp)
+    const int units = plan.units, chunk = plan.chunk;
+    const size_t slots = (size_t)handout_slots((long)ca.n_tasks, units, wgs);
     if (slots > 0x7fffffffu / 8) return GPSACQ_OK;  // (a batch too large for the slot table: one workgroup per cell)
     const size_t ints = 9 * 16 + 8 * slots;
     if (int rc = grow(e->d_persist, e->persist_cap, ints, e->stream)) return rc;

@@ -242,6 +242,79 @@ void emul_ca_chips(int sv, unsigned char* chips /*[1023]*/) {
         ca.clock();
     }
 }
+// The run-time hand-out of k_corr<..., PERSIST> (acq_kernels.hip draw_ticket / task_of_ticket), walked on the CPU with the product's own
+// index arithmetic (acq_phases.hpp handout_*): `wgs` workgroups spread over n_xcd XCDs, each a state machine -- draw a ticket from its
+// XCD's counter; if the ticket opens a unit slot, take the next unit of the global counter and publish it (a SEPARATE step: another
+// workgroup may look at the slot in between and has to wait, like the kernel's spin); resolve the ticket to a cell, a void or the end --
+// scheduled one step at a time in a seeded random order (skew > 0: XCD x is picked (1 + skew x) times as often -- XCDs of different
+// speeds).  counts[task * ndop + di] is incremented per cell handed out.  stats: [0] cells, [1] void tickets, [2] waits on an
+// unpublished slot, [3] largest slot index used + 1, [4] handout_slots bound, [5] units taken by XCD 0, [6] by the last XCD.
+// Returns 0, or 1 if a slot index reached the bound, 2 if the walk did not end within its step budget.
+int emul_handout_walk(int n_tasks, int ndop, int wgs, int n_xcd, unsigned seed, int skew, unsigned* counts, long* stats) {
+    const Handout h = handout_plan(ndop);
+    const long slots = handout_slots(n_tasks, h.units, wgs);
+    std::vector<int> ticket_ctr(n_xcd, 0);
+    std::vector<int> table((size_t)n_xcd * slots, 0);
+    std::vector<long> units_of(n_xcd, 0);
+    int next_unit = 0;
+    struct Wg { int xcd, state, ticket; };  // state 0 draw, 1 publish, 2 resolve, 3 gone
+    std::vector<Wg> wg(wgs);
+    for (int w = 0; w < wgs; ++w) wg[w] = Wg{w % n_xcd, 0, 0};
+    unsigned long long rng = seed * 2654435761ull + 88172645463325252ull;
+    auto rnd = [&]() { rng ^= rng << 13; rng ^= rng >> 7; rng ^= rng << 17; return (unsigned)(rng >> 11); };
+    long cells = 0, voids = 0, waits = 0, max_slot = 0, alive = wgs;
+    const long budget = 64L * ((long)n_tasks * ndop + wgs) + 100000;
+    for (long step = 0; alive > 0; ++step) {
+        if (step > budget) return 2;
+        int w = (int)(rnd() % (unsigned)wgs);
+        if (skew > 0 && (int)(rnd() % (unsigned)(1 + skew * (n_xcd - 1))) >= 1 + skew * wg[w].xcd) continue;  // slower XCDs are scheduled less often
+        Wg& g = wg[w];
+        if (g.state == 3) continue;
+        int slot, j;
+        if (g.state == 0) {
+            g.ticket = ticket_ctr[g.xcd]++;
+            handout_ticket(g.ticket, h.chunk, slot, j);
+            g.state = (j == 0 && slot < slots) ? 1 : 2;
+            continue;
+        }
+        handout_ticket(g.ticket, h.chunk, slot, j);
+        if (slot >= slots) return 1;
+        if (slot + 1 > max_slot) max_slot = slot + 1;
+        if (g.state == 1) {
+            table[(size_t)g.xcd * slots + slot] = ++next_unit;  // unit + 1
+            units_of[g.xcd]++;
+            g.state = 2;
+            continue;
+        }
+        const int u1 = table[(size_t)g.xcd * slots + slot];
+        if (u1 == 0) {
+            ++waits;
+            continue;
+        }
+        int task, di;
+        const int kind = handout_cell(u1 - 1, j, h.units, h.chunk, ndop, n_tasks, task, di);
+        if (kind < 0) {
+            g.state = 3;
+            --alive;
+        } else if (kind == 0) {
+            ++voids;
+            g.state = 0;
+        } else {
+            counts[(size_t)task * ndop + di]++;
+            ++cells;
+            g.state = 0;
+        }
+    }
+    stats[0] = cells; stats[1] = voids; stats[2] = waits; stats[3] = max_slot; stats[4] = slots;
+    stats[5] = units_of[0]; stats[6] = units_of[n_xcd - 1];
+    return 0;
+}
+int emul_handout_plan(int ndop, int* units, int* chunk) {
+    const Handout h = handout_plan(ndop);
+    *units = h.units;
+    *chunk = h.chunk;
+    return 0;
+}
 int emul_dmax(double fs, double max_fo) { return doppler_half_range(fs, max_fo); }
 int emul_nlags(double fs) { return num_lags(fs); }
 }

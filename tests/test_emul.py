@@ -28,6 +28,8 @@ def emul():
     E.emul_lo_masks.argtypes = [d, d, vp, vp]
     E.emul_search_code.argtypes = [i, i]
     E.emul_ca_chips.argtypes = [i, vp]
+    E.emul_handout_walk.argtypes = [i, i, i, i, ctypes.c_uint, i, vp, vp]
+    E.emul_handout_plan.argtypes = [i, vp, vp]
     E.emul_dmax.argtypes = [d, d]
     E.emul_nlags.argtypes = [d]
     return E
@@ -150,3 +152,37 @@ def test_lane_maps_are_bank_conflict_free_in_the_lds_model(emul):
     assert out[2][1] <= 20 and out[2][0] <= 1462
     assert [emul.emul_pass3_rho(2, t) for t in range(250)] == lds_maps.make_rho_c()  # the committed table is the generator's
 
+
+
+def test_handout_plan_of_the_baseline_grids(emul):
+    """acq_phases.hpp handout_plan: the reference's grids (73 / 49 / 143 bins) are one unit per task; fine grids are cut into chunks of
+    <= 128 points that cover the task with fewer void tickets than units."""
+    u, c = ctypes.c_int(), ctypes.c_int()
+    for ndop, units, chunk in ((1, 1, 1), (49, 1, 49), (73, 1, 73), (143, 1, 143), (146, 1, 146), (147, 2, 74), (219, 2, 110), (953, 8, 120), (2857, 23, 125), (4399, 35, 126)):
+        emul.emul_handout_plan(ndop, ctypes.byref(u), ctypes.byref(c))
+        assert (u.value, c.value) == (units, chunk), ndop
+        assert c.value <= 146 and units * chunk >= ndop and units * chunk - ndop < units
+
+
+@pytest.mark.parametrize("n_tasks,ndop,wgs,n_xcd,skew", [(340, 73, 768, 8, 0), (64, 73, 768, 8, 3), (1, 73, 768, 8, 0), (5, 1, 96, 8, 1), (12, 2857, 768, 8, 2),
+                                                        (128, 953, 768, 8, 0), (7, 4399, 768, 8, 5), (3, 147, 24, 3, 0), (40, 49, 768, 1, 0), (1000, 3, 50, 8, 4)])
+def test_handout_gives_every_cell_to_exactly_one_workgroup(emul, n_tasks, ndop, wgs, n_xcd, skew):
+    """The hand-out of k_corr<..., PERSIST> walked on the CPU with the product's index arithmetic, workgroups scheduled in random order
+    (several seeds; XCDs of unequal speed): every (task, Doppler point) is handed out exactly once, every workgroup leaves, the slot
+    table's bound holds, a faster XCD ends up with more units, and waits on an unpublished slot do occur (the kernel's spin is needed)."""
+    total_waits = 0
+    for seed in range(4):
+        counts = np.zeros(n_tasks * ndop, np.uint32)
+        stats = np.zeros(8, np.int64)
+        rc = emul.emul_handout_walk(n_tasks, ndop, wgs, n_xcd, seed, skew, counts.ctypes.data_as(ctypes.c_void_p), stats.ctypes.data_as(ctypes.c_void_p))
+        assert rc == 0, (rc, seed)
+        assert (counts == 1).all(), (seed, int((counts != 1).sum()))
+        assert stats[0] == n_tasks * ndop and stats[3] <= stats[4]
+        u, c = ctypes.c_int(), ctypes.c_int()
+        emul.emul_handout_plan(ndop, ctypes.byref(u), ctypes.byref(c))
+        assert stats[1] >= 0 and (u.value * c.value == ndop or stats[1] > 0 or n_tasks == 0)
+        if skew >= 3 and n_xcd == 8 and n_tasks * u.value >= 64:
+            assert stats[6] > stats[5], (int(stats[5]), int(stats[6]))  # the XCD scheduled most often took more units than the slowest
+        total_waits += int(stats[2])
+    if n_tasks * ndop > 4 * wgs and n_xcd > 1:
+        assert total_waits > 0
