@@ -325,7 +325,7 @@ extern "C" int gpsacq_create(const gpsacq_params* params, gpsacq_engine** out) {
     e->cus = prop.multiProcessorCount;
     {
         const char* pe = getenv("GPSACQ_CORR_PERSIST");  // 0: one workgroup per cell (A/B runs)
-        e->persist = !(pe && atoi(pe) == 0);
+        e->persist = !(pe && pe[0] == '0' && pe[1] == 0);  // exactly "0"
     }
     snprintf(e->name, sizeof e->name, "%s", prop.name);
 #define HCK(expr)                                                                     \

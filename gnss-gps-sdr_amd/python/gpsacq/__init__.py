@@ -247,8 +247,7 @@ class Engine:
         self.fc, self.fs, self.max_fo = float(fc), float(fs), float(max_fo)
         self._quirks = bool(ref_quirks)
         # run-time hand-out of the correlate kernel's cells (gpsacq_set_cell_handout): on unless the environment said 0 at gpsacq_create
-        env = os.environ.get("GPSACQ_CORR_PERSIST", "")
-        self.cell_handout = not (env.lstrip("-+").isdigit() and int(env) == 0)
+        self.cell_handout = os.environ.get("GPSACQ_CORR_PERSIST") != "0"
 
     def _refresh_info(self):
         info = Info()
